@@ -1,0 +1,128 @@
+/*
+ * nolzss_hip.h -- C ABI of libnolzss_hip.so, the MI355X (gfx950) drop-in for the compiled core
+ * of OmerKerner/noLZSS on the factorize path.
+ *
+ * Each entry point replaces one function that the reference's pybind11 module `_noLZSS`
+ * (reference: src/cpp/bindings.cpp) binds for this path; the citation next to a declaration
+ * names the reference interface it stands in for.  Plain pointers and sizes only: no C++,
+ * pybind or torch types cross this boundary.  INTEGRATION.md shows the pybind11 / ctypes stub
+ * a maintainer of the reference would add to bind these.
+ *
+ * Conventions
+ *   - every function returns a status code (NOLZSS_OK == 0); on failure
+ *     nolzss_last_error() returns a thread-local message.  NOLZSS_ERR_INVALID_ARGUMENT maps to
+ *     the reference's std::invalid_argument (Python ValueError), NOLZSS_ERR_RUNTIME to
+ *     std::runtime_error (RuntimeError)  -- bindings.cpp relies on pybind11's default mapping.
+ *   - input buffers are borrowed for the duration of the call (bindings.cpp:66-67);
+ *   - output arrays are allocated by the library and released with nolzss_free();
+ *   - `device` is a HIP device ordinal; the library keeps one context (stream + device arena)
+ *     per device and serialises calls on it, so calls are safe from any host thread
+ *     (the reference releases the GIL around compute, bindings.cpp:70).
+ *   - there is NO CPU fallback: without a usable GPU every compute entry point fails with
+ *     NOLZSS_ERR_DEVICE.
+ */
+#ifndef NOLZSS_HIP_H
+#define NOLZSS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* reference: struct Factor, src/cpp/factorizer.hpp:147-151 (24-byte POD, also the on-disk record) */
+typedef struct nolzss_factor {
+    uint64_t start;
+    uint64_t length;
+    uint64_t ref;
+} nolzss_factor;
+
+/* reference: RC_MASK, src/cpp/factorizer.hpp:41 */
+#define NOLZSS_RC_MASK (1ULL << 63)
+
+enum {
+    NOLZSS_OK = 0,
+    NOLZSS_ERR_INVALID_ARGUMENT = 1,
+    NOLZSS_ERR_RUNTIME = 2,
+    NOLZSS_ERR_NOMEM = 3,
+    NOLZSS_ERR_DEVICE = 4,
+    NOLZSS_ERR_IO = 5
+};
+
+const char *nolzss_last_error(void);
+/* reference: m.attr("__version__"), bindings.cpp:1513-1517 */
+const char *nolzss_version(void);
+void nolzss_free(void *p);
+int nolzss_device_count(int *count);
+
+/* ---- plain mode ------------------------------------------------------------------------ */
+/* reference: noLZSS::factorize(string_view, start_pos), factorizer.cpp:378-384;
+ *            bound as _noLZSS.factorize, bindings.cpp:56-77 */
+int nolzss_factorize(const uint8_t *text, size_t n, size_t start_pos, int device,
+                     nolzss_factor **out, size_t *z);
+/* reference: noLZSS::count_factors, factorizer.cpp:337-343; bindings.cpp:122-141 */
+int nolzss_count_factors(const uint8_t *text, size_t n, size_t start_pos, int device, size_t *z);
+/* reference: noLZSS::factorize_file, factorizer.cpp:401-406; bindings.cpp:96-105 */
+int nolzss_factorize_file(const char *path, size_t start_pos, int device, nolzss_factor **out,
+                          size_t *z);
+/* reference: noLZSS::count_factors_file, factorizer.cpp:359-363; bindings.cpp:157-164 */
+int nolzss_count_factors_file(const char *path, size_t start_pos, int device, size_t *z);
+
+/* Same computation with the text already resident in device memory (d_text is a device
+ * pointer on `device`); `stream` is a hipStream_t or NULL for the context's own stream.
+ * out_host may be NULL (count only).  Used by bench.py (inputs resident in HBM when the clock
+ * starts) and by the multi-GPU shard dispatcher. */
+int nolzss_factorize_device(const void *d_text, size_t n, size_t start_pos, int device,
+                            void *stream, nolzss_factor **out_host, size_t *z);
+
+/* ---- reverse-complement DNA mode ---------------------------------------------------------- */
+/* reference: prepare_multiple_dna_sequences_w_rc, factorizer.cpp:54-172; bindings.cpp:732-740.
+ * S (malloc'ed, may hold any byte value) = T1 s0 ... Tk s(k-1) rc(Tk) sk ... rc(T1) s(2k-1). */
+int nolzss_prepare_multiple_dna_w_rc(const char *const *seqs, const size_t *lens, size_t k,
+                                     uint8_t **S, size_t *S_len, size_t *original_length,
+                                     uint64_t **sentinel_positions, size_t *n_sentinels);
+/* reference: noLZSS::factorize_multiple_dna_w_rc, factorizer.cpp:651-656 over
+ *            detail::nolzss_multiple_dna_w_rc, factorizer_core.hpp:177-383; bindings.cpp:361-382 */
+int nolzss_factorize_multiple_dna_w_rc(const uint8_t *S, size_t S_len, size_t start_pos,
+                                       int device, nolzss_factor **out, size_t *z);
+/* reference: count_factors_multiple_dna_w_rc, factorizer.cpp:700-705; bindings.cpp:427-446 */
+int nolzss_count_factors_multiple_dna_w_rc(const uint8_t *S, size_t S_len, size_t start_pos,
+                                           int device, size_t *z);
+/* reference: noLZSS::factorize_dna_w_rc, factorizer.cpp:519-523; bindings.cpp:207-228 */
+int nolzss_factorize_dna_w_rc(const uint8_t *text, size_t n, int device, nolzss_factor **out,
+                              size_t *z);
+/* reference: noLZSS::count_factors_dna_w_rc, factorizer.cpp:559-561; bindings.cpp:276-295 */
+int nolzss_count_factors_dna_w_rc(const uint8_t *text, size_t n, int device, size_t *z);
+
+/* ---- per-sequence batch (the FASTA shard unit) ------------------------------------------- */
+/* reference: the per-sequence factorize() loop of genomics.read_nucleotide_fasta,
+ *            src/noLZSS/genomics/fasta.py:110-122 (C++ analogue:
+ *            parallel_fasta_processor.cpp:360-385).  Sequence j is factorized on
+ *            devices[j % n_dev]-th device of the list in longest-first order; out[j] / z[j]
+ *            are per sequence (out may be NULL for counts only).  Free with
+ *            nolzss_free_batch(). */
+int nolzss_factorize_batch(const uint8_t *const *texts, const size_t *lens, size_t m,
+                           const int *devices, size_t n_dev, nolzss_factor ***out, size_t **z);
+void nolzss_free_batch(nolzss_factor **out, size_t *z, size_t m);
+
+/* ---- measurement hooks -------------------------------------------------------------------- */
+/* HIP-event timing of every pipeline stage on the context's stream (off by default). */
+int nolzss_profile_enable(int device, int on);
+int nolzss_profile_reset(int device);
+/* Writes lines "name count total_ms\n" into buf (NUL-terminated, truncated to cap). */
+int nolzss_profile_report(int device, char *buf, size_t cap);
+
+/* ---- introspection used by the parity tests of the intermediate arrays -------------------- */
+/* Any output pointer may be NULL.  sa/isa/lstar: n entries; lcp: n + 1 entries. */
+int nolzss_debug_arrays(const uint8_t *text, size_t n, int device, uint32_t *sa, uint32_t *isa,
+                        uint32_t *lcp, uint32_t *lstar);
+/* Sorts n (key, value) pairs in place on the device by all 64 key bits (stable). */
+int nolzss_debug_sort_pairs(uint64_t *keys, uint32_t *vals, size_t n, int device);
+/* mode 0: exclusive add-scan, mode 1: inclusive max-scan, in place. */
+int nolzss_debug_scan(uint32_t *data, size_t n, int mode, int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NOLZSS_HIP_H */

@@ -1,0 +1,84 @@
+"""Loader for libnolzss_hip.so, the gfx950 library behind this package.
+
+There is deliberately no fallback: if the shared library is missing or cannot be loaded the
+import fails loudly, and if no MI355X is visible every compute call raises (the library
+returns NOLZSS_ERR_DEVICE).  Nothing in this package computes factors on the CPU.
+"""
+import ctypes as C
+from pathlib import Path
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "libnolzss_hip.so"
+
+OK, ERR_INVALID_ARGUMENT, ERR_RUNTIME, ERR_NOMEM, ERR_DEVICE, ERR_IO = range(6)
+
+
+class Factor(C.Structure):
+    """Mirror of nolzss_factor / the reference's struct Factor (factorizer.hpp:147-151)."""
+    _fields_ = [("start", C.c_uint64), ("length", C.c_uint64), ("ref", C.c_uint64)]
+
+
+def _load():
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} not found: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C nolzss_amd/csrc). "
+            "nolzss_amd has no CPU fallback.")
+    lib = C.CDLL(str(LIB_PATH))
+    vp, sz = C.c_void_p, C.c_size_t
+    szp, vpp = C.POINTER(C.c_size_t), C.POINTER(C.c_void_p)
+    lib.nolzss_last_error.restype = C.c_char_p
+    lib.nolzss_version.restype = C.c_char_p
+    lib.nolzss_free.argtypes = [vp]
+    lib.nolzss_free.restype = None
+    lib.nolzss_device_count.argtypes = [C.POINTER(C.c_int)]
+    lib.nolzss_factorize.argtypes = [vp, sz, sz, C.c_int, vpp, szp]
+    lib.nolzss_count_factors.argtypes = [vp, sz, sz, C.c_int, szp]
+    lib.nolzss_factorize_file.argtypes = [C.c_char_p, sz, C.c_int, vpp, szp]
+    lib.nolzss_count_factors_file.argtypes = [C.c_char_p, sz, C.c_int, szp]
+    lib.nolzss_factorize_device.argtypes = [vp, sz, sz, C.c_int, vp, vpp, szp]
+    lib.nolzss_prepare_multiple_dna_w_rc.argtypes = [
+        C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), sz, vpp, szp, szp, vpp, szp]
+    lib.nolzss_factorize_multiple_dna_w_rc.argtypes = [vp, sz, sz, C.c_int, vpp, szp]
+    lib.nolzss_count_factors_multiple_dna_w_rc.argtypes = [vp, sz, sz, C.c_int, szp]
+    lib.nolzss_factorize_dna_w_rc.argtypes = [vp, sz, C.c_int, vpp, szp]
+    lib.nolzss_count_factors_dna_w_rc.argtypes = [vp, sz, C.c_int, szp]
+    lib.nolzss_factorize_batch.argtypes = [
+        C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), sz, C.POINTER(C.c_int), sz,
+        C.POINTER(C.POINTER(C.c_void_p)), C.POINTER(C.POINTER(C.c_size_t))]
+    lib.nolzss_free_batch.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), sz]
+    lib.nolzss_free_batch.restype = None
+    lib.nolzss_profile_enable.argtypes = [C.c_int, C.c_int]
+    lib.nolzss_profile_reset.argtypes = [C.c_int]
+    lib.nolzss_profile_report.argtypes = [C.c_int, C.c_char_p, sz]
+    lib.nolzss_debug_arrays.argtypes = [vp, sz, C.c_int, vp, vp, vp, vp]
+    lib.nolzss_debug_sort_pairs.argtypes = [vp, vp, sz, C.c_int]
+    lib.nolzss_debug_scan.argtypes = [vp, sz, C.c_int, C.c_int]
+    return lib
+
+
+lib = _load()
+
+EXPORTED_SYMBOLS = [
+    "nolzss_last_error", "nolzss_version", "nolzss_free", "nolzss_device_count",
+    "nolzss_factorize", "nolzss_count_factors", "nolzss_factorize_file", "nolzss_count_factors_file",
+    "nolzss_factorize_device", "nolzss_prepare_multiple_dna_w_rc",
+    "nolzss_factorize_multiple_dna_w_rc", "nolzss_count_factors_multiple_dna_w_rc",
+    "nolzss_factorize_dna_w_rc", "nolzss_count_factors_dna_w_rc", "nolzss_factorize_batch",
+    "nolzss_free_batch", "nolzss_profile_enable", "nolzss_profile_reset", "nolzss_profile_report",
+    "nolzss_debug_arrays", "nolzss_debug_sort_pairs", "nolzss_debug_scan",
+]
+
+
+def check(rc):
+    """Map a status code to the exception the reference's pybind11 module would raise
+    (std::invalid_argument -> ValueError, std::runtime_error -> RuntimeError;
+    reference: src/cpp/bindings.cpp default exception translation)."""
+    if rc == OK:
+        return
+    msg = lib.nolzss_last_error().decode("utf-8", "replace")
+    if rc == ERR_INVALID_ARGUMENT:
+        raise ValueError(msg)
+    if rc == ERR_NOMEM:
+        raise MemoryError(msg)
+    raise RuntimeError(msg)

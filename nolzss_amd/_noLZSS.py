@@ -1,0 +1,311 @@
+"""Python-visible surface of the reference's compiled module `noLZSS._noLZSS`
+(reference: src/cpp/bindings.cpp), bound to libnolzss_hip.so through ctypes.
+
+Same names, argument meaning, return shapes and error behaviour as the pybind11 module for the
+factorize path; ctypes releases the GIL around every native call just as the reference does
+with gil_scoped_release (bindings.cpp:70).  Functions of `_noLZSS` that are outside the hot
+path exist (so `from ._noLZSS import ...` keeps working for code written against the
+reference) and raise NotImplementedError when called.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import lib, check
+
+__version__ = lib.nolzss_version().decode()
+
+RC_MASK = 1 << 63
+FACTOR_DTYPE = np.dtype([("start", "<u8"), ("length", "<u8"), ("ref", "<u8")])
+
+_default_device = int(os.environ.get("NOLZSS_DEVICE", os.environ.get("LOCAL_RANK", "0")) or 0)
+
+
+def set_device(device: int) -> None:
+    """Select the HIP device used by the calls below (extension; default LOCAL_RANK or 0)."""
+    global _default_device
+    _default_device = int(device)
+
+
+def get_device() -> int:
+    return _default_device
+
+
+class Factor:
+    """reference: py::class_<Factor>, bindings.cpp:44-48"""
+    __slots__ = ("start", "length", "ref")
+
+    def __init__(self, start=0, length=0, ref=0):
+        self.start, self.length, self.ref = start, length, ref
+
+
+def _as_buffer(data):
+    """1-D, itemsize-1 buffer -> (address, nbytes, keepalive)  (bindings.cpp:59-67)."""
+    try:
+        mv = memoryview(data)
+    except TypeError:
+        raise TypeError(f"a bytes-like object is required, not '{type(data).__name__}'")
+    if mv.itemsize != 1 or mv.ndim != 1:
+        raise ValueError("data must be a 1-dimensional bytes-like object")
+    if not mv.c_contiguous:
+        mv = memoryview(bytes(mv))
+    arr = np.frombuffer(mv, dtype=np.uint8)
+    return arr.ctypes.data, arr.size, arr
+
+
+def _take(ptr, z):
+    """library-owned factor array -> numpy structured array (copied), then free."""
+    if not ptr.value:
+        return np.zeros(0, dtype=FACTOR_DTYPE)
+    try:
+        raw = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint64)), shape=(z * 3,)).copy()
+    finally:
+        lib.nolzss_free(ptr)
+    return raw.view(FACTOR_DTYPE)
+
+
+def _tuples3(f):
+    return list(zip(f["start"].tolist(), f["length"].tolist(), f["ref"].tolist()))
+
+
+def _tuples4(f):
+    ref = f["ref"]
+    is_rc = (ref >> np.uint64(63)).astype(bool)
+    clean = ref & np.uint64(RC_MASK - 1)
+    return list(zip(f["start"].tolist(), f["length"].tolist(), clean.tolist(), is_rc.tolist()))
+
+
+# ---- plain mode --------------------------------------------------------------------------
+def factorize_array(data, start_pos: int = 0) -> np.ndarray:
+    """Extension: factors as a numpy structured array (start, length, ref), no tuple building."""
+    p, n, keep = _as_buffer(data)
+    out, z = C.c_void_p(), C.c_size_t()
+    check(lib.nolzss_factorize(p, n, start_pos, _default_device, C.byref(out), C.byref(z)))
+    return _take(out, z.value)
+
+
+def factorize(data):
+    """reference: m.def("factorize"), bindings.cpp:56-77 -> list[(start, length, ref)]"""
+    return _tuples3(factorize_array(data))
+
+
+def count_factors(data) -> int:
+    """reference: m.def("count_factors"), bindings.cpp:122-141"""
+    p, n, keep = _as_buffer(data)
+    z = C.c_size_t()
+    check(lib.nolzss_count_factors(p, n, 0, _default_device, C.byref(z)))
+    return z.value
+
+
+def factorize_file(path: str, reserve_hint: int = 0):
+    """reference: m.def("factorize_file"), bindings.cpp:96-105 (reserve_hint is a host-vector
+    hint in the reference and has no effect here)."""
+    out, z = C.c_void_p(), C.c_size_t()
+    check(lib.nolzss_factorize_file(os.fsencode(path), 0, _default_device, C.byref(out), C.byref(z)))
+    return _tuples3(_take(out, z.value))
+
+
+def count_factors_file(path: str) -> int:
+    """reference: m.def("count_factors_file"), bindings.cpp:157-164"""
+    z = C.c_size_t()
+    check(lib.nolzss_count_factors_file(os.fsencode(path), 0, _default_device, C.byref(z)))
+    return z.value
+
+
+def factorize_device(data_ptr: int, n: int, stream: int = 0, want_factors: bool = True, start_pos: int = 0):
+    """Extension used by bench.py / the shard dispatcher: the text is already in HBM
+    (data_ptr = device address, e.g. torch.Tensor.data_ptr()).  Returns (z, factors-or-None)."""
+    out, z = C.c_void_p(), C.c_size_t()
+    check(lib.nolzss_factorize_device(data_ptr, n, start_pos, _default_device, stream or None,
+                                      C.byref(out) if want_factors else None, C.byref(z)))
+    return z.value, (_take(out, z.value) if want_factors else None)
+
+
+def factorize_batch(texts, devices=None, want_factors: bool = True):
+    """Extension: the per-sequence shard unit of read_nucleotide_fasta
+    (reference: genomics/fasta.py:110-122).  Returns (counts, [factor arrays] or None)."""
+    devices = list(devices) if devices is not None else [_default_device]
+    bufs = [_as_buffer(t) for t in texts]
+    m = len(bufs)
+    ptrs = (C.c_void_p * max(m, 1))(*[b[0] for b in bufs])
+    lens = (C.c_size_t * max(m, 1))(*[b[1] for b in bufs])
+    devs = (C.c_int * len(devices))(*devices)
+    out = C.POINTER(C.c_void_p)()
+    zs = C.POINTER(C.c_size_t)()
+    check(lib.nolzss_factorize_batch(ptrs, lens, m, devs, len(devices),
+                                     C.byref(out) if want_factors else None, C.byref(zs)))
+    try:
+        counts = [zs[j] for j in range(m)]
+        arrays = None
+        if want_factors:
+            arrays = []
+            for j in range(m):
+                if counts[j] == 0 or not out[j]:
+                    arrays.append(np.zeros(0, dtype=FACTOR_DTYPE))
+                else:
+                    raw = np.ctypeslib.as_array(C.cast(out[j], C.POINTER(C.c_uint64)), shape=(counts[j] * 3,))
+                    arrays.append(raw.copy().view(FACTOR_DTYPE))
+    finally:
+        lib.nolzss_free_batch(out if want_factors else None, zs, m)
+    return counts, arrays
+
+
+# ---- reverse-complement DNA mode -----------------------------------------------------------
+def factorize_dna_w_rc_array(data) -> np.ndarray:
+    p, n, keep = _as_buffer(data)
+    out, z = C.c_void_p(), C.c_size_t()
+    check(lib.nolzss_factorize_dna_w_rc(p, n, _default_device, C.byref(out), C.byref(z)))
+    return _take(out, z.value)
+
+
+def factorize_dna_w_rc(data):
+    """reference: bindings.cpp:207-228 -> list[(start, length, ref & ~RC_MASK, is_rc)]"""
+    return _tuples4(factorize_dna_w_rc_array(data))
+
+
+def count_factors_dna_w_rc(data) -> int:
+    """reference: bindings.cpp:276-295"""
+    p, n, keep = _as_buffer(data)
+    z = C.c_size_t()
+    check(lib.nolzss_count_factors_dna_w_rc(p, n, _default_device, C.byref(z)))
+    return z.value
+
+
+def factorize_multiple_dna_w_rc_array(data, start_pos: int = 0) -> np.ndarray:
+    p, n, keep = _as_buffer(data)
+    out, z = C.c_void_p(), C.c_size_t()
+    check(lib.nolzss_factorize_multiple_dna_w_rc(p, n, start_pos, _default_device, C.byref(out), C.byref(z)))
+    return _take(out, z.value)
+
+
+def factorize_multiple_dna_w_rc(data):
+    """reference: bindings.cpp:361-382"""
+    return _tuples4(factorize_multiple_dna_w_rc_array(data))
+
+
+def count_factors_multiple_dna_w_rc(data) -> int:
+    """reference: bindings.cpp:427-446"""
+    p, n, keep = _as_buffer(data)
+    z = C.c_size_t()
+    check(lib.nolzss_count_factors_multiple_dna_w_rc(p, n, 0, _default_device, C.byref(z)))
+    return z.value
+
+
+def prepare_multiple_dna_sequences_w_rc_bytes(sequences):
+    """Extension: like prepare_multiple_dna_sequences_w_rc but returns the prepared string as
+    bytes, so sentinel values >= 128 (more than ~61 sequences) survive."""
+    seqs = [s.encode("latin-1") if isinstance(s, str) else bytes(s) for s in sequences]
+    k = len(seqs)
+    arr = (C.c_char_p * max(k, 1))(*seqs)
+    lens = (C.c_size_t * max(k, 1))(*[len(s) for s in seqs])
+    S, S_len, orig = C.c_void_p(), C.c_size_t(), C.c_size_t()
+    sp, ns = C.c_void_p(), C.c_size_t()
+    check(lib.nolzss_prepare_multiple_dna_w_rc(arr, lens, k, C.byref(S), C.byref(S_len), C.byref(orig),
+                                               C.byref(sp), C.byref(ns)))
+    try:
+        data = C.string_at(S, S_len.value) if S.value else b""
+        sent = []
+        if sp.value and ns.value:
+            sent = np.ctypeslib.as_array(C.cast(sp, C.POINTER(C.c_uint64)), shape=(ns.value,)).tolist()
+    finally:
+        lib.nolzss_free(S)
+        lib.nolzss_free(sp)
+    return data, orig.value, sent
+
+
+def prepare_multiple_dna_sequences_w_rc(sequences):
+    """reference: bindings.cpp:732-740 -> (prepared_string: str, original_length, sentinel_positions).
+    The reference returns a std::string through pybind11, i.e. a UTF-8-decoded str; sentinel
+    bytes >= 128 therefore raise UnicodeDecodeError there, and do so here as well."""
+    data, orig, sent = prepare_multiple_dna_sequences_w_rc_bytes(sequences)
+    return data.decode("utf-8"), orig, sent
+
+
+# ---- measurement hooks ----------------------------------------------------------------------
+def profile_enable(on: bool = True) -> None:
+    check(lib.nolzss_profile_enable(_default_device, 1 if on else 0))
+
+
+def profile_reset() -> None:
+    check(lib.nolzss_profile_reset(_default_device))
+
+
+def profile_report() -> dict:
+    """{stage name: (launch count, total milliseconds)} measured with HIP events on the
+    pipeline stream."""
+    buf = C.create_string_buffer(1 << 16)
+    check(lib.nolzss_profile_report(_default_device, buf, len(buf)))
+    res = {}
+    for line in buf.value.decode().splitlines():
+        name, count, ms = line.split()
+        res[name] = (int(count), float(ms))
+    return res
+
+
+def device_count() -> int:
+    c = C.c_int()
+    check(lib.nolzss_device_count(C.byref(c)))
+    return c.value
+
+
+# ---- intermediate arrays for the parity tests ------------------------------------------------
+def debug_arrays(data):
+    """-> dict(sa, isa, lcp (n+1 entries), lstar) as computed on the device."""
+    p, n, keep = _as_buffer(data)
+    sa = np.zeros(n, dtype=np.uint32)
+    isa = np.zeros(n, dtype=np.uint32)
+    lcp = np.zeros(n + 1, dtype=np.uint32)
+    lstar = np.zeros(n, dtype=np.uint32)
+    check(lib.nolzss_debug_arrays(p, n, _default_device, sa.ctypes.data, isa.ctypes.data, lcp.ctypes.data,
+                                  lstar.ctypes.data))
+    return {"sa": sa, "isa": isa, "lcp": lcp, "lstar": lstar}
+
+
+def debug_sort_pairs(keys, vals):
+    keys = np.ascontiguousarray(keys, dtype=np.uint64).copy()
+    vals = np.ascontiguousarray(vals, dtype=np.uint32).copy()
+    check(lib.nolzss_debug_sort_pairs(keys.ctypes.data, vals.ctypes.data, keys.size, _default_device))
+    return keys, vals
+
+
+def debug_scan(data, mode: int):
+    data = np.ascontiguousarray(data, dtype=np.uint32).copy()
+    check(lib.nolzss_debug_scan(data.ctypes.data, data.size, mode, _default_device))
+    return data
+
+
+# ---- names of the reference module that are outside the hot path -----------------------------
+def _not_on_path(name):
+    def f(*args, **kwargs):
+        raise NotImplementedError(
+            f"_noLZSS.{name} is outside the MI355X hot path of this build (SURVEY.md section 8); "
+            "only the factorize / count_factors / *_dna_w_rc / prepare_* entry points are provided")
+    f.__name__ = name
+    return f
+
+
+for _n in [
+    "write_factors_binary_file", "factorize_file_dna_w_rc", "count_factors_file_dna_w_rc",
+    "write_factors_binary_file_dna_w_rc", "factorize_file_multiple_dna_w_rc",
+    "count_factors_file_multiple_dna_w_rc", "write_factors_binary_file_multiple_dna_w_rc",
+    "factorize_fasta_multiple_dna_w_rc", "factorize_dna_rc_w_ref_fasta_files",
+    "factorize_fasta_multiple_dna_no_rc", "write_factors_binary_file_fasta_multiple_dna_w_rc",
+    "write_factors_binary_file_fasta_multiple_dna_no_rc", "prepare_multiple_dna_sequences_no_rc",
+    "factorize_dna_w_reference_seq", "factorize_dna_w_reference_seq_file", "factorize_w_reference",
+    "factorize_w_reference_file", "write_factors_dna_w_reference_fasta_files_to_binary",
+    "parallel_factorize_to_file", "parallel_factorize_file_to_file",
+    "parallel_factorize_dna_w_rc_to_file", "parallel_factorize_file_dna_w_rc_to_file",
+    "parallel_write_factors_binary_file_fasta_multiple_dna_w_rc",
+    "parallel_write_factors_binary_file_fasta_multiple_dna_no_rc",
+    "parallel_write_factors_dna_w_reference_fasta_files_to_binary",
+    "factorize_fasta_dna_w_rc_per_sequence", "factorize_fasta_dna_no_rc_per_sequence",
+    "write_factors_binary_file_fasta_dna_w_rc_per_sequence",
+    "write_factors_binary_file_fasta_dna_no_rc_per_sequence",
+    "count_factors_fasta_dna_w_rc_per_sequence", "count_factors_fasta_dna_no_rc_per_sequence",
+    "parallel_write_factors_binary_file_fasta_dna_w_rc_per_sequence",
+    "parallel_write_factors_binary_file_fasta_dna_no_rc_per_sequence",
+]:
+    globals()[_n] = _not_on_path(_n)
+del _n

@@ -1,0 +1,638 @@
+// api.hip -- C ABI of libnolzss_hip.so (include/nolzss_hip.h) and the host-side orchestration
+// of the device pipeline.  There is no CPU fallback anywhere in this library.
+#include "../../include/nolzss_hip.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <memory>
+#include <mutex>
+#include <numeric>
+#include <thread>
+
+#include "pipeline.hpp"
+#include "pyramid.hpp"
+#include "radix_sort.hpp"
+#include "scan.hpp"
+
+namespace nolzss {
+
+// stage entry points defined in lpnf.hip / chain.hip / rc.hip
+uint32_t build_lstar(Context &ctx, uint32_t n, const uint32_t *sa, const uint32_t *isa, const uint32_t *lcp,
+                     const Pyramid &Psa, const Pyramid &Plcp, uint32_t *lstar);
+uint32_t resolve_chain(Context &ctx, uint32_t n, uint32_t start_pos, const uint32_t *lstar, const uint32_t *sa,
+                       const uint32_t *isa, const uint32_t *lcp, const Pyramid &Psa, const Pyramid &Plcp,
+                       void **d_factors_out);
+uint32_t run_rc_pipeline(Context &ctx, const uint8_t *d_S, size_t m, size_t start_pos, void **d_factors_out);
+
+namespace {
+
+thread_local std::string g_error;
+
+int set_error(int code, const std::string &msg) {
+    g_error = msg;
+    return code;
+}
+
+struct DeviceContext {
+    std::mutex mu;
+    Context ctx;
+    bool ready = false;
+};
+
+std::mutex g_ctx_mu;
+std::map<int, std::unique_ptr<DeviceContext>> g_ctx;
+
+constexpr size_t kMaxText = 0xffffffffull - (1ull << 16);  // 32-bit index pipeline
+
+size_t arena_bytes_for(size_t n) { return 60 * n + (size_t(64) << 20); }
+
+DeviceContext &get_context(int device) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        throw HipError("no HIP device available: libnolzss_hip has no CPU fallback");
+    if (device < 0 || device >= count) throw std::invalid_argument("device ordinal out of range");
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    auto &slot = g_ctx[device];
+    if (!slot) slot = std::make_unique<DeviceContext>();
+    return *slot;
+}
+
+// RAII: lock the device context, make it current, make sure stream / pinned scratch exist
+struct Session {
+    DeviceContext &dc;
+    std::unique_lock<std::mutex> lk;
+    hipStream_t own_stream;
+    Session(int device, void *user_stream) : dc(get_context(device)), lk(dc.mu) {
+        HIP_CHECK(hipSetDevice(device));
+        if (!dc.ready) {
+            dc.ctx.device = device;
+            HIP_CHECK(hipStreamCreateWithFlags(&dc.ctx.stream, hipStreamNonBlocking));
+            HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&dc.ctx.h_pinned), 64 * sizeof(uint32_t)));
+            dc.ready = true;
+        }
+        own_stream = dc.ctx.stream;
+        if (user_stream) dc.ctx.stream = static_cast<hipStream_t>(user_stream);
+    }
+    ~Session() {
+        dc.ctx.stream = own_stream;
+        dc.ctx.arena.rewind(0);  // every call starts from an empty arena, also after an exception
+    }
+    Context &ctx() { return dc.ctx; }
+};
+
+struct DebugOut {
+    uint32_t *sa = nullptr, *isa = nullptr, *lcp = nullptr, *lstar = nullptr;
+};
+
+void copy_out(Context &ctx, uint32_t *host, const uint32_t *dev, size_t count) {
+    if (!host || !count) return;
+    HIP_CHECK(hipMemcpyAsync(host, dev, count * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx.stream));
+}
+
+// The plain-mode pipeline on a device-resident text.  Returns z; *out_host (optional) receives
+// a malloc'ed array of z factors.
+size_t run_plain(Context &ctx, const uint8_t *d_text, size_t n, size_t start_pos, nolzss_factor **out_host,
+                 DebugOut *dbg) {
+    if (out_host) *out_host = nullptr;
+    if (n == 0 || start_pos >= n) return 0;
+    Arena &arena = ctx.arena;
+    const size_t mark = arena.mark();
+    hipStream_t s = ctx.stream;
+
+    PackedText text = pack_text(ctx, d_text, n);
+    uint32_t *sa = arena.alloc<uint32_t>(n);
+    uint32_t *isa = arena.alloc<uint32_t>(n);
+    build_suffix_array(ctx, text, sa, isa);
+    uint32_t *lcp = arena.alloc<uint32_t>(n + 1);
+    build_lcp(ctx, text, sa, lcp);
+    Pyramid Psa, Plcp;
+    {
+        ProfScope ps(ctx.profiler(), "pyramids", s);
+        Psa = build_pyramid(sa, (uint32_t)n, false, arena, s);
+        Plcp = build_pyramid(lcp, (uint32_t)n + 1, false, arena, s);
+    }
+    uint32_t *lstar = arena.alloc<uint32_t>(n);
+    build_lstar(ctx, (uint32_t)n, sa, isa, lcp, Psa, Plcp, lstar);
+    if (dbg) {
+        copy_out(ctx, dbg->sa, sa, n);
+        copy_out(ctx, dbg->isa, isa, n);
+        copy_out(ctx, dbg->lcp, lcp, n + 1);
+        copy_out(ctx, dbg->lstar, lstar, n);
+    }
+    void *d_recs = nullptr;
+    const uint32_t z = resolve_chain(ctx, (uint32_t)n, (uint32_t)start_pos, lstar, sa, isa, lcp, Psa, Plcp,
+                                     out_host ? &d_recs : nullptr);
+    if (out_host && z) {
+        nolzss_factor *h = static_cast<nolzss_factor *>(std::malloc(sizeof(nolzss_factor) * (size_t)z));
+        if (!h) throw std::bad_alloc();
+        ProfScope ps(ctx.profiler(), "factors_d2h", s);
+        hipError_t e = hipMemcpyAsync(h, d_recs, sizeof(nolzss_factor) * (size_t)z, hipMemcpyDeviceToHost, s);
+        if (e != hipSuccess) {
+            std::free(h);
+            HIP_CHECK(e);
+        }
+        *out_host = h;
+    }
+    HIP_CHECK(hipStreamSynchronize(s));
+    ctx.prof.collect();
+    arena.rewind(mark);
+    return z;
+}
+
+size_t run_plain_host(Context &ctx, const uint8_t *text, size_t n, size_t start_pos, nolzss_factor **out,
+                      DebugOut *dbg) {
+    if (out) *out = nullptr;
+    if (n == 0 || start_pos >= n) return 0;
+    ctx.arena.reserve(arena_bytes_for(n) + n);
+    const size_t mark = ctx.arena.mark();
+    uint8_t *d_text = ctx.arena.alloc<uint8_t>(n);
+    {
+        ProfScope ps(ctx.profiler(), "text_h2d", ctx.stream);
+        HIP_CHECK(hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, ctx.stream));
+    }
+    size_t z;
+    try {
+        z = run_plain(ctx, d_text, n, start_pos, out, dbg);
+    } catch (...) {
+        ctx.arena.rewind(mark);
+        throw;
+    }
+    ctx.arena.rewind(mark);
+    return z;
+}
+
+template <typename F> int guarded(F &&f) {
+    try {
+        f();
+        return NOLZSS_OK;
+    } catch (const HipError &e) {
+        return set_error(NOLZSS_ERR_DEVICE, e.what());
+    } catch (const std::bad_alloc &) {
+        return set_error(NOLZSS_ERR_NOMEM, "out of host memory");
+    } catch (const std::invalid_argument &e) {
+        return set_error(NOLZSS_ERR_INVALID_ARGUMENT, e.what());
+    } catch (const std::ios_base::failure &e) {
+        return set_error(NOLZSS_ERR_IO, e.what());
+    } catch (const std::exception &e) {
+        return set_error(NOLZSS_ERR_RUNTIME, e.what());
+    }
+}
+
+void check_text_args(const void *text, size_t n, size_t start_pos) {
+    if (n && !text) throw std::invalid_argument("text pointer is null");
+    if (n > kMaxText) throw std::invalid_argument("text too long: the device pipeline uses 32-bit indices");
+    if (start_pos > n) throw std::invalid_argument("start_pos beyond the end of the text");
+}
+
+std::vector<uint8_t> read_file(const char *path) {
+    if (!path) throw std::invalid_argument("path is null");
+    std::ifstream is(path, std::ios::binary);
+    if (!is) throw std::runtime_error(std::string("Cannot open input file: ") + path);
+    is.seekg(0, std::ios::end);
+    const std::streamoff len = is.tellg();
+    is.seekg(0, std::ios::beg);
+    std::vector<uint8_t> data((size_t)(len > 0 ? len : 0));
+    if (!data.empty()) is.read(reinterpret_cast<char *>(data.data()), (std::streamsize)data.size());
+    return data;
+}
+
+// ---- reverse-complement preparation (host side, O(n)) ---------------------------------------
+// restates prepare_multiple_dna_sequences_w_rc, /root/reference/src/cpp/factorizer.cpp:54-172
+uint8_t rc_sentinel(size_t index) {  // factorizer.cpp:110-125
+    uint8_t s = 1;
+    size_t count = 0;
+    for (;;) {
+        if (s != 0 && s != 'A' && s != 'C' && s != 'G' && s != 'T') {
+            if (count == index) return s;
+            ++count;
+        }
+        ++s;
+        if (s == 0) s = 1;
+    }
+}
+
+inline uint8_t upper_base(uint8_t c) { return (c >= 'a' && c <= 'z') ? (uint8_t)(c - 'a' + 'A') : c; }
+
+inline uint8_t complement_base(uint8_t c) {  // factorizer.cpp:17-27
+    switch (c) {
+    case 'A': return 'T';
+    case 'C': return 'G';
+    case 'G': return 'C';
+    default: return 'A';  // 'T' (input validated before)
+    }
+}
+
+void prepare_w_rc(const char *const *seqs, const size_t *lens, size_t k, std::vector<uint8_t> &S,
+                  size_t &original_length, std::vector<uint64_t> &sentinels) {
+    S.clear();
+    sentinels.clear();
+    original_length = 0;
+    if (k == 0) return;  // :55-57
+    size_t non_empty = 0, empty = 0, total = 0;
+    for (size_t i = 0; i < k; ++i) (lens[i] ? ++non_empty : ++empty);
+    if (empty)  // :70-72
+        fprintf(stderr, "Warning: Skipping %zu empty sequence(s) in prepare_multiple_dna_sequences_w_rc\n", empty);
+    if (non_empty == 0) throw std::runtime_error("All sequences are empty - cannot prepare for factorization");
+    if (non_empty > 125)
+        throw std::invalid_argument(
+            "Too many sequences: maximum 125 sequences supported (due to sentinel character limitations)");
+    for (size_t i = 0; i < k; ++i)
+        for (size_t j = 0; j < lens[i]; ++j) {
+            const char c = seqs[i][j];
+            if (c != 'A' && c != 'C' && c != 'G' && c != 'T' && c != 'a' && c != 'c' && c != 'g' && c != 't')
+                throw std::runtime_error("Invalid nucleotide '" + std::string(1, c) + "' found in sequence " +
+                                         std::to_string(i));
+        }
+    for (size_t i = 0; i < k; ++i) total += 2 * lens[i];
+    total += 2 * non_empty;
+    S.reserve(total);
+    size_t sidx = 0;
+    for (size_t i = 0; i < k; ++i) {  // :128-147
+        if (!lens[i]) continue;
+        for (size_t j = 0; j < lens[i]; ++j) S.push_back(upper_base((uint8_t)seqs[i][j]));
+        sentinels.push_back(S.size());
+        S.push_back(rc_sentinel(sidx++));
+    }
+    original_length = S.size();
+    for (size_t i = k; i-- > 0;) {  // :150-169
+        if (!lens[i]) continue;
+        for (size_t j = 0; j < lens[i]; ++j)
+            S.push_back(complement_base(upper_base((uint8_t)seqs[i][lens[i] - 1 - j])));
+        sentinels.push_back(S.size());
+        S.push_back(rc_sentinel(sidx++));
+    }
+}
+
+// guards of detail::nolzss_multiple_dna_w_rc, factorizer_core.hpp:180-205
+// returns false when the reference returns 0 factors without building anything
+bool rc_guards(size_t S_len, size_t start_pos) {
+    if (S_len == 0) return false;
+    if (S_len < 4) {
+        fprintf(stderr,
+                "Warning: Input string too short for factorization with reverse complement (size=%zu). "
+                "Returning 0 factors.\n",
+                S_len);
+        return false;
+    }
+    const size_t N = S_len / 2 - 1;
+    if (N == 0) return false;
+    if (start_pos >= N) throw std::invalid_argument("start_pos must be less than the original sequence length");
+    return true;
+}
+
+size_t run_rc_host(Context &ctx, const uint8_t *S, size_t m, size_t start_pos, nolzss_factor **out) {
+    if (out) *out = nullptr;
+    if (m > kMaxText) throw std::invalid_argument("text too long: the device pipeline uses 32-bit indices");
+    if (!rc_guards(m, start_pos)) return 0;
+    ctx.arena.reserve(arena_bytes_for(m) + m);
+    const size_t mark = ctx.arena.mark();
+    size_t z = 0;
+    try {
+        uint8_t *d_S = ctx.arena.alloc<uint8_t>(m);
+        HIP_CHECK(hipMemcpyAsync(d_S, S, m, hipMemcpyHostToDevice, ctx.stream));
+        void *d_recs = nullptr;
+        z = run_rc_pipeline(ctx, d_S, m, start_pos, out ? &d_recs : nullptr);
+        if (out && z) {
+            nolzss_factor *h = static_cast<nolzss_factor *>(std::malloc(sizeof(nolzss_factor) * z));
+            if (!h) throw std::bad_alloc();
+            hipError_t e = hipMemcpyAsync(h, d_recs, sizeof(nolzss_factor) * z, hipMemcpyDeviceToHost, ctx.stream);
+            if (e != hipSuccess) {
+                std::free(h);
+                HIP_CHECK(e);
+            }
+            *out = h;
+        }
+        HIP_CHECK(hipStreamSynchronize(ctx.stream));
+        ctx.prof.collect();
+    } catch (...) {
+        ctx.arena.rewind(mark);
+        if (out && *out) {
+            std::free(*out);
+            *out = nullptr;
+        }
+        throw;
+    }
+    ctx.arena.rewind(mark);
+    return z;
+}
+
+}  // namespace
+}  // namespace nolzss
+
+using namespace nolzss;
+
+extern "C" {
+
+const char *nolzss_last_error(void) { return g_error.c_str(); }
+const char *nolzss_version(void) { return "0.1.0+gfx950"; }
+void nolzss_free(void *p) { std::free(p); }
+
+int nolzss_device_count(int *count) {
+    if (!count) return set_error(NOLZSS_ERR_INVALID_ARGUMENT, "count is null");
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) c = 0;
+    *count = c;
+    return NOLZSS_OK;
+}
+
+int nolzss_factorize(const uint8_t *text, size_t n, size_t start_pos, int device, nolzss_factor **out,
+                     size_t *z) {
+    return guarded([&] {
+        if (!out || !z) throw std::invalid_argument("output pointer is null");
+        *out = nullptr;
+        *z = 0;
+        check_text_args(text, n, start_pos);
+        Session ses(device, nullptr);
+        *z = run_plain_host(ses.ctx(), text, n, start_pos, out, nullptr);
+    });
+}
+
+int nolzss_count_factors(const uint8_t *text, size_t n, size_t start_pos, int device, size_t *z) {
+    return guarded([&] {
+        if (!z) throw std::invalid_argument("output pointer is null");
+        *z = 0;
+        check_text_args(text, n, start_pos);
+        Session ses(device, nullptr);
+        *z = run_plain_host(ses.ctx(), text, n, start_pos, nullptr, nullptr);
+    });
+}
+
+int nolzss_factorize_file(const char *path, size_t start_pos, int device, nolzss_factor **out, size_t *z) {
+    return guarded([&] {
+        if (!out || !z) throw std::invalid_argument("output pointer is null");
+        *out = nullptr;
+        *z = 0;
+        std::vector<uint8_t> data = read_file(path);
+        check_text_args(data.data(), data.size(), start_pos);
+        Session ses(device, nullptr);
+        *z = run_plain_host(ses.ctx(), data.data(), data.size(), start_pos, out, nullptr);
+    });
+}
+
+int nolzss_count_factors_file(const char *path, size_t start_pos, int device, size_t *z) {
+    return guarded([&] {
+        if (!z) throw std::invalid_argument("output pointer is null");
+        *z = 0;
+        std::vector<uint8_t> data = read_file(path);
+        check_text_args(data.data(), data.size(), start_pos);
+        Session ses(device, nullptr);
+        *z = run_plain_host(ses.ctx(), data.data(), data.size(), start_pos, nullptr, nullptr);
+    });
+}
+
+int nolzss_factorize_device(const void *d_text, size_t n, size_t start_pos, int device, void *stream,
+                            nolzss_factor **out_host, size_t *z) {
+    return guarded([&] {
+        if (!z) throw std::invalid_argument("output pointer is null");
+        *z = 0;
+        if (out_host) *out_host = nullptr;
+        check_text_args(d_text, n, start_pos);
+        Session ses(device, stream);
+        ses.ctx().arena.reserve(arena_bytes_for(n));
+        *z = run_plain(ses.ctx(), static_cast<const uint8_t *>(d_text), n, start_pos, out_host, nullptr);
+    });
+}
+
+int nolzss_prepare_multiple_dna_w_rc(const char *const *seqs, const size_t *lens, size_t k, uint8_t **S,
+                                     size_t *S_len, size_t *original_length, uint64_t **sentinel_positions,
+                                     size_t *n_sentinels) {
+    return guarded([&] {
+        if (!S || !S_len || !original_length || !sentinel_positions || !n_sentinels)
+            throw std::invalid_argument("output pointer is null");
+        *S = nullptr;
+        *sentinel_positions = nullptr;
+        *S_len = *original_length = *n_sentinels = 0;
+        if (k && (!seqs || !lens)) throw std::invalid_argument("sequence array is null");
+        std::vector<uint8_t> buf;
+        std::vector<uint64_t> sent;
+        size_t orig = 0;
+        prepare_w_rc(seqs, lens, k, buf, orig, sent);
+        uint8_t *s = static_cast<uint8_t *>(std::malloc(buf.size() ? buf.size() : 1));
+        uint64_t *p = static_cast<uint64_t *>(std::malloc(sent.size() ? sent.size() * sizeof(uint64_t) : 8));
+        if (!s || !p) {
+            std::free(s);
+            std::free(p);
+            throw std::bad_alloc();
+        }
+        if (!buf.empty()) std::memcpy(s, buf.data(), buf.size());
+        if (!sent.empty()) std::memcpy(p, sent.data(), sent.size() * sizeof(uint64_t));
+        *S = s;
+        *S_len = buf.size();
+        *original_length = orig;
+        *sentinel_positions = p;
+        *n_sentinels = sent.size();
+    });
+}
+
+int nolzss_factorize_multiple_dna_w_rc(const uint8_t *S, size_t S_len, size_t start_pos, int device,
+                                       nolzss_factor **out, size_t *z) {
+    return guarded([&] {
+        if (!out || !z) throw std::invalid_argument("output pointer is null");
+        *out = nullptr;
+        *z = 0;
+        if (S_len && !S) throw std::invalid_argument("text pointer is null");
+        if (!rc_guards(S_len, start_pos)) return;
+        Session ses(device, nullptr);
+        *z = run_rc_host(ses.ctx(), S, S_len, start_pos, out);
+    });
+}
+
+int nolzss_count_factors_multiple_dna_w_rc(const uint8_t *S, size_t S_len, size_t start_pos, int device,
+                                           size_t *z) {
+    return guarded([&] {
+        if (!z) throw std::invalid_argument("output pointer is null");
+        *z = 0;
+        if (S_len && !S) throw std::invalid_argument("text pointer is null");
+        if (!rc_guards(S_len, start_pos)) return;
+        Session ses(device, nullptr);
+        *z = run_rc_host(ses.ctx(), S, S_len, start_pos, nullptr);
+    });
+}
+
+static void dna_w_rc_common(const uint8_t *text, size_t n, int device, nolzss_factor **out, size_t *z) {
+    *z = 0;
+    if (out) *out = nullptr;
+    if (n == 0) return;  // factorizer_core.hpp:143
+    if (!text) throw std::invalid_argument("text pointer is null");
+    const char *seqs[1] = {reinterpret_cast<const char *>(text)};
+    const size_t lens[1] = {n};
+    std::vector<uint8_t> S;
+    std::vector<uint64_t> sent;
+    size_t orig = 0;
+    prepare_w_rc(seqs, lens, 1, S, orig, sent);  // factorizer_core.hpp:146
+    if (!rc_guards(S.size(), 0)) return;
+    Session ses(device, nullptr);
+    *z = run_rc_host(ses.ctx(), S.data(), S.size(), 0, out);
+}
+
+int nolzss_factorize_dna_w_rc(const uint8_t *text, size_t n, int device, nolzss_factor **out, size_t *z) {
+    return guarded([&] {
+        if (!out || !z) throw std::invalid_argument("output pointer is null");
+        dna_w_rc_common(text, n, device, out, z);
+    });
+}
+
+int nolzss_count_factors_dna_w_rc(const uint8_t *text, size_t n, int device, size_t *z) {
+    return guarded([&] {
+        if (!z) throw std::invalid_argument("output pointer is null");
+        dna_w_rc_common(text, n, device, nullptr, z);
+    });
+}
+
+int nolzss_factorize_batch(const uint8_t *const *texts, const size_t *lens, size_t m, const int *devices,
+                           size_t n_dev, nolzss_factor ***out, size_t **z) {
+    return guarded([&] {
+        if (!z) throw std::invalid_argument("output pointer is null");
+        *z = nullptr;
+        if (out) *out = nullptr;
+        if (m && (!texts || !lens)) throw std::invalid_argument("sequence array is null");
+        if (!devices || n_dev == 0) throw std::invalid_argument("device list is empty");
+        for (size_t j = 0; j < m; ++j) check_text_args(texts[j], lens[j], 0);
+        size_t *zs = static_cast<size_t *>(std::calloc(m ? m : 1, sizeof(size_t)));
+        nolzss_factor **fs = out ? static_cast<nolzss_factor **>(std::calloc(m ? m : 1, sizeof(nolzss_factor *)))
+                                 : nullptr;
+        if (!zs || (out && !fs)) {
+            std::free(zs);
+            std::free(fs);
+            throw std::bad_alloc();
+        }
+        // longest-processing-time-first assignment of sequences to devices
+        std::vector<size_t> order(m);
+        std::iota(order.begin(), order.end(), size_t(0));
+        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return lens[a] > lens[b]; });
+        std::vector<std::vector<size_t>> plan(n_dev);
+        std::vector<size_t> load(n_dev, 0);
+        for (size_t j : order) {
+            const size_t d = (size_t)(std::min_element(load.begin(), load.end()) - load.begin());
+            plan[d].push_back(j);
+            load[d] += lens[j];
+        }
+        std::vector<int> status(n_dev, NOLZSS_OK);
+        std::vector<std::string> messages(n_dev);
+        auto worker = [&](size_t d) {
+            status[d] = guarded([&] {
+                Session ses(devices[d], nullptr);
+                for (size_t j : plan[d])
+                    zs[j] = run_plain_host(ses.ctx(), texts[j], lens[j], 0, fs ? &fs[j] : nullptr, nullptr);
+            });
+            if (status[d] != NOLZSS_OK) messages[d] = g_error;
+        };
+        if (n_dev == 1) {
+            worker(0);
+        } else {
+            std::vector<std::thread> threads;
+            for (size_t d = 0; d < n_dev; ++d) threads.emplace_back(worker, d);
+            for (auto &t : threads) t.join();
+        }
+        for (size_t d = 0; d < n_dev; ++d)
+            if (status[d] != NOLZSS_OK) {
+                if (fs) {
+                    for (size_t j = 0; j < m; ++j) std::free(fs[j]);
+                    std::free(fs);
+                }
+                std::free(zs);
+                throw std::runtime_error("batch worker failed: " + messages[d]);
+            }
+        *z = zs;
+        if (out) *out = fs;
+    });
+}
+
+void nolzss_free_batch(nolzss_factor **out, size_t *z, size_t m) {
+    if (out) {
+        for (size_t j = 0; j < m; ++j) std::free(out[j]);
+        std::free(out);
+    }
+    std::free(z);
+}
+
+int nolzss_profile_enable(int device, int on) {
+    return guarded([&] {
+        Session ses(device, nullptr);
+        ses.ctx().prof.enable(on != 0);
+    });
+}
+
+int nolzss_profile_reset(int device) {
+    return guarded([&] {
+        Session ses(device, nullptr);
+        ses.ctx().prof.reset();
+    });
+}
+
+int nolzss_profile_report(int device, char *buf, size_t cap) {
+    return guarded([&] {
+        if (!buf || cap == 0) throw std::invalid_argument("buffer is null");
+        Session ses(device, nullptr);
+        std::string text;
+        for (const auto &kv : ses.ctx().prof.stats()) {
+            char line[256];
+            snprintf(line, sizeof line, "%s %llu %.6f\n", kv.first.c_str(), (unsigned long long)kv.second.count,
+                     kv.second.total_ms);
+            text += line;
+        }
+        const size_t len = std::min(text.size(), cap - 1);
+        std::memcpy(buf, text.data(), len);
+        buf[len] = 0;
+    });
+}
+
+int nolzss_debug_arrays(const uint8_t *text, size_t n, int device, uint32_t *sa, uint32_t *isa, uint32_t *lcp,
+                        uint32_t *lstar) {
+    return guarded([&] {
+        check_text_args(text, n, 0);
+        if (n == 0) return;
+        Session ses(device, nullptr);
+        DebugOut dbg;
+        dbg.sa = sa;
+        dbg.isa = isa;
+        dbg.lcp = lcp;
+        dbg.lstar = lstar;
+        run_plain_host(ses.ctx(), text, n, 0, nullptr, &dbg);
+    });
+}
+
+int nolzss_debug_sort_pairs(uint64_t *keys, uint32_t *vals, size_t n, int device) {
+    return guarded([&] {
+        if (n == 0) return;
+        if (!keys || !vals) throw std::invalid_argument("null array");
+        Session ses(device, nullptr);
+        Context &ctx = ses.ctx();
+        ctx.arena.reserve(n * 28 + (size_t(64) << 20));
+        const size_t mark = ctx.arena.mark();
+        uint64_t *k[2] = {ctx.arena.alloc<uint64_t>(n), ctx.arena.alloc<uint64_t>(n)};
+        uint32_t *v[2] = {ctx.arena.alloc<uint32_t>(n), ctx.arena.alloc<uint32_t>(n)};
+        HIP_CHECK(hipMemcpyAsync(k[0], keys, n * 8, hipMemcpyHostToDevice, ctx.stream));
+        HIP_CHECK(hipMemcpyAsync(v[0], vals, n * 4, hipMemcpyHostToDevice, ctx.stream));
+        const int shifts[8] = {0, 8, 16, 24, 32, 40, 48, 56};
+        const int cur = radix_sort_pairs(k, v, n, shifts, 8, ctx.arena, ctx.stream);
+        HIP_CHECK(hipMemcpyAsync(keys, k[cur], n * 8, hipMemcpyDeviceToHost, ctx.stream));
+        HIP_CHECK(hipMemcpyAsync(vals, v[cur], n * 4, hipMemcpyDeviceToHost, ctx.stream));
+        HIP_CHECK(hipStreamSynchronize(ctx.stream));
+        ctx.arena.rewind(mark);
+    });
+}
+
+int nolzss_debug_scan(uint32_t *data, size_t n, int mode, int device) {
+    return guarded([&] {
+        if (n == 0) return;
+        if (!data) throw std::invalid_argument("null array");
+        Session ses(device, nullptr);
+        Context &ctx = ses.ctx();
+        ctx.arena.reserve(n * 8 + (size_t(64) << 20));
+        const size_t mark = ctx.arena.mark();
+        uint32_t *d = ctx.arena.alloc<uint32_t>(n);
+        HIP_CHECK(hipMemcpyAsync(d, data, n * 4, hipMemcpyHostToDevice, ctx.stream));
+        if (mode == 0)
+            scan_exclusive_add_u32(d, d, n, nullptr, ctx.arena, ctx.stream);
+        else
+            scan_inclusive_max_u32(d, d, n, ctx.arena, ctx.stream);
+        HIP_CHECK(hipMemcpyAsync(data, d, n * 4, hipMemcpyDeviceToHost, ctx.stream));
+        HIP_CHECK(hipStreamSynchronize(ctx.stream));
+        ctx.arena.rewind(mark);
+    });
+}
+
+}  // extern "C"

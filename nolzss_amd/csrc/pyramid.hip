@@ -1,0 +1,58 @@
+// pyramid.hip -- builds the upper levels of a 16-ary min / max pyramid (see pyramid.hpp).
+// Streaming kernel: each thread reduces one aligned group of 16 entries (64 bytes).
+#include "pyramid.hpp"
+
+namespace nolzss {
+namespace {
+
+constexpr int kThreads = 256;
+
+template <bool kMax>
+__global__ __launch_bounds__(kThreads) void pyramid_level_kernel(const uint32_t *__restrict__ in, uint32_t len_in,
+                                                                 uint32_t *__restrict__ out, uint32_t len_out) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < len_out; j += stride) {
+        const size_t base = j << kPyrShift;
+        uint32_t res = kMax ? 0u : 0xffffffffu;
+        if (base + kPyrFan <= len_in) {
+            const uint4 *v = reinterpret_cast<const uint4 *>(in + base);  // level arrays are 256-B aligned
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint4 x = v[k];
+                res = pyr_op<kMax>(res, pyr_op<kMax>(pyr_op<kMax>(x.x, x.y), pyr_op<kMax>(x.z, x.w)));
+            }
+        } else {
+            for (size_t q = base; q < len_in; ++q) res = pyr_op<kMax>(res, in[q]);
+        }
+        out[j] = res;
+    }
+}
+
+}  // namespace
+
+Pyramid build_pyramid(const uint32_t *base, uint32_t len, bool is_max, Arena &arena, hipStream_t stream) {
+    Pyramid P{};
+    P.lvl[0] = base;
+    P.len[0] = len;
+    P.nlev = 1;
+    const bool aligned = ((uintptr_t)base & 15) == 0;
+    if (!aligned) throw HipError("pyramid: base array must be 16-byte aligned");
+    while (P.len[P.nlev - 1] > 1 && P.nlev < kPyrMaxLevels) {
+        const uint32_t len_in = P.len[P.nlev - 1];
+        const uint32_t len_out = (len_in + kPyrFan - 1) >> kPyrShift;
+        uint32_t *out = arena.alloc<uint32_t>(len_out);
+        size_t g = div_up(len_out, kThreads);
+        if (g > 8192) g = 8192;
+        if (is_max)
+            pyramid_level_kernel<true><<<(unsigned)g, kThreads, 0, stream>>>(P.lvl[P.nlev - 1], len_in, out, len_out);
+        else
+            pyramid_level_kernel<false><<<(unsigned)g, kThreads, 0, stream>>>(P.lvl[P.nlev - 1], len_in, out, len_out);
+        KERNEL_CHECK();
+        P.lvl[P.nlev] = out;
+        P.len[P.nlev] = len_out;
+        ++P.nlev;
+    }
+    return P;
+}
+
+}  // namespace nolzss

@@ -1,0 +1,353 @@
+// suffix_array.hip -- text packing and suffix-array construction on gfx950.
+//
+// Replaces the SA/CSA part of sdsl::construct_im(cst, text, 1) that the reference calls at
+// /root/reference/src/cpp/factorizer.cpp:340,381 and factorizer_core.hpp:208.
+//
+// Method: prefix doubling with active-set filtering, every ordering step a device radix sort.
+//   round 0   key(i) = first K symbols of suffix i (bit-packed, K = 29 for 2-bit DNA) plus a
+//             length tag; one 8-pass radix sort of (key, i) orders all suffixes by K symbols.
+//   round h   only suffixes whose h-group is not yet a singleton stay active (compacted list);
+//             key = (group head rank, rank[i + h]); radix sort of the active pairs; regroup.
+// All arrays are 32-bit; rank[i] holds (index of the first slot of i's group) + 1, and 0 means
+// "past the end of the text", which sorts before every real suffix exactly as the reference's
+// appended terminator does.
+#include "pipeline.hpp"
+#include "radix_sort.hpp"
+#include "scan.hpp"
+
+namespace nolzss {
+
+void Context::read_back(const uint32_t *d_src, uint32_t *dst, int count) {
+    HIP_CHECK(hipMemcpyAsync(h_pinned, d_src, sizeof(uint32_t) * count, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    for (int k = 0; k < count; ++k) dst[k] = h_pinned[k];
+}
+
+namespace {
+
+constexpr int kThreads = 256;
+
+inline unsigned grid_for(size_t work_items, int per_block, unsigned cap = 256u * 16u) {
+    size_t g = div_up(work_items, (size_t)per_block);
+    if (g < 1) g = 1;
+    return (unsigned)(g > cap ? cap : g);
+}
+
+// ---------------------------------------------------------------------------------------
+// alphabet presence: which byte values occur (256-bit mask, OR-reduced per wavefront)
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void mark_byte(uint64_t (&m)[4], uint32_t b) {
+    const uint64_t bit = 1ull << (b & 63);
+    const uint32_t q = b >> 6;
+    m[0] |= (q == 0) ? bit : 0;
+    m[1] |= (q == 1) ? bit : 0;
+    m[2] |= (q == 2) ? bit : 0;
+    m[3] |= (q == 3) ? bit : 0;
+}
+
+__global__ __launch_bounds__(kThreads) void presence_kernel(const uint8_t *__restrict__ text, size_t n,
+                                                            unsigned long long *presence) {
+    uint64_t m[4] = {0, 0, 0, 0};
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    if (((uintptr_t)text & 15) == 0) {
+        const uint4 *v = reinterpret_cast<const uint4 *>(text);
+        const size_t nv = n / 16;
+        for (size_t i = tid; i < nv; i += stride) {
+            const uint4 x = v[i];
+            const uint32_t wds[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) mark_byte(m, (wds[k] >> (8 * e)) & 255u);
+        }
+        for (size_t i = nv * 16 + tid; i < n; i += stride) mark_byte(m, text[i]);
+    } else {
+        for (size_t i = tid; i < n; i += stride) mark_byte(m, text[i]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint64_t v = m[k];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v |= __shfl_xor(v, d, 64);
+        if (lane_id() == 0 && v) atomicOr(&presence[k], (unsigned long long)v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// packing: one thread per 64-bit output word
+// ---------------------------------------------------------------------------------------
+template <int BITS>
+__global__ __launch_bounds__(kThreads) void pack_kernel(const uint8_t *__restrict__ text, size_t n,
+                                                        const unsigned long long *__restrict__ presence,
+                                                        uint64_t *__restrict__ words, size_t nwords) {
+    constexpr int kSyms = 64 / BITS;
+    __shared__ uint8_t lut[256];
+    {
+        const int b = threadIdx.x;  // kThreads == 256
+        int c = 0;
+        for (int k = 0; k < (b >> 6); ++k) c += __popcll(presence[k]);
+        c += __popcll(presence[b >> 6] & ((1ull << (b & 63)) - 1ull));
+        lut[b] = (uint8_t)c;
+    }
+    __syncthreads();
+    const bool aligned = ((uintptr_t)text & 15) == 0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t wi = (size_t)blockIdx.x * blockDim.x + threadIdx.x; wi < nwords; wi += stride) {
+        const size_t base = wi * kSyms;
+        uint64_t acc = 0;
+        if (aligned && base + kSyms <= n) {
+            if constexpr (kSyms == 8) {
+                const uint2 x = *reinterpret_cast<const uint2 *>(text + base);
+                const uint32_t wds[2] = {x.x, x.y};
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc = (acc << BITS) | lut[(wds[k] >> (8 * e)) & 255u];
+            } else {
+#pragma unroll
+                for (int c = 0; c < kSyms / 16; ++c) {
+                    const uint4 x = *reinterpret_cast<const uint4 *>(text + base + 16 * c);
+                    const uint32_t wds[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc = (acc << BITS) | lut[(wds[k] >> (8 * e)) & 255u];
+                }
+            }
+        } else {
+#pragma unroll 4
+            for (int e = 0; e < kSyms; ++e) {
+                const size_t p = base + e;
+                acc = (acc << BITS) | (p < n ? (uint64_t)lut[text[p]] : 0ull);
+            }
+        }
+        words[wi] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// round 0 keys
+// ---------------------------------------------------------------------------------------
+template <int BITS>
+__global__ __launch_bounds__(kThreads) void initial_keys_kernel(const uint64_t *__restrict__ words,
+                                                                uint32_t n, uint64_t *__restrict__ keys,
+                                                                uint32_t *__restrict__ vals) {
+    constexpr int K = KeyLayout<BITS>::kSyms;
+    constexpr int TAG = KeyLayout<BITS>::kTagBits;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t w = sym_word<BITS>(words, i);
+        const uint32_t rem = n - (uint32_t)i;
+        const uint64_t tag = rem < (uint32_t)K ? rem : (uint32_t)K;
+        keys[i] = ((w >> (64 - K * BITS)) << TAG) | tag;
+        vals[i] = (uint32_t)i;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// regrouping after a sort
+// ---------------------------------------------------------------------------------------
+// headpos[a] = slot(a) if sorted element a starts a new group else 0 (max-scanned afterwards)
+__global__ __launch_bounds__(kThreads) void mark_heads_kernel(const uint64_t *__restrict__ keys,
+                                                              const uint32_t *__restrict__ act_pos,
+                                                              uint32_t m, uint32_t *__restrict__ headpos) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x; a < m; a += stride) {
+        const bool head = (a == 0) || (keys[a] != keys[a - 1]);
+        const uint32_t slot = act_pos ? act_pos[a] : (uint32_t)a;
+        headpos[a] = head ? slot : 0u;
+    }
+}
+
+// writes the new order and ranks; keep[a] = 1 while a's group still has more than one member
+__global__ __launch_bounds__(kThreads) void commit_kernel(const uint64_t *__restrict__ keys,
+                                                          const uint32_t *__restrict__ vals,
+                                                          const uint32_t *__restrict__ act_pos,
+                                                          const uint32_t *__restrict__ head_of, uint32_t m,
+                                                          uint32_t *__restrict__ sa,
+                                                          uint32_t *__restrict__ rank,
+                                                          uint32_t *__restrict__ keep) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x; a < m; a += stride) {
+        const uint64_t k = keys[a];
+        const bool head = (a == 0) || (k != keys[a - 1]);
+        const bool next_head = (a + 1 == m) || (keys[a + 1] != k);
+        const uint32_t slot = act_pos ? act_pos[a] : (uint32_t)a;
+        const uint32_t i = vals[a];
+        sa[slot] = i;
+        rank[i] = head_of[a] + 1u;
+        keep[a] = (head && next_head) ? 0u : 1u;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void compact_kernel(const uint32_t *__restrict__ keep,
+                                                           const uint32_t *__restrict__ idx,
+                                                           const uint32_t *__restrict__ act_pos, uint32_t m,
+                                                           uint32_t *__restrict__ new_act) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x; a < m; a += stride)
+        if (keep[a]) new_act[idx[a]] = act_pos ? act_pos[a] : (uint32_t)a;
+}
+
+__global__ __launch_bounds__(kThreads) void round_keys_kernel(const uint32_t *__restrict__ act_pos,
+                                                              uint32_t m, const uint32_t *__restrict__ sa,
+                                                              const uint32_t *__restrict__ rank, uint32_t n,
+                                                              uint32_t h, uint64_t *__restrict__ keys,
+                                                              uint32_t *__restrict__ vals) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x; a < m; a += stride) {
+        const uint32_t i = sa[act_pos[a]];
+        const uint32_t hi = rank[i];
+        const uint32_t lo = (n - i > h) ? rank[i + h] : 0u;  // i + h < n without overflow
+        keys[a] = ((uint64_t)hi << 32) | lo;
+        vals[a] = i;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void rank_to_isa_kernel(uint32_t *__restrict__ rank, uint32_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) rank[i] -= 1u;
+}
+
+template <int BITS>
+void launch_initial_keys(Context &ctx, const PackedText &t, uint64_t *keys, uint32_t *vals) {
+    ProfScope ps(ctx.profiler(), "sa_initial_keys", ctx.stream);
+    initial_keys_kernel<BITS><<<grid_for(t.n, kThreads), kThreads, 0, ctx.stream>>>(t.words, t.n, keys, vals);
+    KERNEL_CHECK();
+}
+
+// shared tail of every round: sorted (keys, vals) of m active elements -> sa / rank / next active list
+uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *vals, const uint32_t *act_pos,
+                 uint32_t m, uint32_t *sa, uint32_t *rank, uint32_t *new_act, uint32_t *tmp_a,
+                 uint32_t *tmp_b, uint32_t *d_total) {
+    hipStream_t s = ctx.stream;
+    {
+        ProfScope ps(ctx.profiler(), "sa_mark_heads", s);
+        mark_heads_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(keys, act_pos, m, tmp_a);
+        KERNEL_CHECK();
+    }
+    {
+        ProfScope ps(ctx.profiler(), "sa_scan", s);
+        scan_inclusive_max_u32(tmp_a, tmp_a, m, ctx.arena, s);
+    }
+    {
+        ProfScope ps(ctx.profiler(), "sa_commit", s);
+        commit_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(keys, vals, act_pos, tmp_a, m, sa, rank, tmp_b);
+        KERNEL_CHECK();
+    }
+    {
+        ProfScope ps(ctx.profiler(), "sa_scan", s);
+        scan_exclusive_add_u32(tmp_b, tmp_a, m, d_total, ctx.arena, s);
+    }
+    {
+        ProfScope ps(ctx.profiler(), "sa_compact", s);
+        compact_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(tmp_b, tmp_a, act_pos, m, new_act);
+        KERNEL_CHECK();
+    }
+    uint32_t total = 0;
+    ctx.read_back(d_total, &total, 1);
+    return total;
+}
+
+}  // namespace
+
+PackedText pack_text(Context &ctx, const uint8_t *d_text, size_t n) {
+    hipStream_t s = ctx.stream;
+    PackedText t;
+    t.n = (uint32_t)n;
+    unsigned long long *presence = ctx.arena.alloc<unsigned long long>(4);
+    HIP_CHECK(hipMemsetAsync(presence, 0, 32, s));
+    {
+        ProfScope ps(ctx.profiler(), "text_presence", s);
+        presence_kernel<<<grid_for(div_up(n, 16), kThreads, 2048), kThreads, 0, s>>>(d_text, n, presence);
+        KERNEL_CHECK();
+    }
+    uint32_t bitsw[8];
+    ctx.read_back(reinterpret_cast<const uint32_t *>(presence), bitsw, 8);
+    int sigma = 0;
+    for (int k = 0; k < 8; ++k) sigma += __builtin_popcount(bitsw[k]);
+    t.sigma = sigma;
+    t.bits = sigma <= 4 ? 2 : (sigma <= 16 ? 4 : 8);
+    const size_t nwords = div_up(n * (size_t)t.bits, 64) + 2;
+    uint64_t *words = ctx.arena.alloc<uint64_t>(nwords);
+    {
+        ProfScope ps(ctx.profiler(), "text_pack", s);
+        const unsigned g = grid_for(nwords, kThreads);
+        switch (t.bits) {
+        case 2: pack_kernel<2><<<g, kThreads, 0, s>>>(d_text, n, presence, words, nwords); break;
+        case 4: pack_kernel<4><<<g, kThreads, 0, s>>>(d_text, n, presence, words, nwords); break;
+        default: pack_kernel<8><<<g, kThreads, 0, s>>>(d_text, n, presence, words, nwords); break;
+        }
+        KERNEL_CHECK();
+    }
+    t.words = words;
+    return t;
+}
+
+int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint32_t *isa) {
+    const uint32_t n = text.n;
+    hipStream_t s = ctx.stream;
+    Arena &arena = ctx.arena;
+    const size_t mark = arena.mark();
+
+    uint64_t *keys[2] = {arena.alloc<uint64_t>(n), arena.alloc<uint64_t>(n)};
+    uint32_t *vals[2] = {arena.alloc<uint32_t>(n), arena.alloc<uint32_t>(n)};
+    uint32_t *act[2] = {arena.alloc<uint32_t>(n), arena.alloc<uint32_t>(n)};
+    uint32_t *tmp_a = arena.alloc<uint32_t>(n);
+    uint32_t *tmp_b = arena.alloc<uint32_t>(n);
+    uint32_t *d_total = arena.alloc<uint32_t>(1);
+    uint32_t *rank = isa;
+
+    // ---- round 0: order by the first K symbols -------------------------------------------
+    int k_syms = 0;
+    switch (text.bits) {
+    case 2: launch_initial_keys<2>(ctx, text, keys[0], vals[0]); k_syms = KeyLayout<2>::kSyms; break;
+    case 4: launch_initial_keys<4>(ctx, text, keys[0], vals[0]); k_syms = KeyLayout<4>::kSyms; break;
+    default: launch_initial_keys<8>(ctx, text, keys[0], vals[0]); k_syms = KeyLayout<8>::kSyms; break;
+    }
+    int cur;
+    {
+        const int shifts[8] = {0, 8, 16, 24, 32, 40, 48, 56};
+        ProfScope ps(ctx.profiler(), "sa_sort_initial", s);
+        cur = radix_sort_pairs(keys, vals, n, shifts, 8, arena, s);
+    }
+    uint32_t m = regroup(ctx, keys[cur], vals[cur], nullptr, n, sa, rank, act[0], tmp_a, tmp_b, d_total);
+
+    // ---- doubling rounds ------------------------------------------------------------------
+    int nbits = 1;
+    while (nbits < 32 && (1ull << nbits) <= (uint64_t)n) ++nbits;  // ranks are <= n
+    const int half_passes = (nbits + kRadixBits - 1) / kRadixBits;
+    int shifts[8], npasses = 0;
+    for (int p = 0; p < half_passes; ++p) shifts[npasses++] = p * kRadixBits;
+    for (int p = 0; p < half_passes; ++p) shifts[npasses++] = 32 + p * kRadixBits;
+
+    int rounds = 0, a_cur = 0;
+    uint64_t h = (uint64_t)k_syms;
+    while (m > 0) {
+        if (h >= n || rounds > 40) throw HipError("suffix array: prefix doubling failed to converge");
+        {
+            ProfScope ps(ctx.profiler(), "sa_round_keys", s);
+            round_keys_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(act[a_cur], m, sa, rank, n, (uint32_t)h,
+                                                                        keys[0], vals[0]);
+            KERNEL_CHECK();
+        }
+        {
+            ProfScope ps(ctx.profiler(), "sa_sort_round", s);
+            cur = radix_sort_pairs(keys, vals, m, shifts, npasses, arena, s);
+        }
+        m = regroup(ctx, keys[cur], vals[cur], act[a_cur], m, sa, rank, act[a_cur ^ 1], tmp_a, tmp_b, d_total);
+        a_cur ^= 1;
+        h *= 2;
+        ++rounds;
+    }
+    {
+        ProfScope ps(ctx.profiler(), "sa_rank_to_isa", s);
+        rank_to_isa_kernel<<<grid_for(n, kThreads), kThreads, 0, s>>>(rank, n);
+        KERNEL_CHECK();
+    }
+    arena.rewind(mark);
+    return rounds;
+}
+
+}  // namespace nolzss

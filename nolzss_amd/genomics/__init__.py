@@ -1,0 +1,16 @@
+"""Genomics entry points on the hot path (mirror of noLZSS.genomics,
+reference: src/noLZSS/genomics/__init__.py:8-25)."""
+from .._noLZSS import (
+    factorize_dna_w_rc,
+    count_factors_dna_w_rc,
+    factorize_multiple_dna_w_rc,
+    count_factors_multiple_dna_w_rc,
+    prepare_multiple_dna_sequences_w_rc,
+)
+from .fasta import FASTAError, read_nucleotide_fasta, shard_nucleotide_fasta
+
+__all__ = [
+    "factorize_dna_w_rc", "count_factors_dna_w_rc", "factorize_multiple_dna_w_rc",
+    "count_factors_multiple_dna_w_rc", "prepare_multiple_dna_sequences_w_rc",
+    "FASTAError", "read_nucleotide_fasta", "shard_nucleotide_fasta",
+]

@@ -1,0 +1,116 @@
+"""GPU parity of the plain factorize path against the oracle: intermediate arrays
+(SA, LCP, L*) and final factors, through the C ABI (nolzss_amd._noLZSS -> libnolzss_hip.so)."""
+import json
+import random
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import gen
+import oracle_lib as oracle
+
+pytestmark = pytest.mark.gpu
+
+KATS = json.loads((Path(__file__).parent / "golden" / "kats.json").read_text())
+
+
+@pytest.fixture(scope="module")
+def native():
+    from nolzss_amd import _noLZSS
+    assert _noLZSS.device_count() >= 1, "no MI355X visible"
+    return _noLZSS
+
+
+def _text(v):
+    if "input" in v:
+        return v["input"].encode("ascii")
+    s, k = v["input_repeat"]
+    return s.encode("ascii") * k
+
+
+def _cases():
+    rng = random.Random(99)
+    cases = {
+        "abracadabra": b"abracadabra",
+        "abracadabra_x1000": b"abracadabra" * 1000,
+        "single": b"A",
+        "two": b"AA",
+        "aaaa_5000": b"a" * 5000,
+        "ab_period": b"ab" * 3000 + b"b",
+        "acgt_period7": (b"ACGTTGA" * 2000)[:13001],
+        "dna_100": gen.random_dna(100, 1).tobytes(),
+        "dna_5000": gen.random_dna(5000, 2).tobytes(),
+        "dna_70k": gen.random_dna(70_000, 3).tobytes(),
+        "dna_1M": gen.random_dna(1 << 20, 4).tobytes(),
+        "repeat_300k": gen.repeat_dna(300_000, 5, lo=16, hi=4096).tobytes(),
+        "binary_20k": bytes(rng.choice(b"01") for _ in range(20_000)),
+        "protein_30k": bytes(rng.choice(b"ACDEFGHIKLMNPQRSTVWY") for _ in range(30_000)),
+        "bytes_50k": bytes(rng.randrange(1, 256) for _ in range(50_000)),
+        "bytes_with_nul_tail": bytes(rng.randrange(1, 256) for _ in range(999)) + b"\x00",
+        "all256": bytes(range(256)) * 40,
+        "fib": None,
+    }
+    a, b = b"a", b"ab"
+    while len(b) < 40_000:
+        a, b = b, b + a
+    cases["fib"] = b
+    return cases
+
+
+CASES = _cases()
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_intermediate_arrays(native, name):
+    t = CASES[name]
+    n = len(t)
+    d = native.debug_arrays(t)
+    sa = oracle.suffix_array(t)
+    assert np.array_equal(d["sa"].astype(np.int64), sa.astype(np.int64)), "suffix array"
+    isa = np.empty(n, dtype=np.int64)
+    isa[sa] = np.arange(n)
+    assert np.array_equal(d["isa"].astype(np.int64), isa), "inverse suffix array"
+    lcp = oracle.lcp_array(t, sa)
+    assert np.array_equal(d["lcp"][:n].astype(np.int64), lcp.astype(np.int64)), "LCP"
+    assert d["lcp"][n] == 0
+    ln, _ = oracle.lpnf_all(t)
+    got = d["lstar"].astype(np.int64)
+    got_len = np.where(got == 0, 1, got)
+    assert np.array_equal(got_len, ln.astype(np.int64)), "L* (per-position factor length)"
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_factorize_matches_oracle(native, name):
+    t = CASES[name]
+    got = native.factorize_array(t)
+    exp = oracle.factors_array(t)
+    assert len(got) == len(exp)
+    assert np.array_equal(got["start"], exp["start"])
+    assert np.array_equal(got["length"], exp["length"])
+    assert np.array_equal(got["ref"], exp["ref"])
+    assert native.count_factors(t) == len(exp)
+
+
+@pytest.mark.parametrize("v", KATS["plain"] + KATS["derived_plain"], ids=lambda v: v["source"][:40])
+def test_reference_kats(native, v):
+    assert native.factorize(_text(v)) == [tuple(f) for f in v["factors"]]
+
+
+def test_start_pos(native):
+    t = CASES["repeat_300k"]
+    for sp in (0, 1, 4095, 4096, 123_457, len(t) - 1):
+        got = native.factorize_array(t, start_pos=sp)
+        exp = oracle.factors_array(t, start_pos=sp)
+        assert np.array_equal(got["start"], exp["start"]) and np.array_equal(got["ref"], exp["ref"])
+        assert np.array_equal(got["length"], exp["length"])
+    assert len(native.factorize_array(t, start_pos=len(t))) == 0
+
+
+def test_many_random_small(native):
+    rng = random.Random(5)
+    for _ in range(150):
+        n = rng.randint(1, 300)
+        alpha = rng.choice([b"A", b"AC", b"ACGT", b"abcdefghijklmnopqrstuvwxyz"])
+        t = bytes(rng.choice(alpha) for _ in range(n))
+        assert native.factorize(t) == oracle.factorize(t), t
