@@ -71,10 +71,12 @@ int nolzss_count_factors_file(const char *path, size_t start_pos, int device, si
 
 /* Same computation with the text already resident in device memory (d_text is a device
  * pointer on `device`); `stream` is a hipStream_t or NULL for the context's own stream.
- * out_host may be NULL (count only).  Used by bench.py (inputs resident in HBM when the clock
- * starts) and by the multi-GPU shard dispatcher. */
+ * emit = 0: count only (the count_factors path);
+ * emit = 1: build all z factor records in HBM and stop there (no PCIe transfer);
+ * emit = 2: also copy them into a malloc'ed host array returned through out_host.
+ * Used by bench.py (inputs resident in HBM when the clock starts) and by the shard dispatcher. */
 int nolzss_factorize_device(const void *d_text, size_t n, size_t start_pos, int device,
-                            void *stream, nolzss_factor **out_host, size_t *z);
+                            void *stream, int emit, nolzss_factor **out_host, size_t *z);
 
 /* ---- reverse-complement DNA mode ---------------------------------------------------------- */
 /* reference: prepare_multiple_dna_sequences_w_rc, factorizer.cpp:54-172; bindings.cpp:732-740.
@@ -110,7 +112,8 @@ void nolzss_free_batch(nolzss_factor **out, size_t *z, size_t m);
 /* HIP-event timing of every pipeline stage on the context's stream (off by default). */
 int nolzss_profile_enable(int device, int on);
 int nolzss_profile_reset(int device);
-/* Writes lines "name count total_ms\n" into buf (NUL-terminated, truncated to cap). */
+/* Writes lines "name count total_ms algorithmic_bytes\n" into buf (NUL-terminated, truncated
+ * to cap).  Nested scopes are reported separately (a stage and the kernels inside it). */
 int nolzss_profile_report(int device, char *buf, size_t cap);
 
 /* ---- introspection used by the parity tests of the intermediate arrays -------------------- */

@@ -36,7 +36,7 @@ def _load():
     lib.nolzss_count_factors.argtypes = [vp, sz, sz, C.c_int, szp]
     lib.nolzss_factorize_file.argtypes = [C.c_char_p, sz, C.c_int, vpp, szp]
     lib.nolzss_count_factors_file.argtypes = [C.c_char_p, sz, C.c_int, szp]
-    lib.nolzss_factorize_device.argtypes = [vp, sz, sz, C.c_int, vp, vpp, szp]
+    lib.nolzss_factorize_device.argtypes = [vp, sz, sz, C.c_int, vp, C.c_int, vpp, szp]
     lib.nolzss_prepare_multiple_dna_w_rc.argtypes = [
         C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), sz, vpp, szp, szp, vpp, szp]
     lib.nolzss_factorize_multiple_dna_w_rc.argtypes = [vp, sz, sz, C.c_int, vpp, szp]

@@ -114,13 +114,15 @@ def count_factors_file(path: str) -> int:
     return z.value
 
 
-def factorize_device(data_ptr: int, n: int, stream: int = 0, want_factors: bool = True, start_pos: int = 0):
+def factorize_device(data_ptr: int, n: int, stream: int = 0, emit: int = 2, start_pos: int = 0):
     """Extension used by bench.py / the shard dispatcher: the text is already in HBM
-    (data_ptr = device address, e.g. torch.Tensor.data_ptr()).  Returns (z, factors-or-None)."""
+    (data_ptr = device address, e.g. torch.Tensor.data_ptr()).
+    emit 0: count only; 1: build the factor records in HBM, no download; 2: download them.
+    Returns (z, factor array or None)."""
     out, z = C.c_void_p(), C.c_size_t()
-    check(lib.nolzss_factorize_device(data_ptr, n, start_pos, _default_device, stream or None,
-                                      C.byref(out) if want_factors else None, C.byref(z)))
-    return z.value, (_take(out, z.value) if want_factors else None)
+    check(lib.nolzss_factorize_device(data_ptr, n, start_pos, _default_device, stream or None, emit,
+                                      C.byref(out) if emit == 2 else None, C.byref(z)))
+    return z.value, (_take(out, z.value) if emit == 2 else None)
 
 
 def factorize_batch(texts, devices=None, want_factors: bool = True):
@@ -233,14 +235,14 @@ def profile_reset() -> None:
 
 
 def profile_report() -> dict:
-    """{stage name: (launch count, total milliseconds)} measured with HIP events on the
-    pipeline stream."""
+    """{stage name: (launch count, total milliseconds, algorithmic bytes)} measured with HIP
+    events on the pipeline stream."""
     buf = C.create_string_buffer(1 << 16)
     check(lib.nolzss_profile_report(_default_device, buf, len(buf)))
     res = {}
     for line in buf.value.decode().splitlines():
-        name, count, ms = line.split()
-        res[name] = (int(count), float(ms))
+        name, count, ms, nbytes = line.split()
+        res[name] = (int(count), float(ms), float(nbytes))
     return res
 
 

@@ -94,7 +94,7 @@ void copy_out(Context &ctx, uint32_t *host, const uint32_t *dev, size_t count) {
 // The plain-mode pipeline on a device-resident text.  Returns z; *out_host (optional) receives
 // a malloc'ed array of z factors.
 size_t run_plain(Context &ctx, const uint8_t *d_text, size_t n, size_t start_pos, nolzss_factor **out_host,
-                 DebugOut *dbg) {
+                 DebugOut *dbg, bool records_on_device_only = false) {
     if (out_host) *out_host = nullptr;
     if (n == 0 || start_pos >= n) return 0;
     Arena &arena = ctx.arena;
@@ -123,7 +123,7 @@ size_t run_plain(Context &ctx, const uint8_t *d_text, size_t n, size_t start_pos
     }
     void *d_recs = nullptr;
     const uint32_t z = resolve_chain(ctx, (uint32_t)n, (uint32_t)start_pos, lstar, sa, isa, lcp, Psa, Plcp,
-                                     out_host ? &d_recs : nullptr);
+                                     (out_host || records_on_device_only) ? &d_recs : nullptr);
     if (out_host && z) {
         nolzss_factor *h = static_cast<nolzss_factor *>(std::malloc(sizeof(nolzss_factor) * (size_t)z));
         if (!h) throw std::bad_alloc();
@@ -383,15 +383,18 @@ int nolzss_count_factors_file(const char *path, size_t start_pos, int device, si
 }
 
 int nolzss_factorize_device(const void *d_text, size_t n, size_t start_pos, int device, void *stream,
-                            nolzss_factor **out_host, size_t *z) {
+                            int emit, nolzss_factor **out_host, size_t *z) {
     return guarded([&] {
         if (!z) throw std::invalid_argument("output pointer is null");
         *z = 0;
         if (out_host) *out_host = nullptr;
+        if (emit < 0 || emit > 2) throw std::invalid_argument("emit must be 0, 1 or 2");
+        if (emit == 2 && !out_host) throw std::invalid_argument("emit = 2 needs out_host");
         check_text_args(d_text, n, start_pos);
         Session ses(device, stream);
         ses.ctx().arena.reserve(arena_bytes_for(n));
-        *z = run_plain(ses.ctx(), static_cast<const uint8_t *>(d_text), n, start_pos, out_host, nullptr);
+        *z = run_plain(ses.ctx(), static_cast<const uint8_t *>(d_text), n, start_pos,
+                       emit == 2 ? out_host : nullptr, nullptr, emit == 1);
     });
 }
 
@@ -569,8 +572,8 @@ int nolzss_profile_report(int device, char *buf, size_t cap) {
         std::string text;
         for (const auto &kv : ses.ctx().prof.stats()) {
             char line[256];
-            snprintf(line, sizeof line, "%s %llu %.6f\n", kv.first.c_str(), (unsigned long long)kv.second.count,
-                     kv.second.total_ms);
+            snprintf(line, sizeof line, "%s %llu %.6f %.0f\n", kv.first.c_str(),
+                     (unsigned long long)kv.second.count, kv.second.total_ms, kv.second.bytes);
             text += line;
         }
         const size_t len = std::min(text.size(), cap - 1);

@@ -88,14 +88,16 @@ class Profiler {
     struct Stat {
         uint64_t count = 0;
         double total_ms = 0.0;
+        double bytes = 0.0;  // algorithmic bytes moved by the launches (0 if not stated)
     };
     ~Profiler() { drop(); }
     void enable(bool on) { on_ = on; }
     bool enabled() const { return on_; }
-    void start(const char *name, hipStream_t s) {
+    void start(const char *name, hipStream_t s, double bytes = 0.0) {
         if (!on_) return;
         Entry e;
         e.name = name;
+        e.bytes = bytes;
         HIP_CHECK(hipEventCreate(&e.a));
         HIP_CHECK(hipEventCreate(&e.b));
         HIP_CHECK(hipEventRecord(e.a, s));
@@ -116,6 +118,7 @@ class Profiler {
                 Stat &st = stats_[e.name];
                 st.count += 1;
                 st.total_ms += ms;
+                st.bytes += e.bytes;
             }
             (void)hipEventDestroy(e.a);
             (void)hipEventDestroy(e.b);
@@ -131,6 +134,7 @@ class Profiler {
   private:
     struct Entry {
         std::string name;
+        double bytes = 0.0;
         hipEvent_t a = nullptr, b = nullptr;
     };
     void drop() {
@@ -153,8 +157,8 @@ class Profiler {
 struct ProfScope {
     Profiler *p;
     hipStream_t s;
-    ProfScope(Profiler *prof, const char *name, hipStream_t stream) : p(prof), s(stream) {
-        if (p) p->start(name, s);
+    ProfScope(Profiler *prof, const char *name, hipStream_t stream, double bytes = 0.0) : p(prof), s(stream) {
+        if (p) p->start(name, s, bytes);
     }
     ~ProfScope() {
         if (p) p->stop(s);

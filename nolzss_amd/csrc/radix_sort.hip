@@ -142,20 +142,31 @@ __global__ __launch_bounds__(kThreads) void rs_scatter_kernel(
 }  // namespace
 
 int radix_sort_pairs(uint64_t *keys[2], uint32_t *vals[2], size_t n, const int *shifts,
-                     int npasses, Arena &arena, hipStream_t stream) {
+                     int npasses, Arena &arena, hipStream_t stream, Profiler *prof) {
     if (n == 0 || npasses == 0) return 0;
     const size_t m = arena.mark();
     const uint32_t num_tiles = (uint32_t)div_up(n, kTile);
     uint32_t *hist = arena.alloc<uint32_t>((size_t)kBins * num_tiles);
     int cur = 0;
     for (int p = 0; p < npasses; ++p) {
-        rs_hist_kernel<<<num_tiles, kThreads, 0, stream>>>(keys[cur], n, shifts[p], hist, num_tiles);
-        KERNEL_CHECK();
-        scan_exclusive_add_u32(hist, hist, (size_t)kBins * num_tiles, nullptr, arena, stream);
-        rs_scatter_kernel<<<num_tiles, kThreads, 0, stream>>>(keys[cur], vals[cur], keys[cur ^ 1],
-                                                              vals[cur ^ 1], n, shifts[p], hist,
-                                                              num_tiles);
-        KERNEL_CHECK();
+        {
+            ProfScope ps(prof, "rs_hist", stream, 8.0 * (double)n);
+            rs_hist_kernel<<<num_tiles, kThreads, 0, stream>>>(keys[cur], n, shifts[p], hist, num_tiles);
+            KERNEL_CHECK();
+        }
+        {
+            ProfScope ps(prof, "rs_scan", stream, 8.0 * (double)kBins * num_tiles);
+            scan_exclusive_add_u32(hist, hist, (size_t)kBins * num_tiles, nullptr, arena, stream);
+        }
+        {
+            // algorithmic bytes of one scatter launch: every (key, value) pair read once and
+            // written once = 2 * (8 + 4) bytes per pair
+            ProfScope ps(prof, "rs_scatter", stream, 24.0 * (double)n);
+            rs_scatter_kernel<<<num_tiles, kThreads, 0, stream>>>(keys[cur], vals[cur], keys[cur ^ 1],
+                                                                  vals[cur ^ 1], n, shifts[p], hist,
+                                                                  num_tiles);
+            KERNEL_CHECK();
+        }
         cur ^= 1;
     }
     arena.rewind(m);

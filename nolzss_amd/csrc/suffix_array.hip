@@ -310,7 +310,7 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     {
         const int shifts[8] = {0, 8, 16, 24, 32, 40, 48, 56};
         ProfScope ps(ctx.profiler(), "sa_sort_initial", s);
-        cur = radix_sort_pairs(keys, vals, n, shifts, 8, arena, s);
+        cur = radix_sort_pairs(keys, vals, n, shifts, 8, arena, s, ctx.profiler());
     }
     uint32_t m = regroup(ctx, keys[cur], vals[cur], nullptr, n, sa, rank, act[0], tmp_a, tmp_b, d_total);
 
@@ -334,7 +334,7 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         }
         {
             ProfScope ps(ctx.profiler(), "sa_sort_round", s);
-            cur = radix_sort_pairs(keys, vals, m, shifts, npasses, arena, s);
+            cur = radix_sort_pairs(keys, vals, m, shifts, npasses, arena, s, ctx.profiler());
         }
         m = regroup(ctx, keys[cur], vals[cur], act[a_cur], m, sa, rank, act[a_cur ^ 1], tmp_a, tmp_b, d_total);
         a_cur ^= 1;
