@@ -29,7 +29,12 @@ constexpr int kTile = 4096;
 constexpr int kPerThread = kTile / kThreads;  // 16
 constexpr uint32_t kNone = 0xffffffffu;
 
-__device__ __forceinline__ uint32_t next_pos(uint32_t p, uint32_t L, uint32_t n) {
+// L* codes: bit 31 flags a reverse-complement factor (RC mode only), bits 0..30 the length,
+// 0 = literal.
+constexpr uint32_t kLenMask = 0x7fffffffu;
+
+__device__ __forceinline__ uint32_t next_pos(uint32_t p, uint32_t code, uint32_t n) {
+    const uint32_t L = code & kLenMask;
     const uint64_t nx = (uint64_t)p + (L ? L : 1u);
     return nx > n ? n : (uint32_t)nx;
 }
@@ -237,21 +242,30 @@ struct FactorRec {
     uint64_t start, length, ref;
 };
 
-// (start, length, ref) per factor; ref = leftmost occurrence of the factor string = min SA over
-// I(L*) (the reference reports v_min / u_min, factorizer_core.hpp:91,100,105).
+// (start, length, ref) per factor.
+//   forward factor: ref = leftmost occurrence of the factor string = min SA over I(L)
+//     (the reference reports v_min / u_min, factorizer_core.hpp:91,100,105; in RC mode
+//     best_fwd_start, :284,360 -- the minimum over I(L) in both of the cases DESIGN.md 3 lists);
+//   reverse-complement factor (kRC): the reference keeps the smallest T-coordinate END among the
+//     rc-strand suffixes of the node (rc_ends = 2N - SA, factorizer_core.hpp:226-228, 270,
+//     294-296), i.e. the LARGEST SA value in I(L); ref = RC_MASK | (end - L + 1)  (:362-364).
+template <bool kRC>
 __global__ __launch_bounds__(kThreads) void factor_kernel(const uint32_t *__restrict__ fpos, uint32_t z,
                                                           const uint32_t *__restrict__ lstar,
                                                           const uint32_t *__restrict__ isa,
                                                           const uint32_t *__restrict__ sa,
                                                           const uint32_t *__restrict__ lcp, Pyramid Psa,
-                                                          Pyramid Plcp, FactorRec *__restrict__ out) {
+                                                          Pyramid Plcp, Pyramid Pmax, uint32_t rcN,
+                                                          FactorRec *__restrict__ out) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < z; k += stride) {
         const uint32_t i = fpos[k];
-        const uint32_t L = lstar[i];
+        const uint32_t code = lstar[i];
+        const uint32_t L = code & kLenMask;
+        const bool is_rc = kRC && (code >> 31);
         FactorRec f;
         f.start = i;
-        if (L == 0) {  // literal: factorizer_core.hpp:83-88
+        if (L == 0) {  // literal: factorizer_core.hpp:83-88 / :305-316, 354-357
             f.length = 1;
             f.ref = i;
         } else {
@@ -273,18 +287,33 @@ __global__ __launch_bounds__(kThreads) void factor_kernel(const uint32_t *__rest
                 }
             }
             hi -= 1;
-            uint32_t mn;
-            if (hi - lo < 96) {
-                mn = kNone;
-                for (uint32_t q = lo; q <= hi; ++q) {
-                    const uint32_t v = sa[q];
-                    mn = v < mn ? v : mn;
-                }
-            } else {
-                mn = pyr_range<false>(Psa, lo, hi);
-            }
             f.length = L;
-            f.ref = mn;
+            if (!is_rc) {
+                uint32_t mn;
+                if (hi - lo < 96) {
+                    mn = kNone;
+                    for (uint32_t q = lo; q <= hi; ++q) {
+                        const uint32_t v = sa[q];
+                        mn = v < mn ? v : mn;
+                    }
+                } else {
+                    mn = pyr_range<false>(Psa, lo, hi);
+                }
+                f.ref = mn;
+            } else {
+                uint32_t mx;
+                if (hi - lo < 96) {
+                    mx = 0;
+                    for (uint32_t q = lo; q <= hi; ++q) {
+                        const uint32_t v = sa[q];
+                        mx = v > mx ? v : mx;
+                    }
+                } else {
+                    mx = pyr_range<true>(Pmax, lo, hi);
+                }
+                const uint64_t end = 2ull * rcN - mx;  // T-coordinate of the last matched base
+                f.ref = (1ull << 63) | (end - L + 1);
+            }
         }
         out[k] = f;
     }
@@ -300,9 +329,11 @@ inline unsigned grid_for(size_t items, unsigned cap = 256u * 16u) {
 
 // Returns z; if d_factors_out != nullptr the z factor records are left in arena memory (this
 // stage's temporaries are then NOT released: the caller rewinds after copying the records out).
+// Plain mode: rcN = 0, Pmax unused.  RC mode: n = N (factorized prefix of S), rcN = N and Pmax
+// is the max pyramid over SA.
 uint32_t resolve_chain(Context &ctx, uint32_t n, uint32_t start_pos, const uint32_t *lstar, const uint32_t *sa,
                        const uint32_t *isa, const uint32_t *lcp, const Pyramid &Psa, const Pyramid &Plcp,
-                       void **d_factors_out) {
+                       void **d_factors_out, uint32_t rcN, const Pyramid *Pmax) {
     hipStream_t s = ctx.stream;
     Arena &arena = ctx.arena;
     if (d_factors_out) *d_factors_out = nullptr;
@@ -379,7 +410,12 @@ uint32_t resolve_chain(Context &ctx, uint32_t n, uint32_t start_pos, const uint3
         ProfScope ps(ctx.profiler(), "factor_emit", s);
         emit_positions_kernel<<<num_tiles, 64, 0, s>>>(cbits, tile_count, fpos);
         KERNEL_CHECK();
-        factor_kernel<<<grid_for(z), kThreads, 0, s>>>(fpos, z, lstar, isa, sa, lcp, Psa, Plcp, recs_tmp);
+        if (rcN)
+            factor_kernel<true><<<grid_for(z), kThreads, 0, s>>>(fpos, z, lstar, isa, sa, lcp, Psa, Plcp, *Pmax,
+                                                                 rcN, recs_tmp);
+        else
+            factor_kernel<false><<<grid_for(z), kThreads, 0, s>>>(fpos, z, lstar, isa, sa, lcp, Psa, Plcp, Psa, 0u,
+                                                                  recs_tmp);
         KERNEL_CHECK();
     }
     // the caller owns the arena mark: stage temporaries stay allocated until it rewinds

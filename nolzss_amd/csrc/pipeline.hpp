@@ -30,4 +30,19 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
 // lcp[0] = 0, lcp[r] = lcp(suffix sa[r-1], suffix sa[r]); lcp has n+1 entries, lcp[n] = 0.
 void build_lcp(Context &ctx, const PackedText &text, const uint32_t *sa, uint32_t *lcp);
 
+struct Pyramid;
+
+// ---- stage 4: per-position factor length codes (lpnf.hip) ---------------------------------
+// lstar[i] = L*[i] (0 = literal).  Returns the number of positions that needed the exact search.
+uint32_t build_lstar(Context &ctx, uint32_t n, const uint32_t *sa, const uint32_t *isa, const uint32_t *lcp,
+                     const Pyramid &Psa, const Pyramid &Plcp, uint32_t *lstar);
+
+// ---- stage 5: greedy cursor + factor records (chain.hip) ------------------------------------
+uint32_t resolve_chain(Context &ctx, uint32_t n, uint32_t start_pos, const uint32_t *lstar, const uint32_t *sa,
+                       const uint32_t *isa, const uint32_t *lcp, const Pyramid &Psa, const Pyramid &Plcp,
+                       void **d_factors_out, uint32_t rcN = 0, const Pyramid *Pmax = nullptr);
+
+// ---- reverse-complement mode (rc.hip): whole pipeline over the prepared string S -------------
+uint32_t run_rc_pipeline(Context &ctx, const uint8_t *d_S, size_t m, size_t start_pos, void **d_factors_out);
+
 }  // namespace nolzss

@@ -1,10 +1,155 @@
-// rc.hip -- reverse-complement DNA mode (detail::nolzss_multiple_dna_w_rc).
+// rc.hip -- reverse-complement DNA mode on the device.
+//
+// Restates detail::nolzss_multiple_dna_w_rc (/root/reference/src/cpp/factorizer_core.hpp:177-383)
+// over the prepared string  S = T1 s0 ... Tk s(k-1) rc(Tk) sk ... rc(T1) s(2k-1)
+// (prepare_multiple_dna_sequences_w_rc, factorizer.cpp:54-172);  N = |S|/2 - 1  (:195).
+//
+// Array form of the reference's ancestor walk, r = ISA[i], i < N:
+//   forward candidate  (fwd_starts / rmqF, :211-231, 264-266, 280-287, 322-326)
+//       L_f  = max{ d : min SA[I(d)] + d <= i }                 -- as in plain mode, over S
+//       d_u  = deepest EXPLICIT node depth <= L_f = max(LCP[lo], LCP[hi+1]) for [lo,hi] = I(L_f+1)
+//       j    = min SA[I(d_u)],   fwd = min(lcp(i, j), i - j)     -- may be shorter than L_f
+//   reverse-complement candidate  (rc_ends / rmqRcEnd, :224-232, 269-271, 290-299, 328-330)
+//       rc_ends[k] = 2N - SA[k] for rc-strand suffixes, so  rc_ends < i  <=>  SA[k] > 2N - i:
+//       rc   = longest LCP between suffix i and a suffix starting after 2N - i
+//            = nearest GREATER SA value above / below r (max pyramid), running LCP minimum
+//   selection  (:338-352)  forward wins ties; RC must beat the forward match, or 1 if none.
+// When the best forward neighbour does not overlap position i (the common case) L_f is an LCA
+// depth, hence explicit, and fwd = L_f directly; only overlapping positions take the exact path.
+#include "nearest.hpp"
 #include "pipeline.hpp"
 
 namespace nolzss {
+namespace {
 
-uint32_t run_rc_pipeline(Context &, const uint8_t *, size_t, size_t, void **) {
-    throw std::runtime_error("reverse-complement mode: device pipeline not built yet");
+constexpr int kThreads = 256;
+constexpr uint32_t kRcFlag = 0x80000000u;
+
+__device__ __forceinline__ uint32_t rc_select(uint32_t fwd, uint32_t rc) {
+    if (fwd >= 1) return (rc > fwd) ? (rc | kRcFlag) : fwd;  // :338-344
+    return (rc > 1) ? (rc | kRcFlag) : 0u;                   // :345-352 (0 = literal)
+}
+
+__global__ __launch_bounds__(kThreads) void rc_candidates_kernel(
+    const uint32_t *__restrict__ sa, const uint32_t *__restrict__ lcp, uint32_t m, uint32_t N, Pyramid Pmin,
+    Pyramid Pmax, Pyramid Plcp, uint32_t *__restrict__ code, uint32_t *__restrict__ queue,
+    uint32_t *__restrict__ queue_rc, uint32_t *__restrict__ queue_count) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t rr = (size_t)blockIdx.x * blockDim.x + threadIdx.x; rr < m; rr += stride) {
+        const uint32_t r = (uint32_t)rr;
+        const uint32_t i = sa[r];
+        if (i >= N) continue;  // only positions of the original strand are factorized (:241)
+
+        // forward: earlier suffixes, SA[q] < i
+        uint32_t lp, jp, ls, js;
+        nearest_up<false>(sa, lcp, Pmin, Plcp, r, i, 0u, lp, jp);
+        nearest_down<false>(sa, lcp, m, Pmin, Plcp, r, i, lp, ls, js);
+        const uint32_t M = lp > ls ? lp : ls;
+        const bool fwd_final = (M == 0) || (lp == M && i - jp >= M) || (ls == M && i - js >= M);
+
+        // reverse complement: suffixes starting after 2N - i.  A candidate can only matter if it
+        // is longer than the forward match (or than a literal).
+        const uint32_t thr = 2u * N - i;
+        const uint32_t floor = fwd_final ? (M >= 1 ? M + 1 : 2u) : 2u;
+        uint32_t ru, rd, unused;
+        nearest_up<true>(sa, lcp, Pmax, Plcp, r, thr, floor, ru, unused);
+        nearest_down<true>(sa, lcp, m, Pmax, Plcp, r, thr, ru > floor ? ru : floor, rd, unused);
+        const uint32_t rc = ru > rd ? ru : rd;
+
+        if (fwd_final) {
+            code[i] = rc_select(M, rc);
+            continue;
+        }
+        uint32_t lo = 0;
+        if (lp > 0) { const uint32_t c = lp < i - jp ? lp : i - jp; lo = c > lo ? c : lo; }
+        if (ls > 0) { const uint32_t c = ls < i - js ? ls : i - js; lo = c > lo ? c : lo; }
+        code[i] = lo;  // provisional: P(lo) holds
+        const uint32_t k = atomicAdd(queue_count, 1u);
+        queue[k] = i;
+        queue_rc[k] = rc;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void rc_fallback_kernel(const uint32_t *__restrict__ queue,
+                                                               const uint32_t *__restrict__ queue_rc,
+                                                               uint32_t count, uint32_t m,
+                                                               const uint32_t *__restrict__ isa,
+                                                               const uint32_t *__restrict__ lcp, Pyramid Pmin,
+                                                               Pyramid Plcp, uint32_t *__restrict__ code) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < count; k += stride) {
+        const uint32_t i = queue[k];
+        const uint32_t r = isa[i];
+        const uint32_t cap = (m - i) < i ? (m - i) : i;
+        const uint32_t Lf = lpnf_search(Pmin, Plcp, r, i, code[i], cap);  // >= 1 for queued positions
+        // deepest explicit ancestor of leaf(i) with depth <= L_f
+        uint32_t a, b;
+        lcp_interval(Plcp, r, Lf + 1, a, b);
+        const uint32_t da = lcp[a], db = lcp[b + 1];
+        const uint32_t d_u = da > db ? da : db;
+        if (d_u == 0) {  // cannot happen for L_f >= 1; keep the search well-defined
+            code[i] = rc_select(0u, queue_rc[k]);
+            continue;
+        }
+        lcp_interval(Plcp, r, d_u, a, b);
+        const uint32_t j = pyr_range<false>(Pmin, a, b);  // best_fwd_start (:284)
+        const uint32_t rj = isa[j];
+        const uint32_t x = r < rj ? r : rj, y = r < rj ? rj : r;
+        const uint32_t l = pyr_range<false>(Plcp, x + 1, y);  // lcp(cst, i, best_fwd_start) (:324)
+        const uint32_t fwd = l < i - j ? l : i - j;           // :323-325
+        code[i] = rc_select(fwd, queue_rc[k]);
+    }
+}
+
+}  // namespace
+
+uint32_t run_rc_pipeline(Context &ctx, const uint8_t *d_S, size_t m_sz, size_t start_pos, void **d_factors_out) {
+    const uint32_t m = (uint32_t)m_sz;
+    const uint32_t N = m / 2 - 1;
+    hipStream_t s = ctx.stream;
+    Arena &arena = ctx.arena;
+
+    PackedText text = pack_text(ctx, d_S, m);
+    uint32_t *sa = arena.alloc<uint32_t>(m);
+    uint32_t *isa = arena.alloc<uint32_t>(m);
+    build_suffix_array(ctx, text, sa, isa);
+    uint32_t *lcp = arena.alloc<uint32_t>((size_t)m + 1);
+    build_lcp(ctx, text, sa, lcp);
+    Pyramid Pmin, Pmax, Plcp;
+    {
+        ProfScope ps(ctx.profiler(), "pyramids", s);
+        Pmin = build_pyramid(sa, m, false, arena, s);
+        Pmax = build_pyramid(sa, m, true, arena, s);
+        Plcp = build_pyramid(lcp, m + 1, false, arena, s);
+    }
+    uint32_t *code = arena.alloc<uint32_t>(N);
+    {
+        const size_t mark = arena.mark();
+        uint32_t *queue = arena.alloc<uint32_t>(N);
+        uint32_t *queue_rc = arena.alloc<uint32_t>(N);
+        uint32_t *count = arena.alloc<uint32_t>(1);
+        HIP_CHECK(hipMemsetAsync(count, 0, sizeof(uint32_t), s));
+        {
+            ProfScope ps(ctx.profiler(), "rc_candidates", s);
+            size_t g = div_up(m, kThreads);
+            if (g > 256u * 32u) g = 256u * 32u;
+            rc_candidates_kernel<<<(unsigned)g, kThreads, 0, s>>>(sa, lcp, m, N, Pmin, Pmax, Plcp, code, queue,
+                                                                  queue_rc, count);
+            KERNEL_CHECK();
+        }
+        uint32_t h_count = 0;
+        ctx.read_back(count, &h_count, 1);
+        if (h_count > 0) {
+            ProfScope ps(ctx.profiler(), "rc_fallback", s);
+            size_t g = div_up(h_count, kThreads);
+            if (g > 256u * 32u) g = 256u * 32u;
+            rc_fallback_kernel<<<(unsigned)g, kThreads, 0, s>>>(queue, queue_rc, h_count, m, isa, lcp, Pmin, Plcp,
+                                                                code);
+            KERNEL_CHECK();
+        }
+        arena.rewind(mark);
+    }
+    return resolve_chain(ctx, N, (uint32_t)start_pos, code, sa, isa, lcp, Pmin, Plcp, d_factors_out, N, &Pmax);
 }
 
 }  // namespace nolzss

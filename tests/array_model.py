@@ -118,3 +118,38 @@ def factor_rc(sa, isa, lcp, m, N, i):
     if rc > 1:
         return (rc, end - rc + 1, True)
     return (1, i, False)
+
+
+def factor_rc_fastpath(sa, isa, lcp, m, N, i):
+    """Same result as factor_rc, organised the way rc_candidates_kernel / rc_fallback_kernel are:
+    when a best forward neighbour does not overlap position i the forward length is final and no
+    explicit-node bookkeeping is needed; reverse-complement candidates shorter than what the
+    forward side already has are pruned."""
+    r = isa[i]
+    (lp, jp), (ls, js) = _nearest(sa, lcp, m, r, lambda v: v < i)
+    M = max(lp, ls)
+    final = M == 0 or any(l == M and i - j >= M for (l, j) in ((lp, jp), (ls, js)) if l > 0)
+    thr = 2 * N - i
+    (ru, _), (rd, _) = _nearest(sa, lcp, m, r, lambda v: v > thr)
+    rc = max(ru, rd)
+    if final:
+        fwd = M
+    else:
+        Lf = lstar_plain(sa, isa, lcp, m, i)
+        a, b = _interval(lcp, m, r, Lf + 1)
+        d_u = max(lcp[a], lcp[b + 1] if b + 1 < m else 0)
+        a, b = _interval(lcp, m, r, d_u)
+        j = int(sa[a:b + 1].min())
+        fwd = min(_range_lcp(lcp, isa, i, j), i - j)
+    if fwd >= 1:
+        use_rc = rc > fwd
+    else:
+        use_rc = rc > 1
+        if not use_rc:
+            return (1, i, False)
+    L = rc if use_rc else fwd
+    a, b = _interval(lcp, m, r, L)
+    if use_rc:
+        end = 2 * N - int(sa[a:b + 1].max())
+        return (L, end - L + 1, True)
+    return (L, int(sa[a:b + 1].min()), False)
