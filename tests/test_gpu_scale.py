@@ -1,0 +1,124 @@
+"""GPU parity at the BASELINE.json sizes: exact against the oracle where the oracle finishes in
+seconds (config 2, FASTA records, a 4 Mi RC case), size-independent properties at full size
+(config 3: 2^30 bases; config 5: 2^28 bases + RC strand)."""
+import numpy as np
+import pytest
+
+import gen
+import oracle_lib as oracle
+
+pytestmark = pytest.mark.gpu
+
+COMP = np.zeros(256, dtype=np.uint8)
+for a, b in zip(b"ACGT", b"TGCA"):
+    COMP[a] = b
+
+
+@pytest.fixture(scope="module")
+def native():
+    from nolzss_amd import _noLZSS
+    assert _noLZSS.device_count() >= 1, "no MI355X visible"
+    return _noLZSS
+
+
+def _check_tiling(f, n, start=0):
+    assert f["start"][0] == start
+    assert np.array_equal(f["start"][1:], f["start"][:-1] + f["length"][:-1])
+    assert int(f["start"][-1] + f["length"][-1]) == n
+    assert f["length"].min() >= 1
+
+
+def _check_matches(text, f, sample, rng, rc_mode=False):
+    idx = rng.choice(len(f), size=min(sample, len(f)), replace=False)
+    for k in idx.tolist():
+        s, l, r = int(f["start"][k]), int(f["length"][k]), int(f["ref"][k])
+        is_rc = bool(r >> 63)
+        r &= (1 << 63) - 1
+        if not is_rc and r == s:
+            assert l == 1
+            continue
+        assert r + l <= s, (s, l, r, is_rc)
+        src = text[r:r + l]
+        if is_rc:
+            assert rc_mode
+            src = COMP[src[::-1]]
+        assert np.array_equal(src, text[s:s + l]), (s, l, r, is_rc)
+
+
+@pytest.mark.timeout(900)
+def test_config2_random_64Mi_exact(native):
+    """BASELINE config 2: 64 Mi iid ACGT, every factor compared with the oracle."""
+    n = 1 << 26
+    text = gen.random_dna(n)
+    got = native.factorize_array(text)
+    exp = oracle.factors_array(text)
+    assert len(got) == len(exp)
+    for k in ("start", "length", "ref"):
+        assert np.array_equal(got[k], exp[k]), k
+    assert native.count_factors(text) == len(exp)
+
+
+@pytest.mark.timeout(1200)
+def test_config3_repeat_1Gi_properties_and_prefix_exact(native):
+    """BASELINE config 3: 2^30 bases, 40 % copied blocks.  Tiling + sampled true-match checks on
+    the full result; the factors that end inside the first 2^24 bases are compared one by one with
+    the oracle run on that prefix (a greedy parse of a prefix is a prefix of the parse)."""
+    n = 1 << 30
+    text = gen.repeat_dna(n)
+    f = native.factorize_array(text)
+    _check_tiling(f, n)
+    _check_matches(text, f, 50_000, np.random.default_rng(1))
+    P = 1 << 24
+    exp = oracle.factors_array(text[:P])
+    cut = int(np.searchsorted(f["start"] + f["length"], P, side="right"))
+    assert cut > 500_000 and cut <= len(exp)
+    for k in ("start", "length", "ref"):
+        assert np.array_equal(f[k][:cut], exp[k][:cut]), k
+    assert native.count_factors(text) == len(f)
+
+
+@pytest.mark.timeout(900)
+def test_config4_fasta_records_batch(native, tmp_path):
+    """BASELINE config 4 shape at reduced record count (16 x 4 Mi instead of 512 x 4 Mi; the
+    full count only repeats the same independent unit): batch / FASTA path vs oracle."""
+    from nolzss_amd.genomics import read_nucleotide_fasta
+    recs = gen.fasta_records(16, 1 << 22)
+    counts, arrays = native.factorize_batch([s for _, s in recs], want_factors=True)
+    for j in (0, 7, 15):
+        exp = oracle.factors_array(recs[j][1])
+        assert counts[j] == len(exp)
+        for k in ("start", "length", "ref"):
+            assert np.array_equal(arrays[j][k], exp[k])
+    counts2, none = native.factorize_batch([s for _, s in recs], want_factors=False)
+    assert counts2 == counts and none is None
+    small = [(f"s{k}", gen.random_dna(3000 + 17 * k, 900 + k)) for k in range(5)]
+    path = tmp_path / "small.fa"
+    gen.write_fasta(path, small)
+    res = read_nucleotide_fasta(path)
+    assert [rid for rid, _ in res] == [rid for rid, _ in small]
+    for (rid, factors), (_, seq) in zip(res, small):
+        assert factors == oracle.factorize(seq)
+
+
+@pytest.mark.timeout(900)
+def test_rc_4Mi_exact(native):
+    text = gen.repeat_dna(1 << 22, seed=0x5EED0005, lo=16, hi=8192)
+    got = native.factorize_dna_w_rc_array(text)
+    S, _, _ = oracle.prepare_multiple_dna_w_rc([text.tobytes()])
+    exp = oracle.factors_array_multiple_dna_w_rc(S)
+    assert len(got) == len(exp)
+    for k in ("start", "length", "ref"):
+        assert np.array_equal(got[k], exp[k]), k
+
+
+@pytest.mark.timeout(1200)
+def test_config5_rc_256Mi_properties(native):
+    """BASELINE config 5 size: 2^28 bases + RC strand.  Tiling, sampled (reverse-complement)
+    true-match checks, and count == len."""
+    n = 1 << 28
+    text = gen.repeat_dna(n, seed=0x5EED0005)
+    f = native.factorize_dna_w_rc_array(text)
+    _check_tiling(f, n)
+    _check_matches(text, f, 50_000, np.random.default_rng(2), rc_mode=True)
+    assert (f["ref"] >> np.uint64(63)).any(), "no reverse-complement factor at all?"
+    assert native.count_factors_dna_w_rc(text) == len(f)

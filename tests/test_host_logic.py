@@ -1,0 +1,166 @@
+"""CPU tests (no GPU): the C-ABI library loads and exports every declared symbol, the host-side
+mirror of the reference interface behaves like the reference (validation, FASTA parsing, error
+types), and the product path fails loudly without a device."""
+import ctypes
+import re
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_library_exports_every_declared_symbol():
+    from nolzss_amd import _lib
+    header = (ROOT / "include" / "nolzss_hip.h").read_text()
+    declared = set(re.findall(r"\b(nolzss_[a-z_0-9]+)\s*\(", header))
+    declared -= {"nolzss_factor"}
+    assert declared, "no declarations parsed"
+    lib = ctypes.CDLL(str(_lib.LIB_PATH))
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/nolzss_hip.h but not exported"
+    assert declared == set(_lib.EXPORTED_SYMBOLS)
+
+
+def test_version_and_error_string():
+    from nolzss_amd import _noLZSS
+    assert _noLZSS.__version__.startswith("0.")
+    assert isinstance(_noLZSS.lib.nolzss_last_error(), bytes)
+
+
+def test_reference_module_names_exist():
+    """names the reference imports from _noLZSS at package import time"""
+    from nolzss_amd import _noLZSS
+    for name in ["factorize", "factorize_file", "count_factors", "count_factors_file",
+                 "write_factors_binary_file", "factorize_w_reference", "factorize_w_reference_file",
+                 "factorize_dna_w_rc", "factorize_file_dna_w_rc", "count_factors_dna_w_rc",
+                 "count_factors_file_dna_w_rc", "write_factors_binary_file_dna_w_rc",
+                 "factorize_multiple_dna_w_rc", "factorize_file_multiple_dna_w_rc",
+                 "count_factors_multiple_dna_w_rc", "count_factors_file_multiple_dna_w_rc",
+                 "write_factors_binary_file_multiple_dna_w_rc", "factorize_fasta_multiple_dna_w_rc",
+                 "prepare_multiple_dna_sequences_w_rc", "Factor", "__version__"]:
+        assert hasattr(_noLZSS, name), name
+    with pytest.raises(NotImplementedError):
+        _noLZSS.write_factors_binary_file("a", "b")
+
+
+def test_validate_input_mirrors_reference():
+    """reference: tests/test_utils.py:26-73, src/noLZSS/utils.py:26-58"""
+    from nolzss_amd import InvalidInputError, validate_input
+    assert validate_input("hello") == b"hello"
+    assert validate_input(b"hello") == b"hello"
+    assert validate_input(b"abc\x00") == b"abc\x00"          # NUL allowed only as last byte
+    with pytest.raises(InvalidInputError):
+        validate_input("")
+    with pytest.raises(InvalidInputError):
+        validate_input(b"")
+    with pytest.raises(InvalidInputError):
+        validate_input(b"a\x00b")
+    with pytest.raises(InvalidInputError):
+        validate_input("héllo")
+    with pytest.raises(TypeError):
+        validate_input(123)
+    with pytest.raises(TypeError):
+        validate_input(bytearray(b"abc"))
+
+
+def test_core_wrappers_validate_before_native(tmp_path):
+    """reference: src/noLZSS/core.py:25-107 -- errors raised before the extension is touched"""
+    import nolzss_amd
+    with pytest.raises(nolzss_amd.InvalidInputError):
+        nolzss_amd.factorize("")
+    with pytest.raises(TypeError):
+        nolzss_amd.count_factors(12)
+    with pytest.raises(FileNotFoundError):
+        nolzss_amd.factorize_file(tmp_path / "missing.txt")
+    with pytest.raises(FileNotFoundError):
+        nolzss_amd.count_factors_file(tmp_path / "missing.txt")
+
+
+def test_buffer_contract():
+    """bindings.cpp:59-64: 1-D, itemsize 1, else ValueError"""
+    import numpy as np
+    from nolzss_amd import _noLZSS
+    with pytest.raises(ValueError):
+        _noLZSS._as_buffer(np.zeros(4, dtype=np.uint16))
+    with pytest.raises(ValueError):
+        _noLZSS._as_buffer(np.zeros((2, 2), dtype=np.uint8))
+    with pytest.raises(TypeError):
+        _noLZSS._as_buffer(3.5)
+    p, n, keep = _noLZSS._as_buffer(bytearray(b"abc"))
+    assert n == 3
+
+
+def test_no_cpu_fallback_without_device():
+    """The product path must fail loudly when no GPU is usable (never route through a CPU path)."""
+    import nolzss_amd
+    from nolzss_amd import _noLZSS
+    if _noLZSS.device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        nolzss_amd.factorize(b"abracadabra")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        nolzss_amd.count_factors(b"abracadabra")
+    from nolzss_amd.genomics import factorize_dna_w_rc
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        factorize_dna_w_rc(b"ACGT")
+
+
+def test_product_never_imports_oracle():
+    for path in (ROOT / "nolzss_amd").rglob("*"):
+        if path.suffix in {".py", ".hip", ".hpp", ".h"} or path.name == "Makefile":
+            text = path.read_text(errors="ignore")
+            assert "oracle" not in text.lower(), f"{path} mentions the oracle"
+
+
+def test_prepare_w_rc_host_side_matches_oracle():
+    """prepare_* is host-side O(n) code in the C ABI (no GPU needed)."""
+    import oracle_lib as oracle
+    from nolzss_amd import _noLZSS
+    for seqs in (["ACGT"], ["acgt", "TTGA", "C"], ["A"] * 125, ["AC", "", "GT"]):
+        assert _noLZSS.prepare_multiple_dna_sequences_w_rc_bytes(seqs) == oracle.prepare_multiple_dna_w_rc(seqs)
+    s, orig, sent = _noLZSS.prepare_multiple_dna_sequences_w_rc(["ACGT", "GG"])
+    assert isinstance(s, str) and orig == 8 and sent == [4, 7, 10, 15]
+    with pytest.raises(ValueError):                       # std::invalid_argument, factorizer.cpp:81-83
+        _noLZSS.prepare_multiple_dna_sequences_w_rc(["A"] * 126)
+    with pytest.raises(RuntimeError):                     # std::runtime_error, :86-95
+        _noLZSS.prepare_multiple_dna_sequences_w_rc(["ACGX"])
+    with pytest.raises(RuntimeError):                     # :76-78
+        _noLZSS.prepare_multiple_dna_sequences_w_rc(["", ""])
+    assert _noLZSS.prepare_multiple_dna_sequences_w_rc([]) == ("", 0, [])
+    with pytest.raises(UnicodeDecodeError):               # sentinel bytes >= 128 cannot become str
+        _noLZSS.prepare_multiple_dna_sequences_w_rc(["A"] * 70)
+
+
+def test_fasta_parsing_mirrors_reference(tmp_path):
+    """reference: tests/test_genomics.py:96-144, src/noLZSS/genomics/fasta.py:28-76"""
+    from nolzss_amd.genomics.fasta import FASTAError, _parse_fasta_content, _load_validated
+    d = _parse_fasta_content(">seq1 some description\nacgt\nAC GT\n\n>seq2\nTTTT\n")
+    assert d == {"seq1": "ACGTACGT", "seq2": "TTTT"}
+    assert list(_parse_fasta_content(">a\nAC\n>b\nGG\n>a\nTT\n").items()) == [("a", "TT"), ("b", "GG")]
+    with pytest.raises(FASTAError):
+        _parse_fasta_content(">\nACGT\n")
+    with pytest.raises(FASTAError):
+        _parse_fasta_content("ACGT\n>x\nAC\n")
+    with pytest.raises(FASTAError):
+        _parse_fasta_content("\n\n")
+    p = tmp_path / "bad.fa"
+    p.write_text(">x\nACGTN\n")
+    with pytest.raises(FASTAError):
+        _load_validated(p)
+    with pytest.raises(FileNotFoundError):
+        _load_validated(tmp_path / "nope.fa")
+    p2 = tmp_path / "ok.fa"
+    p2.write_text(">x\nacgt\n>y z\nGG\n")
+    assert _load_validated(p2) == [("x", b"ACGT"), ("y", b"GG")]
+
+
+def test_lpt_assignment_is_deterministic_and_balanced():
+    from nolzss_amd.genomics.fasta import lpt_assignment
+    lens = [10, 9, 8, 7, 6, 5, 4, 3, 2, 1]
+    own = lpt_assignment(lens, 3)
+    assert own == lpt_assignment(lens, 3)
+    loads = [sum(l for l, o in zip(lens, own) if o == b) for b in range(3)]
+    assert max(loads) - min(loads) <= max(lens)
+    assert lpt_assignment([5, 5, 5, 5], 4) == [0, 1, 2, 3]
+    assert lpt_assignment([], 2) == []
