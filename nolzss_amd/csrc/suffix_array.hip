@@ -148,32 +148,48 @@ __global__ __launch_bounds__(kThreads) void initial_keys_kernel(const uint64_t *
 // ---------------------------------------------------------------------------------------
 // regrouping after a sort
 // ---------------------------------------------------------------------------------------
+// The sorted view of the m active elements is either the 64-bit round-0 keys (kRound0) or, in
+// the doubling rounds, the pair (grp[a], lo[a]) = (slot of the element's current group head,
+// rank of the suffix h symbols further on).  Element a starts a new group iff its view differs
+// from element a-1.
+template <bool kRound0>
+__device__ __forceinline__ bool is_head(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ grp,
+                                        const uint32_t *__restrict__ lo, size_t a) {
+    if (a == 0) return true;
+    if (kRound0) return keys[a] != keys[a - 1];
+    return grp[a] != grp[a - 1] || lo[a] != lo[a - 1];
+}
+
 // headpos[a] = slot(a) if sorted element a starts a new group else 0 (max-scanned afterwards)
+template <bool kRound0>
 __global__ __launch_bounds__(kThreads) void mark_heads_kernel(const uint64_t *__restrict__ keys,
-                                                              const uint32_t *__restrict__ act_pos,
-                                                              uint32_t m, uint32_t *__restrict__ headpos) {
+                                                              const uint32_t *__restrict__ grp,
+                                                              const uint32_t *__restrict__ lo,
+                                                              const uint32_t *__restrict__ act_slot, uint32_t m,
+                                                              uint32_t *__restrict__ headpos) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x; a < m; a += stride) {
-        const bool head = (a == 0) || (keys[a] != keys[a - 1]);
-        const uint32_t slot = act_pos ? act_pos[a] : (uint32_t)a;
-        headpos[a] = head ? slot : 0u;
+        const uint32_t slot = kRound0 ? (uint32_t)a : act_slot[a];
+        headpos[a] = is_head<kRound0>(keys, grp, lo, a) ? slot : 0u;
     }
 }
 
 // writes the new order and ranks; keep[a] = 1 while a's group still has more than one member
+template <bool kRound0>
 __global__ __launch_bounds__(kThreads) void commit_kernel(const uint64_t *__restrict__ keys,
+                                                          const uint32_t *__restrict__ grp,
+                                                          const uint32_t *__restrict__ lo,
                                                           const uint32_t *__restrict__ vals,
-                                                          const uint32_t *__restrict__ act_pos,
+                                                          const uint32_t *__restrict__ act_slot,
                                                           const uint32_t *__restrict__ head_of, uint32_t m,
                                                           uint32_t *__restrict__ sa,
                                                           uint32_t *__restrict__ rank,
                                                           uint32_t *__restrict__ keep) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x; a < m; a += stride) {
-        const uint64_t k = keys[a];
-        const bool head = (a == 0) || (k != keys[a - 1]);
-        const bool next_head = (a + 1 == m) || (keys[a + 1] != k);
-        const uint32_t slot = act_pos ? act_pos[a] : (uint32_t)a;
+        const bool head = is_head<kRound0>(keys, grp, lo, a);
+        const bool next_head = (a + 1 == m) || is_head<kRound0>(keys, grp, lo, a + 1);
+        const uint32_t slot = kRound0 ? (uint32_t)a : act_slot[a];
         const uint32_t i = vals[a];
         sa[slot] = i;
         rank[i] = head_of[a] + 1u;
@@ -181,27 +197,102 @@ __global__ __launch_bounds__(kThreads) void commit_kernel(const uint64_t *__rest
     }
 }
 
+// surviving elements keep their slot and learn the slot of their (new) group head
 __global__ __launch_bounds__(kThreads) void compact_kernel(const uint32_t *__restrict__ keep,
                                                            const uint32_t *__restrict__ idx,
-                                                           const uint32_t *__restrict__ act_pos, uint32_t m,
-                                                           uint32_t *__restrict__ new_act) {
+                                                           const uint32_t *__restrict__ act_slot,
+                                                           const uint32_t *__restrict__ head_of, uint32_t m,
+                                                           uint32_t *__restrict__ new_slot,
+                                                           uint32_t *__restrict__ new_grp) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x; a < m; a += stride)
-        if (keep[a]) new_act[idx[a]] = act_pos ? act_pos[a] : (uint32_t)a;
+        if (keep[a]) {
+            const uint32_t k = idx[a];
+            new_slot[k] = act_slot ? act_slot[a] : (uint32_t)a;
+            new_grp[k] = head_of[a];
+        }
 }
 
-__global__ __launch_bounds__(kThreads) void round_keys_kernel(const uint32_t *__restrict__ act_pos,
+// secondary key of a doubling round: rank of the suffix h symbols further on (0 past the end)
+__global__ __launch_bounds__(kThreads) void round_keys_kernel(const uint32_t *__restrict__ act_slot,
                                                               uint32_t m, const uint32_t *__restrict__ sa,
                                                               const uint32_t *__restrict__ rank, uint32_t n,
-                                                              uint32_t h, uint64_t *__restrict__ keys,
+                                                              uint32_t h, uint32_t *__restrict__ lo,
                                                               uint32_t *__restrict__ vals) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x; a < m; a += stride) {
-        const uint32_t i = sa[act_pos[a]];
-        const uint32_t hi = rank[i];
-        const uint32_t lo = (n - i > h) ? rank[i + h] : 0u;  // i + h < n without overflow
-        keys[a] = ((uint64_t)hi << 32) | lo;
+        const uint32_t i = sa[act_slot[a]];
+        lo[a] = (n - i > h) ? rank[i + h] : 0u;  // i + h < n without overflow
         vals[a] = i;
+    }
+}
+
+// Segmented sort of the active list by lo inside each group.  Groups are contiguous in the
+// list and (for real sequence data) almost all tiny, so each element finds its place by
+// counting the smaller members of its own group -- one pass, no radix passes.  Members of
+// groups larger than kSmallGroup are flagged for the radix fallback instead.
+constexpr uint32_t kSmallGroup = 32;
+
+__global__ __launch_bounds__(kThreads) void small_sort_kernel(const uint32_t *__restrict__ act_slot,
+                                                              const uint32_t *__restrict__ act_grp,
+                                                              const uint32_t *__restrict__ lo,
+                                                              const uint32_t *__restrict__ vals, uint32_t m,
+                                                              uint32_t *__restrict__ out_lo,
+                                                              uint32_t *__restrict__ out_vals,
+                                                              uint32_t *__restrict__ large_flag) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x; a < m; a += stride) {
+        const uint32_t g = act_grp[a];
+        const size_t g0 = a - (act_slot[a] - g);  // list index of the group's first member
+        const uint32_t mine = lo[a];
+        uint32_t below = 0, cnt = 0;
+        bool large = false;
+        for (size_t b = g0; b < m; ++b) {
+            if (act_grp[b] != g) break;
+            if (++cnt > kSmallGroup) {
+                large = true;
+                break;
+            }
+            const uint32_t l = lo[b];
+            below += (l < mine || (l == mine && b < a)) ? 1u : 0u;
+        }
+        large_flag[a] = large ? 1u : 0u;
+        if (!large) {
+            out_lo[g0 + below] = mine;
+            out_vals[g0 + below] = vals[a];
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void gather_large_kernel(const uint32_t *__restrict__ large_flag,
+                                                                const uint32_t *__restrict__ idx,
+                                                                const uint32_t *__restrict__ act_grp,
+                                                                const uint32_t *__restrict__ lo,
+                                                                const uint32_t *__restrict__ vals, uint32_t m,
+                                                                uint64_t *__restrict__ lkeys,
+                                                                uint32_t *__restrict__ lvals,
+                                                                uint32_t *__restrict__ lidx) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x; a < m; a += stride)
+        if (large_flag[a]) {
+            const uint32_t k = idx[a];
+            lkeys[k] = ((uint64_t)act_grp[a] << 32) | lo[a];
+            lvals[k] = vals[a];
+            lidx[k] = (uint32_t)a;
+        }
+}
+
+// the k-th smallest large element goes to the k-th list position owned by a large group
+__global__ __launch_bounds__(kThreads) void scatter_large_kernel(const uint64_t *__restrict__ lkeys,
+                                                                 const uint32_t *__restrict__ lvals,
+                                                                 const uint32_t *__restrict__ lidx, uint32_t count,
+                                                                 uint32_t *__restrict__ out_lo,
+                                                                 uint32_t *__restrict__ out_vals) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < count; k += stride) {
+        const uint32_t a = lidx[k];
+        out_lo[a] = (uint32_t)lkeys[k];
+        out_vals[a] = lvals[k];
     }
 }
 
@@ -217,14 +308,15 @@ void launch_initial_keys(Context &ctx, const PackedText &t, uint64_t *keys, uint
     KERNEL_CHECK();
 }
 
-// shared tail of every round: sorted (keys, vals) of m active elements -> sa / rank / next active list
-uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *vals, const uint32_t *act_pos,
-                 uint32_t m, uint32_t *sa, uint32_t *rank, uint32_t *new_act, uint32_t *tmp_a,
-                 uint32_t *tmp_b, uint32_t *d_total) {
+// shared tail of every round: sorted view of m active elements -> sa / rank / next active list
+template <bool kRound0>
+uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *grp, const uint32_t *lo, const uint32_t *vals,
+                 const uint32_t *act_slot, uint32_t m, uint32_t *sa, uint32_t *rank, uint32_t *new_slot,
+                 uint32_t *new_grp, uint32_t *tmp_a, uint32_t *tmp_b, uint32_t *tmp_c, uint32_t *d_total) {
     hipStream_t s = ctx.stream;
     {
         ProfScope ps(ctx.profiler(), "sa_mark_heads", s);
-        mark_heads_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(keys, act_pos, m, tmp_a);
+        mark_heads_kernel<kRound0><<<grid_for(m, kThreads), kThreads, 0, s>>>(keys, grp, lo, act_slot, m, tmp_a);
         KERNEL_CHECK();
     }
     {
@@ -233,16 +325,18 @@ uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *vals, const
     }
     {
         ProfScope ps(ctx.profiler(), "sa_commit", s);
-        commit_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(keys, vals, act_pos, tmp_a, m, sa, rank, tmp_b);
+        commit_kernel<kRound0><<<grid_for(m, kThreads), kThreads, 0, s>>>(keys, grp, lo, vals, act_slot, tmp_a, m,
+                                                                          sa, rank, tmp_b);
         KERNEL_CHECK();
     }
     {
         ProfScope ps(ctx.profiler(), "sa_scan", s);
-        scan_exclusive_add_u32(tmp_b, tmp_a, m, d_total, ctx.arena, s);
+        scan_exclusive_add_u32(tmp_b, tmp_c, m, d_total, ctx.arena, s);
     }
     {
         ProfScope ps(ctx.profiler(), "sa_compact", s);
-        compact_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(tmp_b, tmp_a, act_pos, m, new_act);
+        compact_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(tmp_b, tmp_c, kRound0 ? nullptr : act_slot, tmp_a,
+                                                                  m, new_slot, new_grp);
         KERNEL_CHECK();
     }
     uint32_t total = 0;
@@ -293,9 +387,11 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
 
     uint64_t *keys[2] = {arena.alloc<uint64_t>(n), arena.alloc<uint64_t>(n)};
     uint32_t *vals[2] = {arena.alloc<uint32_t>(n), arena.alloc<uint32_t>(n)};
-    uint32_t *act[2] = {arena.alloc<uint32_t>(n), arena.alloc<uint32_t>(n)};
+    uint32_t *act_slot[2] = {arena.alloc<uint32_t>(n), arena.alloc<uint32_t>(n)};
+    uint32_t *act_grp[2] = {arena.alloc<uint32_t>(n), arena.alloc<uint32_t>(n)};
     uint32_t *tmp_a = arena.alloc<uint32_t>(n);
     uint32_t *tmp_b = arena.alloc<uint32_t>(n);
+    uint32_t *tmp_c = arena.alloc<uint32_t>(n);
     uint32_t *d_total = arena.alloc<uint32_t>(1);
     uint32_t *rank = isa;
 
@@ -312,11 +408,17 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         ProfScope ps(ctx.profiler(), "sa_sort_initial", s);
         cur = radix_sort_pairs(keys, vals, n, shifts, 8, arena, s, ctx.profiler());
     }
-    uint32_t m = regroup(ctx, keys[cur], vals[cur], nullptr, n, sa, rank, act[0], tmp_a, tmp_b, d_total);
+    uint32_t m = regroup<true>(ctx, keys[cur], nullptr, nullptr, vals[cur], nullptr, n, sa, rank, act_slot[0],
+                               act_grp[0], tmp_a, tmp_b, tmp_c, d_total);
 
     // ---- doubling rounds ------------------------------------------------------------------
+    // in the rounds the 8n-byte key buffers are reused as four u32 arrays
+    uint32_t *lo = reinterpret_cast<uint32_t *>(keys[0]);
+    uint32_t *out_lo = lo + n;
+    uint32_t *rvals = vals[0];
+    uint32_t *out_vals = vals[1];
     int nbits = 1;
-    while (nbits < 32 && (1ull << nbits) <= (uint64_t)n) ++nbits;  // ranks are <= n
+    while (nbits < 32 && (1ull << nbits) <= (uint64_t)n) ++nbits;  // ranks and slots are <= n
     const int half_passes = (nbits + kRadixBits - 1) / kRadixBits;
     int shifts[8], npasses = 0;
     for (int p = 0; p < half_passes; ++p) shifts[npasses++] = p * kRadixBits;
@@ -326,17 +428,38 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     uint64_t h = (uint64_t)k_syms;
     while (m > 0) {
         if (h >= n || rounds > 40) throw HipError("suffix array: prefix doubling failed to converge");
+        const uint32_t *slot = act_slot[a_cur], *grp = act_grp[a_cur];
         {
             ProfScope ps(ctx.profiler(), "sa_round_keys", s);
-            round_keys_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(act[a_cur], m, sa, rank, n, (uint32_t)h,
-                                                                        keys[0], vals[0]);
+            round_keys_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(slot, m, sa, rank, n, (uint32_t)h, lo, rvals);
             KERNEL_CHECK();
         }
         {
-            ProfScope ps(ctx.profiler(), "sa_sort_round", s);
-            cur = radix_sort_pairs(keys, vals, m, shifts, npasses, arena, s, ctx.profiler());
+            ProfScope ps(ctx.profiler(), "sa_small_sort", s);
+            small_sort_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(slot, grp, lo, rvals, m, out_lo, out_vals,
+                                                                         tmp_a);
+            KERNEL_CHECK();
+            scan_exclusive_add_u32(tmp_a, tmp_b, m, d_total, arena, s);
         }
-        m = regroup(ctx, keys[cur], vals[cur], act[a_cur], m, sa, rank, act[a_cur ^ 1], tmp_a, tmp_b, d_total);
+        uint32_t n_large = 0;
+        ctx.read_back(d_total, &n_large, 1);
+        if (n_large > 0) {  // members of groups larger than kSmallGroup: global radix sort
+            ProfScope ps(ctx.profiler(), "sa_sort_large", s);
+            const size_t lmark = arena.mark();
+            uint64_t *lk[2] = {keys[1], arena.alloc<uint64_t>(n_large)};
+            uint32_t *lv[2] = {arena.alloc<uint32_t>(n_large), arena.alloc<uint32_t>(n_large)};
+            uint32_t *lidx = tmp_c;
+            gather_large_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(tmp_a, tmp_b, grp, lo, rvals, m, lk[0],
+                                                                           lv[0], lidx);
+            KERNEL_CHECK();
+            const int c = radix_sort_pairs(lk, lv, n_large, shifts, npasses, arena, s, ctx.profiler());
+            scatter_large_kernel<<<grid_for(n_large, kThreads), kThreads, 0, s>>>(lk[c], lv[c], lidx, n_large,
+                                                                                  out_lo, out_vals);
+            KERNEL_CHECK();
+            arena.rewind(lmark);
+        }
+        m = regroup<false>(ctx, nullptr, grp, out_lo, out_vals, slot, m, sa, rank, act_slot[a_cur ^ 1],
+                           act_grp[a_cur ^ 1], tmp_a, tmp_b, tmp_c, d_total);
         a_cur ^= 1;
         h *= 2;
         ++rounds;
