@@ -602,10 +602,11 @@ int nolzss_debug_sort_pairs(uint64_t *keys, uint32_t *vals, size_t n, int device
         HIP_CHECK(hipMemcpyAsync(k[0], keys, n * 8, hipMemcpyHostToDevice, ctx.stream));
         HIP_CHECK(hipMemcpyAsync(v[0], vals, n * 4, hipMemcpyHostToDevice, ctx.stream));
         const int shifts[8] = {0, 8, 16, 24, 32, 40, 48, 56};
-        const int cur = radix_sort_pairs(k, v, n, shifts, 8, ctx.arena, ctx.stream);
+        const int cur = radix_sort_pairs(k, v, n, shifts, 8, ctx.arena, ctx.stream, ctx.profiler());
         HIP_CHECK(hipMemcpyAsync(keys, k[cur], n * 8, hipMemcpyDeviceToHost, ctx.stream));
         HIP_CHECK(hipMemcpyAsync(vals, v[cur], n * 4, hipMemcpyDeviceToHost, ctx.stream));
         HIP_CHECK(hipStreamSynchronize(ctx.stream));
+        ctx.prof.collect();
         ctx.arena.rewind(mark);
     });
 }

@@ -6,7 +6,9 @@
 // (DESIGN.md section 3):  with r = ISA[i] and I(d) the maximal rank interval around r whose
 // LCP values are >= d,   L*[i] = max{ d : min SA[I(d)] + d <= i },   0 meaning "literal".
 //
-// Data-parallel evaluation, one thread per RANK r (coalesced SA / LCP reads):
+// Data-parallel evaluation, one thread per RANK r; SA / LCP tiles are staged in LDS
+// (nearest_lds.hpp) and ranks whose search leaves the tile's reach go to a compacted second
+// kernel that walks the pyramids from global memory (nearest.hpp):
 //   1. nearest smaller SA value above and below r (the classic LPF candidates) with the
 //      running LCP minimum -> M = max lcp over all earlier suffixes;
 //   2. if a candidate j with lcp M also satisfies i - j >= M it does not overlap, so L* = M;
@@ -14,42 +16,85 @@
 //      and lpnf_fallback_kernel finds max d by galloping + binary search on the monotone
 //      predicate, using the LCP pyramid for I(d) and the SA pyramid for the range minimum.
 #include "pipeline.hpp"
-#include "nearest.hpp"
+#include "nearest_lds.hpp"
 
 namespace nolzss {
 namespace {
 
 constexpr int kThreads = 256;
 
-__global__ __launch_bounds__(kThreads) void lpf_kernel(const uint32_t *__restrict__ sa,
-                                                       const uint32_t *__restrict__ lcp, uint32_t n,
-                                                       Pyramid Psa, Pyramid Plcp,
-                                                       uint32_t *__restrict__ lstar,
-                                                       uint32_t *__restrict__ queue,
-                                                       uint32_t *__restrict__ queue_count) {
+// turn the two neighbour candidates into L*[i], or queue i for the exact search
+__device__ __forceinline__ void lpf_decide(uint32_t i, uint32_t lp, uint32_t jp, uint32_t ls, uint32_t js,
+                                           uint32_t *__restrict__ lstar, uint32_t *__restrict__ queue,
+                                           uint32_t *__restrict__ queue_count) {
+    const uint32_t M = lp > ls ? lp : ls;
+    if (M == 0) {
+        lstar[i] = 0;
+        return;
+    }
+    const bool ok = (lp == M && i - jp >= M) || (ls == M && i - js >= M);
+    if (ok) {
+        lstar[i] = M;
+        return;
+    }
+    // best earlier match overlaps position i: exact search needed; record a true lower bound
+    uint32_t lo = 0;
+    if (lp > 0) { const uint32_t c = lp < i - jp ? lp : i - jp; lo = c > lo ? c : lo; }
+    if (ls > 0) { const uint32_t c = ls < i - js ? ls : i - js; lo = c > lo ? c : lo; }
+    lstar[i] = lo;
+    queue[atomicAdd(queue_count, 1u)] = i;
+}
+
+__global__ __launch_bounds__(kLdsThreads) void lpf_tile_kernel(const uint32_t *__restrict__ sa,
+                                                               const uint32_t *__restrict__ lcp, uint32_t n,
+                                                               uint32_t *__restrict__ lstar,
+                                                               uint32_t *__restrict__ queue,
+                                                               uint32_t *__restrict__ queue_count,
+                                                               uint32_t *__restrict__ far_queue,
+                                                               uint32_t *__restrict__ far_count) {
+    constexpr int NS = 2;
+    __shared__ uint32_t s_sa[kLdsSpan];
+    __shared__ uint32_t s_lcp[kLdsSpan + 1];
+    __shared__ uint32_t s_len[NS * kLdsTile];
+    __shared__ uint32_t s_pos[NS * kLdsTile];
+    __shared__ uint16_t s_list[kLdsWaves][2][NS * kLdsPerWave];
+    const uint32_t base = blockIdx.x * (uint32_t)kLdsTile;
+    stage_tile(sa, lcp, n, base, s_sa, s_lcp);
+    __syncthreads();
+    const int w = threadIdx.x >> 6;
+    lds_search_wave<NS>(s_sa, s_lcp, n, base, s_len, s_pos, s_list[w][0], s_list[w][1],
+                        [](uint32_t) { return true; }, [](uint32_t) { return 0u; });
+#pragma unroll 1
+    for (int row = 0; row < kLdsPerWave / 64; ++row) {
+        const int t = w * kLdsPerWave + row * 64 + lane_id();
+        const uint64_t rr = (uint64_t)base + t;
+        if (rr >= n) break;
+        const uint32_t i = s_sa[t + kLdsReach];
+        const uint32_t lp = s_len[t], jp = s_pos[t], ls = s_len[kLdsTile + t], js = s_pos[kLdsTile + t];
+        if (jp == kFarPos || js == kFarPos) {
+            far_queue[atomicAdd(far_count, 1u)] = (uint32_t)rr;  // finish from global memory
+            continue;
+        }
+        lpf_decide(i, lp, jp, ls, js, lstar, queue, queue_count);
+    }
+}
+
+// ranks whose nearest earlier suffix lies outside the LDS reach: pyramid search
+__global__ __launch_bounds__(kThreads) void lpf_far_kernel(const uint32_t *__restrict__ far_queue, uint32_t count,
+                                                           const uint32_t *__restrict__ sa,
+                                                           const uint32_t *__restrict__ lcp, uint32_t n,
+                                                           Pyramid Psa, Pyramid Plcp,
+                                                           uint32_t *__restrict__ lstar,
+                                                           uint32_t *__restrict__ queue,
+                                                           uint32_t *__restrict__ queue_count) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t rr = (size_t)blockIdx.x * blockDim.x + threadIdx.x; rr < n; rr += stride) {
-        const uint32_t r = (uint32_t)rr;
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < count; k += stride) {
+        const uint32_t r = far_queue[k];
         const uint32_t i = sa[r];
         uint32_t lp, jp, ls, js;
         nearest_up<false>(sa, lcp, Psa, Plcp, r, i, 0u, lp, jp);
         nearest_down<false>(sa, lcp, n, Psa, Plcp, r, i, lp, ls, js);  // cannot beat lp below lp
-        const uint32_t M = lp > ls ? lp : ls;
-        if (M == 0) {
-            lstar[i] = 0;
-            continue;
-        }
-        const bool ok = (lp == M && i - jp >= M) || (ls == M && i - js >= M);
-        if (ok) {
-            lstar[i] = M;
-            continue;
-        }
-        // best earlier match overlaps position i: exact search needed; record a true lower bound
-        uint32_t lo = 0;
-        if (lp > 0) { const uint32_t c = lp < i - jp ? lp : i - jp; lo = c > lo ? c : lo; }
-        if (ls > 0) { const uint32_t c = ls < i - js ? ls : i - js; lo = c > lo ? c : lo; }
-        lstar[i] = lo;
-        queue[atomicAdd(queue_count, 1u)] = i;
+        lpf_decide(i, lp, jp, ls, js, lstar, queue, queue_count);
     }
 }
 
@@ -73,26 +118,34 @@ uint32_t build_lstar(Context &ctx, uint32_t n, const uint32_t *sa, const uint32_
     hipStream_t s = ctx.stream;
     const size_t mark = ctx.arena.mark();
     uint32_t *queue = ctx.arena.alloc<uint32_t>(n);
-    uint32_t *count = ctx.arena.alloc<uint32_t>(1);
-    HIP_CHECK(hipMemsetAsync(count, 0, sizeof(uint32_t), s));
+    uint32_t *far_queue = ctx.arena.alloc<uint32_t>(n);
+    uint32_t *counts = ctx.arena.alloc<uint32_t>(2);  // [0] exact-search queue, [1] far queue
+    HIP_CHECK(hipMemsetAsync(counts, 0, 2 * sizeof(uint32_t), s));
     {
-        ProfScope ps(ctx.profiler(), "lpf", s);
-        size_t g = div_up(n, kThreads);
-        if (g > 256u * 32u) g = 256u * 32u;
-        lpf_kernel<<<(unsigned)g, kThreads, 0, s>>>(sa, lcp, n, Psa, Plcp, lstar, queue, count);
+        ProfScope ps(ctx.profiler(), "lpf", s, 12.0 * (double)n);
+        lpf_tile_kernel<<<(unsigned)div_up(n, kLdsTile), kLdsThreads, 0, s>>>(sa, lcp, n, lstar, queue, counts, far_queue,
+                                                                       counts + 1);
         KERNEL_CHECK();
     }
-    uint32_t h_count = 0;
-    ctx.read_back(count, &h_count, 1);
-    if (h_count > 0) {
-        ProfScope ps(ctx.profiler(), "lpnf_fallback", s);
-        size_t g = div_up(h_count, kThreads);
+    uint32_t h[2] = {0, 0};
+    ctx.read_back(counts, h, 2);
+    if (h[1] > 0) {
+        ProfScope ps(ctx.profiler(), "lpf_far", s);
+        size_t g = div_up(h[1], kThreads);
         if (g > 256u * 32u) g = 256u * 32u;
-        lpnf_fallback_kernel<<<(unsigned)g, kThreads, 0, s>>>(queue, h_count, n, isa, Psa, Plcp, lstar);
+        lpf_far_kernel<<<(unsigned)g, kThreads, 0, s>>>(far_queue, h[1], sa, lcp, n, Psa, Plcp, lstar, queue, counts);
+        KERNEL_CHECK();
+        ctx.read_back(counts, h, 1);
+    }
+    if (h[0] > 0) {
+        ProfScope ps(ctx.profiler(), "lpnf_fallback", s);
+        size_t g = div_up(h[0], kThreads);
+        if (g > 256u * 32u) g = 256u * 32u;
+        lpnf_fallback_kernel<<<(unsigned)g, kThreads, 0, s>>>(queue, h[0], n, isa, Psa, Plcp, lstar);
         KERNEL_CHECK();
     }
     ctx.arena.rewind(mark);
-    return h_count;
+    return h[0];
 }
 
 }  // namespace nolzss

@@ -1,0 +1,150 @@
+// nearest_lds.hpp -- work-efficient "nearest qualifying suffix" searches on an LDS tile.
+//
+// Problem: for every rank r of a tile, find the nearest rank above / below whose suffix start
+// qualifies (kGreater ? SA[q] > x : SA[q] < x) and the minimum LCP crossed on the way.  The
+// distance to that rank is heavy-tailed (P(distance > k) ~ 1/(k+1) on random data), so a
+// lock-step scan makes every wavefront pay for its slowest lane.
+//
+// Scheme (per wavefront, no workgroup barriers after staging):
+//   * the workgroup stages kLdsTile ranks of SA and LCP plus a halo of kLdsReach on both sides;
+//   * round 0: every lane advances each of its searches by 8 steps, branch-free;
+//   * unfinished searches are compacted (ballot + popcount) into a per-wave work list in LDS
+//     and the wave keeps taking 64 list items at a time, 8 more steps each, until the list is
+//     empty: all lanes stay busy, total work ~ n * H(reach) instead of n * reach;
+//   * a search that leaves the reach is marked FAR and the rank is finished from global memory
+//     with the pyramids (nearest.hpp) by a separate compacted kernel.
+#pragma once
+#include "nearest.hpp"
+
+namespace nolzss {
+
+constexpr int kLdsThreads = 256;
+constexpr int kLdsWaves = kLdsThreads / 64;
+constexpr int kLdsTile = 1024;                      // ranks per workgroup
+constexpr int kLdsPerWave = kLdsTile / kLdsWaves;   // 256 ranks per wavefront
+constexpr int kLdsReach = 256;                      // steps each way that stay inside LDS
+constexpr int kLdsSpan = kLdsTile + 2 * kLdsReach;
+constexpr int kLdsStep = 8;                         // steps per round
+constexpr uint32_t kFarPos = 0xfffffffeu;           // search left the reach
+
+// stage SA[base - reach, base + tile + reach) and the matching LCP entries; out-of-range = 0
+__device__ __forceinline__ void stage_tile(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ lcp,
+                                           uint32_t n, uint32_t base, uint32_t *s_sa, uint32_t *s_lcp) {
+    const int64_t first = (int64_t)base - kLdsReach;
+    for (int j = threadIdx.x; j < kLdsSpan + 1; j += blockDim.x) {
+        const int64_t g = first + j;
+        const bool in_sa = g >= 0 && g < (int64_t)n;
+        const bool in_lcp = g >= 0 && g <= (int64_t)n;
+        if (j < kLdsSpan) s_sa[j] = in_sa ? sa[g] : 0u;
+        s_lcp[j] = in_lcp ? lcp[g] : 0u;
+    }
+}
+
+// One round of kLdsStep steps of one search, branch-free.  li = local index of rank r in the
+// staged tile, s0 = steps already taken, m = running LCP minimum (in/out).
+// Returns 0 = finished without a match (len 0), 1 = match (m = its LCP, pos = its suffix start),
+// 2 = still searching.
+__device__ __forceinline__ int lds_scan_round(const uint32_t *s_sa, const uint32_t *s_lcp, uint32_t n, uint32_t r,
+                                              int li, int s0, bool greater, bool up, uint32_t x, uint32_t &m,
+                                              uint32_t &pos) {
+    uint32_t c[kLdsStep], v[kLdsStep];
+    const int dir = up ? -1 : 1;
+#pragma unroll
+    for (int k = 0; k < kLdsStep; ++k) {
+        const int q = li + dir * (s0 + k + 1);
+        c[k] = s_lcp[q + (up ? 1 : 0)];
+        v[k] = s_sa[q];
+    }
+    int status = 2;
+#pragma unroll
+    for (int k = 0; k < kLdsStep; ++k) {
+        const uint32_t s = (uint32_t)(s0 + k + 1);
+        const bool oob = up ? (r < s) : ((uint64_t)r + s >= n);
+        const uint32_t mk = c[k] < m ? c[k] : m;
+        const bool open = status == 2;
+        const bool dead = oob || mk == 0;
+        const bool hit = !dead && (greater ? (v[k] > x) : (v[k] < x));
+        m = open ? mk : m;
+        pos = (open && hit) ? v[k] : pos;
+        status = open ? (dead ? 0 : (hit ? 1 : 2)) : status;
+    }
+    return status;
+}
+
+// Runs NS searches for each of the wavefront's kLdsPerWave ranks.  Search k is "up" for even k,
+// "down" for odd k; searches 0/1 look for smaller values (threshold = own suffix start i),
+// searches 2/3 (NS == 4) for values greater than thr_gt(i).  A rank takes part iff active(i).
+// Results: res_len[k * kLdsTile + t], res_pos[...] (kNoPos: none, kFarPos: left the reach).
+// list0/list1: this wave's two work lists (NS * kLdsPerWave items each).
+template <int NS, typename Active, typename ThrGt>
+__device__ __forceinline__ void lds_search_wave(const uint32_t *s_sa, const uint32_t *s_lcp, uint32_t n,
+                                                uint32_t base, uint32_t *res_len, uint32_t *res_pos,
+                                                uint16_t *list0, uint16_t *list1, Active active, ThrGt thr_gt) {
+    const int lane = lane_id();
+    const int w = threadIdx.x >> 6;
+    const uint64_t lt = lanemask_lt();
+    uint16_t *lists[2] = {list0, list1};
+    uint32_t cnt = 0;
+
+    // ---- round 0: every rank, every search, steps 1..kLdsStep --------------------------------
+#pragma unroll 1
+    for (int row = 0; row < kLdsPerWave / 64; ++row) {
+        const int tl = row * 64 + lane;
+        const int t = w * kLdsPerWave + tl;
+        const uint64_t rr = (uint64_t)base + t;
+        const int li = t + kLdsReach;
+        const uint32_t i = s_sa[li];
+        const bool valid = rr < n && active(i);
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const bool greater = k >= 2, up = (k & 1) == 0;
+            uint32_t m = 0xffffffffu, pos = kNoPos;
+            int st = 0;
+            if (valid) st = lds_scan_round(s_sa, s_lcp, n, (uint32_t)rr, li, 0, greater, up, greater ? thr_gt(i) : i, m, pos);
+            res_len[k * kLdsTile + t] = (st == 0) ? 0u : m;
+            res_pos[k * kLdsTile + t] = (st == 1) ? pos : kNoPos;
+            const bool pending = st == 2;
+            const uint64_t bal = __ballot(pending);
+            if (pending) lists[0][cnt + (uint32_t)__popcll(bal & lt)] = (uint16_t)(tl | (k << 8) | (1 << 10));
+            cnt += (uint32_t)__popcll(bal);
+        }
+    }
+
+    // ---- drain the work list: 64 items at a time, kLdsStep more steps each --------------------
+    int cur = 0;
+    while (cnt > 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t next_cnt = 0;
+        for (uint32_t c0 = 0; c0 < cnt; c0 += 64) {
+            const bool have = c0 + lane < cnt;
+            const uint32_t item = have ? lists[cur][c0 + lane] : 0u;
+            const int tl = item & 255, k = (item >> 8) & 3, chunk = (int)(item >> 10);
+            const int t = w * kLdsPerWave + tl;
+            const uint32_t r = base + (uint32_t)t;
+            const int li = t + kLdsReach;
+            const bool greater = k >= 2, up = (k & 1) == 0;
+            bool pending = false;
+            if (have) {
+                const uint32_t i = s_sa[li];
+                uint32_t m = res_len[k * kLdsTile + t], pos = kNoPos;
+                const int st = lds_scan_round(s_sa, s_lcp, n, r, li, chunk * kLdsStep, greater, up,
+                                              greater ? thr_gt(i) : i, m, pos);
+                const bool at_reach = (chunk + 1) * kLdsStep >= kLdsReach;
+                pending = st == 2 && !at_reach;
+                res_len[k * kLdsTile + t] = (st == 0) ? 0u : m;
+                res_pos[k * kLdsTile + t] = (st == 1) ? pos : ((st == 2 && at_reach) ? kFarPos : kNoPos);
+            }
+            const uint64_t bal = __ballot(pending);
+            if (pending)
+                lists[cur ^ 1][next_cnt + (uint32_t)__popcll(bal & lt)] = (uint16_t)(tl | (k << 8) | ((chunk + 1) << 10));
+            next_cnt += (uint32_t)__popcll(bal);
+        }
+        cur ^= 1;
+        cnt = next_cnt;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+}  // namespace nolzss

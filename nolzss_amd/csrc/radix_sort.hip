@@ -14,24 +14,36 @@
 
 #include "scan.hpp"
 
+#include <cstdlib>
+
 namespace nolzss {
 namespace {
 
-constexpr int kThreads = 256;
-constexpr int kWaves = kThreads / 64;
 constexpr int kKeysPerThread = 16;
-constexpr int kTile = kThreads * kKeysPerThread;  // 4096
 constexpr int kBins = 1 << kRadixBits;
-constexpr int kWaveSpan = kTile / kWaves;  // 1024 keys per wavefront, 16 rows of 64
+constexpr int kWaveSpan = 64 * kKeysPerThread;  // 1024 keys per wavefront, 16 rows of 64
 
-static_assert(kBins == kThreads, "one thread per bin in the offset phase");
+// Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 shares an XCD).  Give each
+// XCD a contiguous range of tiles so that the bin runs of neighbouring tiles -- which are
+// adjacent in the output -- meet in the same L2 and partial cache lines merge there.
+__device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t num_tiles, bool remap) {
+    if (!remap) return b;
+    const uint32_t per = num_tiles / 8, rem = num_tiles % 8;
+    const uint32_t x = b % 8, k = b / 8;
+    // XCD x owns tiles [x*per + min(x, rem), ...) with one extra tile for x < rem
+    const uint32_t start = x * per + (x < rem ? x : rem);
+    const uint32_t cnt = per + (x < rem ? 1u : 0u);
+    return k < cnt ? start + k : 0xffffffffu;
+}
 
+template <int kThreads>
 __global__ __launch_bounds__(kThreads) void rs_hist_kernel(const uint64_t *__restrict__ keys,
                                                            size_t n, int shift,
                                                            uint32_t *__restrict__ tile_hist,
                                                            uint32_t num_tiles) {
+    constexpr int kTile = kThreads * kKeysPerThread;
     __shared__ uint32_t hist[kBins];
-    hist[threadIdx.x] = 0;
+    for (int d = threadIdx.x; d < kBins; d += kThreads) hist[d] = 0;
     __syncthreads();
     const size_t base = (size_t)blockIdx.x * kTile;
 #pragma unroll
@@ -40,15 +52,23 @@ __global__ __launch_bounds__(kThreads) void rs_hist_kernel(const uint64_t *__res
         if (idx < n) atomicAdd(&hist[(uint32_t)(keys[idx] >> shift) & (kBins - 1)], 1u);
     }
     __syncthreads();
-    tile_hist[(size_t)threadIdx.x * num_tiles + blockIdx.x] = hist[threadIdx.x];
+    for (int d = threadIdx.x; d < kBins; d += kThreads)
+        tile_hist[(size_t)d * num_tiles + blockIdx.x] = hist[d];
 }
 
+template <int kThreads>
 __global__ __launch_bounds__(kThreads) void rs_scatter_kernel(
     const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
     uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, size_t n, int shift,
-    const uint32_t *__restrict__ tile_base, uint32_t num_tiles) {
+    const uint32_t *__restrict__ tile_base, uint32_t num_tiles, bool remap) {
+    constexpr int kWaves = kThreads / 64;
+    constexpr int kTile = kThreads * kKeysPerThread;
+    const uint32_t tile = xcd_tile(blockIdx.x, num_tiles, remap);
+    if (tile == 0xffffffffu) return;
+    // keys and values take turns in one staging buffer (8 B x tile): 37 KiB of LDS per 256-thread
+    // workgroup instead of 53 KiB lets a fourth workgroup share the CU
     __shared__ uint64_t s_keys[kTile];
-    __shared__ uint32_t s_vals[kTile];
+    uint32_t *s_vals = reinterpret_cast<uint32_t *>(s_keys);
     __shared__ uint32_t s_whist[kWaves * kBins];
     __shared__ uint32_t s_glob[kBins];
     __shared__ uint32_t s_scan[kWaves];
@@ -58,11 +78,10 @@ __global__ __launch_bounds__(kThreads) void rs_scatter_kernel(
     const int lane = tid & 63;
     volatile uint32_t *whist = s_whist + w * kBins;
 
-#pragma unroll
-    for (int k = 0; k < kWaves; ++k) s_whist[k * kBins + tid] = 0;
+    for (int k = tid; k < kWaves * kBins; k += kThreads) s_whist[k] = 0;
     __syncthreads();
 
-    const size_t base = (size_t)blockIdx.x * kTile;
+    const size_t base = (size_t)tile * kTile;
     uint64_t key[kKeysPerThread];
     uint32_t val[kKeysPerThread];
     uint32_t lrank[kKeysPerThread];
@@ -95,55 +114,71 @@ __global__ __launch_bounds__(kThreads) void rs_scatter_kernel(
     {
         const int d = tid;
         uint32_t c[kWaves], total = 0;
+        if (d < kBins) {
 #pragma unroll
-        for (int k = 0; k < kWaves; ++k) {
-            c[k] = s_whist[k * kBins + d];
-            total += c[k];
+            for (int k = 0; k < kWaves; ++k) {
+                c[k] = s_whist[k * kBins + d];
+                total += c[k];
+            }
         }
         uint32_t tile_total;
         const uint32_t bin_start =
             block_scan_exclusive<kWaves>(total, OpAdd<uint32_t>(), s_scan, tile_total);
-        uint32_t run = bin_start;
+        if (d < kBins) {
+            uint32_t run = bin_start;
 #pragma unroll
-        for (int k = 0; k < kWaves; ++k) {
-            s_whist[k * kBins + d] = run;
-            run += c[k];
+            for (int k = 0; k < kWaves; ++k) {
+                s_whist[k * kBins + d] = run;
+                run += c[k];
+            }
+            s_glob[d] = tile_base[(size_t)d * num_tiles + tile] - bin_start;
         }
-        s_glob[d] = tile_base[(size_t)d * num_tiles + blockIdx.x] - bin_start;
     }
     __syncthreads();
 
+    // tile-local sorted position of every element (reuses lrank)
+#pragma unroll
+    for (int row = 0; row < kKeysPerThread; ++row) {
+        const uint32_t d = (uint32_t)(key[row] >> shift) & (kBins - 1);
+        lrank[row] += s_whist[w * kBins + d];
+    }
 #pragma unroll
     for (int row = 0; row < kKeysPerThread; ++row) {
         const size_t idx = base + (size_t)w * kWaveSpan + (size_t)row * 64 + lane;
-        if (idx < n) {
-            const uint32_t d = (uint32_t)(key[row] >> shift) & (kBins - 1);
-            const uint32_t pos = s_whist[w * kBins + d] + lrank[row];
-            s_keys[pos] = key[row];
-            s_vals[pos] = val[row];
-        }
+        if (idx < n) s_keys[lrank[row]] = key[row];
     }
     __syncthreads();
 
     const uint32_t count = (uint32_t)((n - base < (size_t)kTile) ? (n - base) : (size_t)kTile);
+    uint32_t gpos[kKeysPerThread];
 #pragma unroll
     for (int j = 0; j < kKeysPerThread; ++j) {
         const uint32_t p = (uint32_t)j * kThreads + tid;
         if (p < count) {
             const uint64_t k = s_keys[p];
             const uint32_t d = (uint32_t)(k >> shift) & (kBins - 1);
-            const uint32_t g = s_glob[d] + p;
-            keys_out[g] = k;
-            vals_out[g] = s_vals[p];
+            gpos[j] = s_glob[d] + p;
+            keys_out[gpos[j]] = k;
         }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int row = 0; row < kKeysPerThread; ++row) {
+        const size_t idx = base + (size_t)w * kWaveSpan + (size_t)row * 64 + lane;
+        if (idx < n) s_vals[lrank[row]] = val[row];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kKeysPerThread; ++j) {
+        const uint32_t p = (uint32_t)j * kThreads + tid;
+        if (p < count) vals_out[gpos[j]] = s_vals[p];
     }
 }
 
-}  // namespace
-
-int radix_sort_pairs(uint64_t *keys[2], uint32_t *vals[2], size_t n, const int *shifts,
-                     int npasses, Arena &arena, hipStream_t stream, Profiler *prof) {
-    if (n == 0 || npasses == 0) return 0;
+template <int kThreads>
+int radix_sort_impl(uint64_t *keys[2], uint32_t *vals[2], size_t n, const int *shifts, int npasses,
+                    Arena &arena, hipStream_t stream, Profiler *prof, bool remap) {
+    constexpr int kTile = kThreads * kKeysPerThread;
     const size_t m = arena.mark();
     const uint32_t num_tiles = (uint32_t)div_up(n, kTile);
     uint32_t *hist = arena.alloc<uint32_t>((size_t)kBins * num_tiles);
@@ -151,7 +186,7 @@ int radix_sort_pairs(uint64_t *keys[2], uint32_t *vals[2], size_t n, const int *
     for (int p = 0; p < npasses; ++p) {
         {
             ProfScope ps(prof, "rs_hist", stream, 8.0 * (double)n);
-            rs_hist_kernel<<<num_tiles, kThreads, 0, stream>>>(keys[cur], n, shifts[p], hist, num_tiles);
+            rs_hist_kernel<kThreads><<<num_tiles, kThreads, 0, stream>>>(keys[cur], n, shifts[p], hist, num_tiles);
             KERNEL_CHECK();
         }
         {
@@ -162,15 +197,32 @@ int radix_sort_pairs(uint64_t *keys[2], uint32_t *vals[2], size_t n, const int *
             // algorithmic bytes of one scatter launch: every (key, value) pair read once and
             // written once = 2 * (8 + 4) bytes per pair
             ProfScope ps(prof, "rs_scatter", stream, 24.0 * (double)n);
-            rs_scatter_kernel<<<num_tiles, kThreads, 0, stream>>>(keys[cur], vals[cur], keys[cur ^ 1],
-                                                                  vals[cur ^ 1], n, shifts[p], hist,
-                                                                  num_tiles);
+            const uint32_t grid = remap ? (uint32_t)div_up(num_tiles, 8) * 8 : num_tiles;
+            rs_scatter_kernel<kThreads><<<grid, kThreads, 0, stream>>>(keys[cur], vals[cur], keys[cur ^ 1],
+                                                                       vals[cur ^ 1], n, shifts[p], hist,
+                                                                       num_tiles, remap);
             KERNEL_CHECK();
         }
         cur ^= 1;
     }
     arena.rewind(m);
     return cur;
+}
+
+}  // namespace
+
+int radix_sort_pairs(uint64_t *keys[2], uint32_t *vals[2], size_t n, const int *shifts,
+                     int npasses, Arena &arena, hipStream_t stream, Profiler *prof) {
+    if (n == 0 || npasses == 0) return 0;
+    // tuning knob (bit 0: XCD-contiguous tile mapping, bit 1: 512-thread / 8192-key tiles);
+    // default = the fastest measured on MI355X: 256 threads, XCD mapping on
+    static const int variant = [] {
+        const char *e = getenv("NOLZSS_RS_VARIANT");
+        return e ? atoi(e) : 1;
+    }();
+    const bool remap = (variant & 1) != 0;
+    if (variant & 2) return radix_sort_impl<512>(keys, vals, n, shifts, npasses, arena, stream, prof, remap);
+    return radix_sort_impl<256>(keys, vals, n, shifts, npasses, arena, stream, prof, remap);
 }
 
 }  // namespace nolzss
