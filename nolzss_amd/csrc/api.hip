@@ -96,9 +96,8 @@ size_t run_plain(Context &ctx, const uint8_t *d_text, size_t n, size_t start_pos
     PackedText text = pack_text(ctx, d_text, n);
     uint32_t *sa = arena.alloc<uint32_t>(n);
     uint32_t *isa = arena.alloc<uint32_t>(n);
-    build_suffix_array(ctx, text, sa, isa);
     uint32_t *lcp = arena.alloc<uint32_t>(n + 1);
-    build_lcp(ctx, text, sa, lcp);
+    build_suffix_array(ctx, text, sa, isa, lcp);
     Pyramid Psa, Plcp;
     {
         ProfScope ps(ctx.profiler(), "pyramids", s);

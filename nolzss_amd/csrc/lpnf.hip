@@ -62,7 +62,7 @@ __global__ __launch_bounds__(kLdsThreads) void lpf_tile_kernel(const uint32_t *_
     stage_tile(sa, lcp, n, base, s_sa, s_lcp);
     __syncthreads();
     const int w = threadIdx.x >> 6;
-    lds_search_wave<NS>(s_sa, s_lcp, n, base, s_len, s_pos, s_list[w][0], s_list[w][1],
+    lds_search_wave<NS, NS>(s_sa, s_lcp, n, base, s_len, s_pos, s_list[w][0], s_list[w][1],
                         [](uint32_t) { return true; }, [](uint32_t) { return 0u; });
 #pragma unroll 1
     for (int row = 0; row < kLdsPerWave / 64; ++row) {
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(kLdsThreads) void lpf_tile_kernel(const uint32_t *_
         if (rr >= n) break;
         const uint32_t i = s_sa[t + kLdsReach];
         const uint32_t lp = s_len[t], jp = s_pos[t], ls = s_len[kLdsTile + t], js = s_pos[kLdsTile + t];
-        if (jp == kFarPos || js == kFarPos) {
+        if (lp == kFarLen || ls == kFarLen) {
             far_queue[atomicAdd(far_count, 1u)] = (uint32_t)rr;  // finish from global memory
             continue;
         }

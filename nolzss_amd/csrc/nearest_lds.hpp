@@ -25,7 +25,7 @@ constexpr int kLdsPerWave = kLdsTile / kLdsWaves;   // 256 ranks per wavefront
 constexpr int kLdsReach = 256;                      // steps each way that stay inside LDS
 constexpr int kLdsSpan = kLdsTile + 2 * kLdsReach;
 constexpr int kLdsStep = 8;                         // steps per round
-constexpr uint32_t kFarPos = 0xfffffffeu;           // search left the reach
+constexpr uint32_t kFarLen = 0xffffffffu;           // res_len marker: search left the reach
 
 // stage SA[base - reach, base + tile + reach) and the matching LCP entries; out-of-range = 0
 __device__ __forceinline__ void stage_tile(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ lcp,
@@ -74,9 +74,10 @@ __device__ __forceinline__ int lds_scan_round(const uint32_t *s_sa, const uint32
 // Runs NS searches for each of the wavefront's kLdsPerWave ranks.  Search k is "up" for even k,
 // "down" for odd k; searches 0/1 look for smaller values (threshold = own suffix start i),
 // searches 2/3 (NS == 4) for values greater than thr_gt(i).  A rank takes part iff active(i).
-// Results: res_len[k * kLdsTile + t], res_pos[...] (kNoPos: none, kFarPos: left the reach).
+// Results: res_len[k * kLdsTile + t] (0: none, kFarLen: left the reach) and, for the first NP
+// searches only, res_pos[k * kLdsTile + t] (suffix start of the match).
 // list0/list1: this wave's two work lists (NS * kLdsPerWave items each).
-template <int NS, typename Active, typename ThrGt>
+template <int NS, int NP, typename Active, typename ThrGt>
 __device__ __forceinline__ void lds_search_wave(const uint32_t *s_sa, const uint32_t *s_lcp, uint32_t n,
                                                 uint32_t base, uint32_t *res_len, uint32_t *res_pos,
                                                 uint16_t *list0, uint16_t *list1, Active active, ThrGt thr_gt) {
@@ -102,7 +103,7 @@ __device__ __forceinline__ void lds_search_wave(const uint32_t *s_sa, const uint
             int st = 0;
             if (valid) st = lds_scan_round(s_sa, s_lcp, n, (uint32_t)rr, li, 0, greater, up, greater ? thr_gt(i) : i, m, pos);
             res_len[k * kLdsTile + t] = (st == 0) ? 0u : m;
-            res_pos[k * kLdsTile + t] = (st == 1) ? pos : kNoPos;
+            if (k < NP) res_pos[k * kLdsTile + t] = (st == 1) ? pos : kNoPos;
             const bool pending = st == 2;
             const uint64_t bal = __ballot(pending);
             if (pending) lists[0][cnt + (uint32_t)__popcll(bal & lt)] = (uint16_t)(tl | (k << 8) | (1 << 10));
@@ -132,8 +133,8 @@ __device__ __forceinline__ void lds_search_wave(const uint32_t *s_sa, const uint
                                               greater ? thr_gt(i) : i, m, pos);
                 const bool at_reach = (chunk + 1) * kLdsStep >= kLdsReach;
                 pending = st == 2 && !at_reach;
-                res_len[k * kLdsTile + t] = (st == 0) ? 0u : m;
-                res_pos[k * kLdsTile + t] = (st == 1) ? pos : ((st == 2 && at_reach) ? kFarPos : kNoPos);
+                res_len[k * kLdsTile + t] = (st == 0) ? 0u : ((st == 2 && at_reach) ? kFarLen : m);
+                if (k < NP) res_pos[k * kLdsTile + t] = (st == 1) ? pos : kNoPos;
             }
             const uint64_t bal = __ballot(pending);
             if (pending)

@@ -21,14 +21,12 @@ struct Context {
 // Scans the byte text for its alphabet, builds dense codes and packs it (2/4/8 bits/symbol).
 PackedText pack_text(Context &ctx, const uint8_t *d_text, size_t n);
 
-// ---- stage 2: suffix array (prefix doubling over radix sorts) ----------------------------
-// sa[r] = start of the r-th smallest suffix, isa[i] = rank of suffix i.  Both arrays (n u32)
-// are caller-allocated.  Returns the number of doubling rounds run.
-int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint32_t *isa);
-
-// ---- stage 3: LCP array ------------------------------------------------------------------
-// lcp[0] = 0, lcp[r] = lcp(suffix sa[r-1], suffix sa[r]); lcp has n+1 entries, lcp[n] = 0.
-void build_lcp(Context &ctx, const PackedText &text, const uint32_t *sa, uint32_t *lcp);
+// ---- stages 2+3: suffix array (prefix doubling over radix sorts) and LCP array -------------
+// sa[r] = start of the r-th smallest suffix, isa[i] = rank of suffix i (n u32 each);
+// lcp[0] = 0, lcp[r] = lcp(suffix sa[r-1], suffix sa[r]), lcp[n] = 0 (n + 1 u32).  All
+// caller-allocated.  LCP entries between suffixes that round 0 already separates come straight
+// from the sort keys; only the others compare packed text.  Returns the doubling rounds run.
+int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint32_t *isa, uint32_t *lcp);
 
 struct Pyramid;
 

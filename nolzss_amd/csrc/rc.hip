@@ -16,7 +16,7 @@
 //   selection  (:338-352)  forward wins ties; RC must beat the forward match, or 1 if none.
 // When the best forward neighbour does not overlap position i (the common case) L_f is an LCA
 // depth, hence explicit, and fwd = L_f directly; only overlapping positions take the exact path.
-#include "nearest.hpp"
+#include "nearest_lds.hpp"
 #include "pipeline.hpp"
 
 namespace nolzss {
@@ -30,43 +30,85 @@ __device__ __forceinline__ uint32_t rc_select(uint32_t fwd, uint32_t rc) {
     return (rc > 1) ? (rc | kRcFlag) : 0u;                   // :345-352 (0 = literal)
 }
 
-__global__ __launch_bounds__(kThreads) void rc_candidates_kernel(
-    const uint32_t *__restrict__ sa, const uint32_t *__restrict__ lcp, uint32_t m, uint32_t N, Pyramid Pmin,
-    Pyramid Pmax, Pyramid Plcp, uint32_t *__restrict__ code, uint32_t *__restrict__ queue,
-    uint32_t *__restrict__ queue_rc, uint32_t *__restrict__ queue_count) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t rr = (size_t)blockIdx.x * blockDim.x + threadIdx.x; rr < m; rr += stride) {
-        const uint32_t r = (uint32_t)rr;
-        const uint32_t i = sa[r];
-        if (i >= N) continue;  // only positions of the original strand are factorized (:241)
+// combine the forward neighbours (lp/jp above, ls/js below) and the reverse-complement length
+// into the factor code of position i, or queue i for the exact forward search
+__device__ __forceinline__ void rc_decide(uint32_t i, uint32_t lp, uint32_t jp, uint32_t ls, uint32_t js,
+                                          uint32_t rc, uint32_t *__restrict__ code,
+                                          uint32_t *__restrict__ queue, uint32_t *__restrict__ queue_rc,
+                                          uint32_t *__restrict__ queue_count) {
+    const uint32_t M = lp > ls ? lp : ls;
+    const bool fwd_final = (M == 0) || (lp == M && i - jp >= M) || (ls == M && i - js >= M);
+    if (fwd_final) {
+        code[i] = rc_select(M, rc);
+        return;
+    }
+    uint32_t lo = 0;
+    if (lp > 0) { const uint32_t c = lp < i - jp ? lp : i - jp; lo = c > lo ? c : lo; }
+    if (ls > 0) { const uint32_t c = ls < i - js ? ls : i - js; lo = c > lo ? c : lo; }
+    code[i] = lo;  // provisional: P(lo) holds
+    const uint32_t k = atomicAdd(queue_count, 1u);
+    queue[k] = i;
+    queue_rc[k] = rc;
+}
 
+// LDS-tiled candidate search (nearest_lds.hpp): four searches per rank of the original strand
+__global__ __launch_bounds__(kLdsThreads) void rc_tile_kernel(const uint32_t *__restrict__ sa,
+                                                              const uint32_t *__restrict__ lcp, uint32_t m,
+                                                              uint32_t N, uint32_t *__restrict__ code,
+                                                              uint32_t *__restrict__ queue,
+                                                              uint32_t *__restrict__ queue_rc,
+                                                              uint32_t *__restrict__ queue_count,
+                                                              uint32_t *__restrict__ far_queue,
+                                                              uint32_t *__restrict__ far_count) {
+    constexpr int NS = 4, NP = 2;
+    __shared__ uint32_t s_sa[kLdsSpan];
+    __shared__ uint32_t s_lcp[kLdsSpan + 1];
+    __shared__ uint32_t s_len[NS * kLdsTile];
+    __shared__ uint32_t s_pos[NP * kLdsTile];
+    __shared__ uint16_t s_list[kLdsWaves][2][NS * kLdsPerWave];
+    const uint32_t base = blockIdx.x * (uint32_t)kLdsTile;
+    stage_tile(sa, lcp, m, base, s_sa, s_lcp);
+    __syncthreads();
+    const int w = threadIdx.x >> 6;
+    lds_search_wave<NS, NP>(s_sa, s_lcp, m, base, s_len, s_pos, s_list[w][0], s_list[w][1],
+                            [N](uint32_t i) { return i < N; }, [N](uint32_t i) { return 2u * N - i; });
+#pragma unroll 1
+    for (int row = 0; row < kLdsPerWave / 64; ++row) {
+        const int t = w * kLdsPerWave + row * 64 + lane_id();
+        const uint64_t rr = (uint64_t)base + t;
+        if (rr >= m) break;
+        const uint32_t i = s_sa[t + kLdsReach];
+        if (i >= N) continue;  // only positions of the original strand are factorized (:241)
+        const uint32_t lp = s_len[t], ls = s_len[kLdsTile + t];
+        const uint32_t ru = s_len[2 * kLdsTile + t], rd = s_len[3 * kLdsTile + t];
+        if (lp == kFarLen || ls == kFarLen || ru == kFarLen || rd == kFarLen) {
+            far_queue[atomicAdd(far_count, 1u)] = (uint32_t)rr;  // finish from global memory
+            continue;
+        }
+        rc_decide(i, lp, s_pos[t], ls, s_pos[kLdsTile + t], ru > rd ? ru : rd, code, queue, queue_rc, queue_count);
+    }
+}
+
+// ranks whose searches leave the LDS reach: pyramid searches from global memory
+__global__ __launch_bounds__(kThreads) void rc_far_kernel(
+    const uint32_t *__restrict__ far_queue, uint32_t count, const uint32_t *__restrict__ sa,
+    const uint32_t *__restrict__ lcp, uint32_t m, uint32_t N, Pyramid Pmin, Pyramid Pmax, Pyramid Plcp,
+    uint32_t *__restrict__ code, uint32_t *__restrict__ queue, uint32_t *__restrict__ queue_rc,
+    uint32_t *__restrict__ queue_count) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < count; k += stride) {
+        const uint32_t r = far_queue[k];
+        const uint32_t i = sa[r];
         // forward: earlier suffixes, SA[q] < i
         uint32_t lp, jp, ls, js;
         nearest_up<false>(sa, lcp, Pmin, Plcp, r, i, 0u, lp, jp);
         nearest_down<false>(sa, lcp, m, Pmin, Plcp, r, i, lp, ls, js);
-        const uint32_t M = lp > ls ? lp : ls;
-        const bool fwd_final = (M == 0) || (lp == M && i - jp >= M) || (ls == M && i - js >= M);
-
-        // reverse complement: suffixes starting after 2N - i.  A candidate can only matter if it
-        // is longer than the forward match (or than a literal).
+        // reverse complement: suffixes starting after 2N - i; lengths <= 1 can never be chosen
         const uint32_t thr = 2u * N - i;
-        const uint32_t floor = fwd_final ? (M >= 1 ? M + 1 : 2u) : 2u;
         uint32_t ru, rd, unused;
-        nearest_up<true>(sa, lcp, Pmax, Plcp, r, thr, floor, ru, unused);
-        nearest_down<true>(sa, lcp, m, Pmax, Plcp, r, thr, ru > floor ? ru : floor, rd, unused);
-        const uint32_t rc = ru > rd ? ru : rd;
-
-        if (fwd_final) {
-            code[i] = rc_select(M, rc);
-            continue;
-        }
-        uint32_t lo = 0;
-        if (lp > 0) { const uint32_t c = lp < i - jp ? lp : i - jp; lo = c > lo ? c : lo; }
-        if (ls > 0) { const uint32_t c = ls < i - js ? ls : i - js; lo = c > lo ? c : lo; }
-        code[i] = lo;  // provisional: P(lo) holds
-        const uint32_t k = atomicAdd(queue_count, 1u);
-        queue[k] = i;
-        queue_rc[k] = rc;
+        nearest_up<true>(sa, lcp, Pmax, Plcp, r, thr, 2u, ru, unused);
+        nearest_down<true>(sa, lcp, m, Pmax, Plcp, r, thr, ru > 2u ? ru : 2u, rd, unused);
+        rc_decide(i, lp, jp, ls, js, ru > rd ? ru : rd, code, queue, queue_rc, queue_count);
     }
 }
 
@@ -112,9 +154,8 @@ uint32_t run_rc_pipeline(Context &ctx, const uint8_t *d_S, size_t m_sz, size_t s
     PackedText text = pack_text(ctx, d_S, m);
     uint32_t *sa = arena.alloc<uint32_t>(m);
     uint32_t *isa = arena.alloc<uint32_t>(m);
-    build_suffix_array(ctx, text, sa, isa);
     uint32_t *lcp = arena.alloc<uint32_t>((size_t)m + 1);
-    build_lcp(ctx, text, sa, lcp);
+    build_suffix_array(ctx, text, sa, isa, lcp);
     Pyramid Pmin, Pmax, Plcp;
     {
         ProfScope ps(ctx.profiler(), "pyramids", s);
@@ -127,24 +168,31 @@ uint32_t run_rc_pipeline(Context &ctx, const uint8_t *d_S, size_t m_sz, size_t s
         const size_t mark = arena.mark();
         uint32_t *queue = arena.alloc<uint32_t>(N);
         uint32_t *queue_rc = arena.alloc<uint32_t>(N);
-        uint32_t *count = arena.alloc<uint32_t>(1);
-        HIP_CHECK(hipMemsetAsync(count, 0, sizeof(uint32_t), s));
+        uint32_t *far_queue = arena.alloc<uint32_t>(N);
+        uint32_t *counts = arena.alloc<uint32_t>(2);  // [0] exact-search queue, [1] far queue
+        HIP_CHECK(hipMemsetAsync(counts, 0, 2 * sizeof(uint32_t), s));
         {
             ProfScope ps(ctx.profiler(), "rc_candidates", s);
-            size_t g = div_up(m, kThreads);
-            if (g > 256u * 32u) g = 256u * 32u;
-            rc_candidates_kernel<<<(unsigned)g, kThreads, 0, s>>>(sa, lcp, m, N, Pmin, Pmax, Plcp, code, queue,
-                                                                  queue_rc, count);
+            rc_tile_kernel<<<(unsigned)div_up(m, kLdsTile), kLdsThreads, 0, s>>>(sa, lcp, m, N, code, queue, queue_rc,
+                                                                             counts, far_queue, counts + 1);
             KERNEL_CHECK();
         }
-        uint32_t h_count = 0;
-        ctx.read_back(count, &h_count, 1);
-        if (h_count > 0) {
-            ProfScope ps(ctx.profiler(), "rc_fallback", s);
-            size_t g = div_up(h_count, kThreads);
+        uint32_t h[2] = {0, 0};
+        ctx.read_back(counts, h, 2);
+        if (h[1] > 0) {
+            ProfScope ps(ctx.profiler(), "rc_far", s);
+            size_t g = div_up(h[1], kThreads);
             if (g > 256u * 32u) g = 256u * 32u;
-            rc_fallback_kernel<<<(unsigned)g, kThreads, 0, s>>>(queue, queue_rc, h_count, m, isa, lcp, Pmin, Plcp,
-                                                                code);
+            rc_far_kernel<<<(unsigned)g, kThreads, 0, s>>>(far_queue, h[1], sa, lcp, m, N, Pmin, Pmax, Plcp, code,
+                                                           queue, queue_rc, counts);
+            KERNEL_CHECK();
+            ctx.read_back(counts, h, 1);
+        }
+        if (h[0] > 0) {
+            ProfScope ps(ctx.profiler(), "rc_fallback", s);
+            size_t g = div_up(h[0], kThreads);
+            if (g > 256u * 32u) g = 256u * 32u;
+            rc_fallback_kernel<<<(unsigned)g, kThreads, 0, s>>>(queue, queue_rc, h[0], m, isa, lcp, Pmin, Plcp, code);
             KERNEL_CHECK();
         }
         arena.rewind(mark);

@@ -174,6 +174,8 @@ __global__ __launch_bounds__(kThreads) void mark_heads_kernel(const uint64_t *__
     }
 }
 
+constexpr uint32_t kLcpPending = 0xffffffffu;
+
 // writes the new order and ranks; keep[a] = 1 while a's group still has more than one member
 template <bool kRound0>
 __global__ __launch_bounds__(kThreads) void commit_kernel(const uint64_t *__restrict__ keys,
@@ -184,7 +186,9 @@ __global__ __launch_bounds__(kThreads) void commit_kernel(const uint64_t *__rest
                                                           const uint32_t *__restrict__ head_of, uint32_t m,
                                                           uint32_t *__restrict__ sa,
                                                           uint32_t *__restrict__ rank,
-                                                          uint32_t *__restrict__ keep) {
+                                                          uint32_t *__restrict__ keep,
+                                                          uint32_t *__restrict__ lcp, int sym_bits, int tag_bits,
+                                                          int bits) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x; a < m; a += stride) {
         const bool head = is_head<kRound0>(keys, grp, lo, a);
@@ -194,6 +198,23 @@ __global__ __launch_bounds__(kThreads) void commit_kernel(const uint64_t *__rest
         sa[slot] = i;
         rank[i] = head_of[a] + 1u;
         keep[a] = (head && next_head) ? 0u : 1u;
+        if (kRound0) {
+            // LCP of neighbours that round 0 already separates can be read off the two keys
+            // (symbol prefix, capped by both length tags); the rest is marked pending.
+            uint32_t l = kLcpPending;
+            if (a == 0) {
+                l = 0;
+            } else if (head) {
+                const uint64_t ka = keys[a], kb = keys[a - 1];
+                const uint64_t tmask = (1ull << tag_bits) - 1ull;
+                const uint32_t ta = (uint32_t)(ka & tmask), tb = (uint32_t)(kb & tmask);
+                const uint64_t x = (ka ^ kb) >> tag_bits << (64 - sym_bits);  // symbols, left-aligned
+                uint32_t ls = x ? (uint32_t)__clzll((long long)x) / (uint32_t)bits : 0xffffffffu;
+                ls = ls < ta ? ls : ta;
+                l = ls < tb ? ls : tb;
+            }
+            lcp[a] = l;
+        }
     }
 }
 
@@ -312,7 +333,8 @@ void launch_initial_keys(Context &ctx, const PackedText &t, uint64_t *keys, uint
 template <bool kRound0>
 uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *grp, const uint32_t *lo, const uint32_t *vals,
                  const uint32_t *act_slot, uint32_t m, uint32_t *sa, uint32_t *rank, uint32_t *new_slot,
-                 uint32_t *new_grp, uint32_t *tmp_a, uint32_t *tmp_b, uint32_t *tmp_c, uint32_t *d_total) {
+                 uint32_t *new_grp, uint32_t *tmp_a, uint32_t *tmp_b, uint32_t *tmp_c, uint32_t *d_total,
+                 uint32_t *lcp = nullptr, int sym_bits = 0, int tag_bits = 0, int bits = 0) {
     hipStream_t s = ctx.stream;
     {
         ProfScope ps(ctx.profiler(), "sa_mark_heads", s);
@@ -326,7 +348,8 @@ uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *grp, const 
     {
         ProfScope ps(ctx.profiler(), "sa_commit", s);
         commit_kernel<kRound0><<<grid_for(m, kThreads), kThreads, 0, s>>>(keys, grp, lo, vals, act_slot, tmp_a, m,
-                                                                          sa, rank, tmp_b);
+                                                                          sa, rank, tmp_b, lcp, sym_bits, tag_bits,
+                                                                          bits);
         KERNEL_CHECK();
     }
     {
@@ -379,7 +402,23 @@ PackedText pack_text(Context &ctx, const uint8_t *d_text, size_t n) {
     return t;
 }
 
-int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint32_t *isa) {
+// finishes the LCP entries that round 0 could not decide: both suffixes share their first
+// `skip` symbols, so the packed-word comparison starts there
+template <int BITS>
+__global__ __launch_bounds__(kThreads) void lcp_finish_kernel(const uint64_t *__restrict__ words, uint32_t n,
+                                                              const uint32_t *__restrict__ sa, uint32_t skip,
+                                                              uint32_t *__restrict__ lcp) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r <= n; r += stride) {
+        if (r == n) {
+            lcp[r] = 0;
+        } else if (lcp[r] == kLcpPending) {
+            lcp[r] = suffix_lcp<BITS>(words, n, sa[r - 1], sa[r], skip);
+        }
+    }
+}
+
+int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint32_t *isa, uint32_t *lcp) {
     const uint32_t n = text.n;
     hipStream_t s = ctx.stream;
     Arena &arena = ctx.arena;
@@ -408,8 +447,15 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         ProfScope ps(ctx.profiler(), "sa_sort_initial", s);
         cur = radix_sort_pairs(keys, vals, n, shifts, 8, arena, s, ctx.profiler());
     }
+    int tag_bits = 0;
+    switch (text.bits) {
+    case 2: tag_bits = KeyLayout<2>::kTagBits; break;
+    case 4: tag_bits = KeyLayout<4>::kTagBits; break;
+    default: tag_bits = KeyLayout<8>::kTagBits; break;
+    }
     uint32_t m = regroup<true>(ctx, keys[cur], nullptr, nullptr, vals[cur], nullptr, n, sa, rank, act_slot[0],
-                               act_grp[0], tmp_a, tmp_b, tmp_c, d_total);
+                               act_grp[0], tmp_a, tmp_b, tmp_c, d_total, lcp, k_syms * text.bits, tag_bits,
+                               text.bits);
 
     // ---- doubling rounds ------------------------------------------------------------------
     // in the rounds the 8n-byte key buffers are reused as four u32 arrays
@@ -467,6 +513,16 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     {
         ProfScope ps(ctx.profiler(), "sa_rank_to_isa", s);
         rank_to_isa_kernel<<<grid_for(n, kThreads), kThreads, 0, s>>>(rank, n);
+        KERNEL_CHECK();
+    }
+    {
+        ProfScope ps(ctx.profiler(), "lcp_finish", s);
+        const unsigned g = grid_for((size_t)n + 1, kThreads, 256u * 32u);
+        switch (text.bits) {
+        case 2: lcp_finish_kernel<2><<<g, kThreads, 0, s>>>(text.words, n, sa, (uint32_t)k_syms, lcp); break;
+        case 4: lcp_finish_kernel<4><<<g, kThreads, 0, s>>>(text.words, n, sa, (uint32_t)k_syms, lcp); break;
+        default: lcp_finish_kernel<8><<<g, kThreads, 0, s>>>(text.words, n, sa, (uint32_t)k_syms, lcp); break;
+        }
         KERNEL_CHECK();
     }
     arena.rewind(mark);
