@@ -183,6 +183,21 @@ template <typename T> struct OpMax {
     static __device__ __forceinline__ T identity() { return T(0); }
 };
 
+// Inclusive scan of a u32 across the 64 lanes with DPP only (no LDS crossbar): four shifts
+// inside each row of 16 lanes, then the last lane of row 0/2 is broadcast into row 1/3
+// (row_bcast:15) and the last lane of row 1 into rows 2-3 (row_bcast:31).  Lanes without a
+// source keep `identity` (bound_ctrl off).
+template <typename Op>
+__device__ __forceinline__ uint32_t wave_scan_inclusive_dpp(uint32_t v, uint32_t identity, Op op) {
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, 0x111, 0xf, 0xf, false));  // row_shr:1
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, 0x112, 0xf, 0xf, false));  // row_shr:2
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, 0x114, 0xf, 0xf, false));  // row_shr:4
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, 0x118, 0xf, 0xf, false));  // row_shr:8
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, 0x142, 0xa, 0xf, false));  // row_bcast:15
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, 0x143, 0xc, 0xf, false));  // row_bcast:31
+    return v;
+}
+
 // inclusive scan across the 64 lanes of a wavefront
 template <typename T, typename Op> __device__ __forceinline__ T wave_scan_inclusive(T v, Op op) {
 #pragma unroll

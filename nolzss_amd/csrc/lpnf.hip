@@ -17,6 +17,7 @@
 //      predicate, using the LCP pyramid for I(d) and the SA pyramid for the range minimum.
 #include "pipeline.hpp"
 #include "nearest_lds.hpp"
+#include "radix_sort.hpp"
 
 namespace nolzss {
 namespace {
@@ -24,30 +25,31 @@ namespace {
 constexpr int kThreads = 256;
 
 // turn the two neighbour candidates into L*[i], or queue i for the exact search
+// (*dst receives L*[i] or, for queued positions, a lower bound with P(bound) true)
 __device__ __forceinline__ void lpf_decide(uint32_t i, uint32_t lp, uint32_t jp, uint32_t ls, uint32_t js,
-                                           uint32_t *__restrict__ lstar, uint32_t *__restrict__ queue,
+                                           uint32_t *__restrict__ dst, uint32_t *__restrict__ queue,
                                            uint32_t *__restrict__ queue_count) {
     const uint32_t M = lp > ls ? lp : ls;
     if (M == 0) {
-        lstar[i] = 0;
+        *dst = 0;
         return;
     }
     const bool ok = (lp == M && i - jp >= M) || (ls == M && i - js >= M);
     if (ok) {
-        lstar[i] = M;
+        *dst = M;
         return;
     }
     // best earlier match overlaps position i: exact search needed; record a true lower bound
     uint32_t lo = 0;
     if (lp > 0) { const uint32_t c = lp < i - jp ? lp : i - jp; lo = c > lo ? c : lo; }
     if (ls > 0) { const uint32_t c = ls < i - js ? ls : i - js; lo = c > lo ? c : lo; }
-    lstar[i] = lo;
+    *dst = lo;
     queue[atomicAdd(queue_count, 1u)] = i;
 }
 
 __global__ __launch_bounds__(kLdsThreads) void lpf_tile_kernel(const uint32_t *__restrict__ sa,
                                                                const uint32_t *__restrict__ lcp, uint32_t n,
-                                                               uint32_t *__restrict__ lstar,
+                                                               uint32_t *__restrict__ lstar_by_rank,
                                                                uint32_t *__restrict__ queue,
                                                                uint32_t *__restrict__ queue_count,
                                                                uint32_t *__restrict__ far_queue,
@@ -64,18 +66,35 @@ __global__ __launch_bounds__(kLdsThreads) void lpf_tile_kernel(const uint32_t *_
     const int w = threadIdx.x >> 6;
     lds_search_wave<NS, NS>(s_sa, s_lcp, n, base, s_len, s_pos, s_list[w][0], s_list[w][1],
                         [](uint32_t) { return true; }, [](uint32_t) { return 0u; });
-#pragma unroll 1
+    // ranks with a search beyond the reach go to the far queue: one atomic per wavefront
+    uint64_t far_mask[kLdsPerWave / 64];
+    uint32_t far_total = 0;
+#pragma unroll
+    for (int row = 0; row < kLdsPerWave / 64; ++row) {
+        const int t = w * kLdsPerWave + row * 64 + lane_id();
+        const bool far = (uint64_t)base + t < n && (s_len[t] == kFarLen || s_len[kLdsTile + t] == kFarLen);
+        far_mask[row] = __ballot(far);
+        far_total += (uint32_t)__popcll(far_mask[row]);
+    }
+    uint32_t far_base = 0;
+    if (far_total) {
+        if (lane_id() == 0) far_base = atomicAdd(far_count, far_total);
+        far_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)far_base);
+    }
+#pragma unroll
     for (int row = 0; row < kLdsPerWave / 64; ++row) {
         const int t = w * kLdsPerWave + row * 64 + lane_id();
         const uint64_t rr = (uint64_t)base + t;
-        if (rr >= n) break;
-        const uint32_t i = s_sa[t + kLdsReach];
-        const uint32_t lp = s_len[t], jp = s_pos[t], ls = s_len[kLdsTile + t], js = s_pos[kLdsTile + t];
-        if (lp == kFarLen || ls == kFarLen) {
-            far_queue[atomicAdd(far_count, 1u)] = (uint32_t)rr;  // finish from global memory
+        const bool far = (far_mask[row] >> lane_id()) & 1;
+        if (far) far_queue[far_base + (uint32_t)__popcll(far_mask[row] & lanemask_lt())] = (uint32_t)rr;
+        far_base += (uint32_t)__popcll(far_mask[row]);
+        if (rr >= n) continue;
+        if (far) {
+            lstar_by_rank[rr] = 0;  // finished from global memory by lpf_far_kernel
             continue;
         }
-        lpf_decide(i, lp, jp, ls, js, lstar, queue, queue_count);
+        lpf_decide(s_sa[t + kLdsReach], s_len[t], s_pos[t], s_len[kLdsTile + t], s_pos[kLdsTile + t],
+                   lstar_by_rank + rr, queue, queue_count);
     }
 }
 
@@ -94,7 +113,7 @@ __global__ __launch_bounds__(kThreads) void lpf_far_kernel(const uint32_t *__res
         uint32_t lp, jp, ls, js;
         nearest_up<false>(sa, lcp, Psa, Plcp, r, i, 0u, lp, jp);
         nearest_down<false>(sa, lcp, n, Psa, Plcp, r, i, lp, ls, js);  // cannot beat lp below lp
-        lpf_decide(i, lp, jp, ls, js, lstar, queue, queue_count);
+        lpf_decide(i, lp, jp, ls, js, lstar + i, queue, queue_count);
     }
 }
 
@@ -120,12 +139,22 @@ uint32_t build_lstar(Context &ctx, uint32_t n, const uint32_t *sa, const uint32_
     uint32_t *queue = ctx.arena.alloc<uint32_t>(n);
     uint32_t *far_queue = ctx.arena.alloc<uint32_t>(n);
     uint32_t *counts = ctx.arena.alloc<uint32_t>(2);  // [0] exact-search queue, [1] far queue
+    uint32_t *by_rank = ctx.arena.alloc<uint32_t>(n);
+    uint32_t *scratch_idx = ctx.arena.alloc<uint32_t>(n);
+    uint32_t *scratch_val = ctx.arena.alloc<uint32_t>(n);
     HIP_CHECK(hipMemsetAsync(counts, 0, 2 * sizeof(uint32_t), s));
     {
         ProfScope ps(ctx.profiler(), "lpf", s, 12.0 * (double)n);
-        lpf_tile_kernel<<<(unsigned)div_up(n, kLdsTile), kLdsThreads, 0, s>>>(sa, lcp, n, lstar, queue, counts, far_queue,
-                                                                       counts + 1);
+        lpf_tile_kernel<<<(unsigned)div_up(n, kLdsTile), kLdsThreads, 0, s>>>(sa, lcp, n, by_rank, queue, counts,
+                                                                          far_queue, counts + 1);
         KERNEL_CHECK();
+    }
+    {
+        // lstar[sa[r]] = by_rank[r]: rank order -> text order (a permutation scatter)
+        ProfScope ps(ctx.profiler(), "lpf_to_text_order", s);
+        uint32_t *idx[2] = {const_cast<uint32_t *>(sa), scratch_idx};
+        uint32_t *val[2] = {by_rank, scratch_val};
+        bucketed_scatter(idx, val, n, lstar, n, ctx.arena, s, ctx.profiler(), true);
     }
     uint32_t h[2] = {0, 0};
     ctx.read_back(counts, h, 2);

@@ -26,6 +26,11 @@ constexpr int kLdsReach = 256;                      // steps each way that stay 
 constexpr int kLdsSpan = kLdsTile + 2 * kLdsReach;
 constexpr int kLdsStep = 8;                         // steps per round
 constexpr uint32_t kFarLen = 0xffffffffu;           // res_len marker: search left the reach
+constexpr uint32_t kLdsSparse = 24;                 // work-list length below which the wave gangs up
+
+struct OpMinU32 {
+    __device__ __forceinline__ uint32_t operator()(uint32_t a, uint32_t b) const { return a < b ? a : b; }
+};
 
 // stage SA[base - reach, base + tile + reach) and the matching LCP entries; out-of-range = 0
 __device__ __forceinline__ void stage_tile(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ lcp,
@@ -112,8 +117,9 @@ __device__ __forceinline__ void lds_search_wave(const uint32_t *s_sa, const uint
     }
 
     // ---- drain the work list: 64 items at a time, kLdsStep more steps each --------------------
+    // (while the list is long enough to keep most lanes busy)
     int cur = 0;
-    while (cnt > 0) {
+    while (cnt > kLdsSparse) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         uint32_t next_cnt = 0;
@@ -143,6 +149,57 @@ __device__ __forceinline__ void lds_search_wave(const uint32_t *s_sa, const uint
         }
         cur ^= 1;
         cnt = next_cnt;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- the long tail: few searches left, each possibly far from done.  The whole wavefront
+    // now works on ONE search at a time: lane l inspects step s0 + l + 1, a wave-wide prefix
+    // minimum gives every lane its running LCP, and a ballot finds the first lane that stops.
+    for (uint32_t e = 0; e < cnt; ++e) {
+        const uint32_t item = lists[cur][e];  // same address in every lane: broadcast
+        const int tl = item & 255, k = (item >> 8) & 3;
+        int s0 = (int)(item >> 10) * kLdsStep;
+        const int t = w * kLdsPerWave + tl;
+        const uint32_t r = base + (uint32_t)t;
+        const int li = t + kLdsReach;
+        const bool greater = k >= 2, up = (k & 1) == 0;
+        const uint32_t i = s_sa[li];
+        const uint32_t x = greater ? thr_gt(i) : i;
+        uint32_t m = res_len[k * kLdsTile + t];
+        uint32_t out_len = kFarLen, out_pos = kNoPos;
+        while (s0 < kLdsReach) {
+            const int step = s0 + lane + 1;
+            const bool inside = step <= kLdsReach;
+            const int q = inside ? (up ? li - step : li + step) : li;
+            const uint32_t c = inside ? s_lcp[q + (up ? 1 : 0)] : 0xffffffffu;
+            const uint32_t v = s_sa[q];
+            const bool oob = up ? (r < (uint32_t)step) : ((uint64_t)r + (uint32_t)step >= n);
+            uint32_t mk = wave_scan_inclusive_dpp(c, 0xffffffffu, OpMinU32());
+            mk = mk < m ? mk : m;
+            const bool dead = inside && (oob || mk == 0);
+            const bool hit = inside && !dead && (greater ? (v > x) : (v < x));
+            const uint64_t stop = __ballot(dead || hit || !inside);
+            if (stop) {
+                const int first = __ffsll((long long)stop) - 1;  // wave-uniform
+                const uint32_t f_len = (uint32_t)__builtin_amdgcn_readlane((int)mk, first);
+                const uint32_t f_pos = (uint32_t)__builtin_amdgcn_readlane((int)v, first);
+                const uint64_t hitmask = __ballot(hit), deadmask = __ballot(dead);
+                if ((hitmask >> first) & 1) {
+                    out_len = f_len;
+                    out_pos = f_pos;
+                } else if ((deadmask >> first) & 1) {
+                    out_len = 0;
+                }  // else: first stop is the end of the reach -> kFarLen
+                break;
+            }
+            m = (uint32_t)__builtin_amdgcn_readlane((int)mk, 63);
+            s0 += 64;
+        }
+        if (lane == 0) {
+            res_len[k * kLdsTile + t] = out_len;
+            if (k < NP) res_pos[k * kLdsTile + t] = out_pos;
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();

@@ -1,4 +1,4 @@
-// radix_sort.hip -- stable LSD radix sort of (u64 key, u32 value) pairs for gfx950.
+// radix_sort.hip -- stable LSD radix sort of (key, u32 value) pairs for gfx950; keys u64 or u32.
 //
 // One pass = three launches:
 //   rs_hist_kernel     per 4096-key tile, a 256-bin digit histogram (LDS atomics) written
@@ -8,8 +8,14 @@
 //                      ballot-based peer matching (64-lane match-any over the 8 digit bits),
 //                      sorts the tile by digit through LDS, and writes each bin's run with
 //                      consecutive lanes on consecutive addresses.
-// HBM-bound: algorithmic traffic per pass = n * (8 + 4) bytes read + the same written by the
-// scatter kernel, plus n * 8 bytes read by the histogram kernel.
+// HBM-bound: algorithmic traffic of the scatter kernel = 2 * (sizeof(key) + 4) bytes per pair;
+// the histogram kernel reads sizeof(key) bytes per pair.
+//
+// Occupancy is what the scatter kernel lives on: keys and values take turns in ONE LDS staging
+// buffer (37 KiB per workgroup -> 4 workgroups = 16 waves per CU), which took it from 2.0 to
+// 3.3 TB/s algorithmic on MI355X.  Tiles are dealt to XCDs in contiguous ranges (blockIdx % 8
+// shares an XCD) so that the bin runs of neighbouring tiles, adjacent in the output, meet in one
+// L2 and their partial cache lines merge there (+10 %).
 #include "radix_sort.hpp"
 
 #include "scan.hpp"
@@ -19,31 +25,30 @@
 namespace nolzss {
 namespace {
 
+constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / 64;
 constexpr int kKeysPerThread = 16;
+constexpr int kTile = kThreads * kKeysPerThread;  // 4096
 constexpr int kBins = 1 << kRadixBits;
 constexpr int kWaveSpan = 64 * kKeysPerThread;  // 1024 keys per wavefront, 16 rows of 64
 
-// Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 shares an XCD).  Give each
-// XCD a contiguous range of tiles so that the bin runs of neighbouring tiles -- which are
-// adjacent in the output -- meet in the same L2 and partial cache lines merge there.
-__device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t num_tiles, bool remap) {
-    if (!remap) return b;
+static_assert(kBins == kThreads, "one thread per bin in the offset phase");
+
+// block -> tile, XCD x owning a contiguous range of tiles (one extra tile for x < rem)
+__device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t num_tiles) {
     const uint32_t per = num_tiles / 8, rem = num_tiles % 8;
     const uint32_t x = b % 8, k = b / 8;
-    // XCD x owns tiles [x*per + min(x, rem), ...) with one extra tile for x < rem
     const uint32_t start = x * per + (x < rem ? x : rem);
     const uint32_t cnt = per + (x < rem ? 1u : 0u);
     return k < cnt ? start + k : 0xffffffffu;
 }
 
-template <int kThreads>
-__global__ __launch_bounds__(kThreads) void rs_hist_kernel(const uint64_t *__restrict__ keys,
-                                                           size_t n, int shift,
+template <typename KeyT>
+__global__ __launch_bounds__(kThreads) void rs_hist_kernel(const KeyT *__restrict__ keys, size_t n, int shift,
                                                            uint32_t *__restrict__ tile_hist,
                                                            uint32_t num_tiles) {
-    constexpr int kTile = kThreads * kKeysPerThread;
     __shared__ uint32_t hist[kBins];
-    for (int d = threadIdx.x; d < kBins; d += kThreads) hist[d] = 0;
+    hist[threadIdx.x] = 0;
     __syncthreads();
     const size_t base = (size_t)blockIdx.x * kTile;
 #pragma unroll
@@ -52,23 +57,19 @@ __global__ __launch_bounds__(kThreads) void rs_hist_kernel(const uint64_t *__res
         if (idx < n) atomicAdd(&hist[(uint32_t)(keys[idx] >> shift) & (kBins - 1)], 1u);
     }
     __syncthreads();
-    for (int d = threadIdx.x; d < kBins; d += kThreads)
-        tile_hist[(size_t)d * num_tiles + blockIdx.x] = hist[d];
+    tile_hist[(size_t)threadIdx.x * num_tiles + blockIdx.x] = hist[threadIdx.x];
 }
 
-template <int kThreads>
+template <typename KeyT>
 __global__ __launch_bounds__(kThreads) void rs_scatter_kernel(
-    const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
-    uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, size_t n, int shift,
-    const uint32_t *__restrict__ tile_base, uint32_t num_tiles, bool remap) {
-    constexpr int kWaves = kThreads / 64;
-    constexpr int kTile = kThreads * kKeysPerThread;
-    const uint32_t tile = xcd_tile(blockIdx.x, num_tiles, remap);
+    const KeyT *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, KeyT *__restrict__ keys_out,
+    uint32_t *__restrict__ vals_out, size_t n, int shift, const uint32_t *__restrict__ tile_base,
+    uint32_t num_tiles) {
+    const uint32_t tile = xcd_tile(blockIdx.x, num_tiles);
     if (tile == 0xffffffffu) return;
-    // keys and values take turns in one staging buffer (8 B x tile): 37 KiB of LDS per 256-thread
-    // workgroup instead of 53 KiB lets a fourth workgroup share the CU
-    __shared__ uint64_t s_keys[kTile];
-    uint32_t *s_vals = reinterpret_cast<uint32_t *>(s_keys);
+    __shared__ uint64_t s_stage[kTile];  // keys, then values, take turns here
+    KeyT *s_keys = reinterpret_cast<KeyT *>(s_stage);
+    uint32_t *s_vals = reinterpret_cast<uint32_t *>(s_stage);
     __shared__ uint32_t s_whist[kWaves * kBins];
     __shared__ uint32_t s_glob[kBins];
     __shared__ uint32_t s_scan[kWaves];
@@ -78,11 +79,12 @@ __global__ __launch_bounds__(kThreads) void rs_scatter_kernel(
     const int lane = tid & 63;
     volatile uint32_t *whist = s_whist + w * kBins;
 
-    for (int k = tid; k < kWaves * kBins; k += kThreads) s_whist[k] = 0;
+#pragma unroll
+    for (int k = 0; k < kWaves; ++k) s_whist[k * kBins + tid] = 0;
     __syncthreads();
 
     const size_t base = (size_t)tile * kTile;
-    uint64_t key[kKeysPerThread];
+    KeyT key[kKeysPerThread];
     uint32_t val[kKeysPerThread];
     uint32_t lrank[kKeysPerThread];
 
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(kThreads) void rs_scatter_kernel(
     for (int row = 0; row < kKeysPerThread; ++row) {
         const size_t idx = base + (size_t)w * kWaveSpan + (size_t)row * 64 + lane;
         const bool valid = idx < n;
-        key[row] = valid ? keys_in[idx] : 0;
+        key[row] = valid ? keys_in[idx] : KeyT(0);
         val[row] = valid ? vals_in[idx] : 0;
         const uint32_t d = (uint32_t)(key[row] >> shift) & (kBins - 1);
         uint64_t peers = __ballot(valid);
@@ -114,25 +116,20 @@ __global__ __launch_bounds__(kThreads) void rs_scatter_kernel(
     {
         const int d = tid;
         uint32_t c[kWaves], total = 0;
-        if (d < kBins) {
 #pragma unroll
-            for (int k = 0; k < kWaves; ++k) {
-                c[k] = s_whist[k * kBins + d];
-                total += c[k];
-            }
+        for (int k = 0; k < kWaves; ++k) {
+            c[k] = s_whist[k * kBins + d];
+            total += c[k];
         }
         uint32_t tile_total;
-        const uint32_t bin_start =
-            block_scan_exclusive<kWaves>(total, OpAdd<uint32_t>(), s_scan, tile_total);
-        if (d < kBins) {
-            uint32_t run = bin_start;
+        const uint32_t bin_start = block_scan_exclusive<kWaves>(total, OpAdd<uint32_t>(), s_scan, tile_total);
+        uint32_t run = bin_start;
 #pragma unroll
-            for (int k = 0; k < kWaves; ++k) {
-                s_whist[k * kBins + d] = run;
-                run += c[k];
-            }
-            s_glob[d] = tile_base[(size_t)d * num_tiles + tile] - bin_start;
+        for (int k = 0; k < kWaves; ++k) {
+            s_whist[k * kBins + d] = run;
+            run += c[k];
         }
+        s_glob[d] = tile_base[(size_t)d * num_tiles + tile] - bin_start;
     }
     __syncthreads();
 
@@ -155,7 +152,7 @@ __global__ __launch_bounds__(kThreads) void rs_scatter_kernel(
     for (int j = 0; j < kKeysPerThread; ++j) {
         const uint32_t p = (uint32_t)j * kThreads + tid;
         if (p < count) {
-            const uint64_t k = s_keys[p];
+            const KeyT k = s_keys[p];
             const uint32_t d = (uint32_t)(k >> shift) & (kBins - 1);
             gpos[j] = s_glob[d] + p;
             keys_out[gpos[j]] = k;
@@ -175,18 +172,18 @@ __global__ __launch_bounds__(kThreads) void rs_scatter_kernel(
     }
 }
 
-template <int kThreads>
-int radix_sort_impl(uint64_t *keys[2], uint32_t *vals[2], size_t n, const int *shifts, int npasses,
-                    Arena &arena, hipStream_t stream, Profiler *prof, bool remap) {
-    constexpr int kTile = kThreads * kKeysPerThread;
+template <typename KeyT>
+int radix_sort_impl(KeyT *keys[2], uint32_t *vals[2], size_t n, const int *shifts, int npasses, Arena &arena,
+                    hipStream_t stream, Profiler *prof) {
+    if (n == 0 || npasses == 0) return 0;
     const size_t m = arena.mark();
     const uint32_t num_tiles = (uint32_t)div_up(n, kTile);
     uint32_t *hist = arena.alloc<uint32_t>((size_t)kBins * num_tiles);
     int cur = 0;
     for (int p = 0; p < npasses; ++p) {
         {
-            ProfScope ps(prof, "rs_hist", stream, 8.0 * (double)n);
-            rs_hist_kernel<kThreads><<<num_tiles, kThreads, 0, stream>>>(keys[cur], n, shifts[p], hist, num_tiles);
+            ProfScope ps(prof, "rs_hist", stream, (double)sizeof(KeyT) * (double)n);
+            rs_hist_kernel<KeyT><<<num_tiles, kThreads, 0, stream>>>(keys[cur], n, shifts[p], hist, num_tiles);
             KERNEL_CHECK();
         }
         {
@@ -195,12 +192,11 @@ int radix_sort_impl(uint64_t *keys[2], uint32_t *vals[2], size_t n, const int *s
         }
         {
             // algorithmic bytes of one scatter launch: every (key, value) pair read once and
-            // written once = 2 * (8 + 4) bytes per pair
-            ProfScope ps(prof, "rs_scatter", stream, 24.0 * (double)n);
-            const uint32_t grid = remap ? (uint32_t)div_up(num_tiles, 8) * 8 : num_tiles;
-            rs_scatter_kernel<kThreads><<<grid, kThreads, 0, stream>>>(keys[cur], vals[cur], keys[cur ^ 1],
-                                                                       vals[cur ^ 1], n, shifts[p], hist,
-                                                                       num_tiles, remap);
+            // written once = 2 * (sizeof(key) + 4) bytes per pair
+            ProfScope ps(prof, "rs_scatter", stream, 2.0 * (sizeof(KeyT) + 4.0) * (double)n);
+            const uint32_t grid = (uint32_t)div_up(num_tiles, 8) * 8;
+            rs_scatter_kernel<KeyT><<<grid, kThreads, 0, stream>>>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1],
+                                                                   n, shifts[p], hist, num_tiles);
             KERNEL_CHECK();
         }
         cur ^= 1;
@@ -209,20 +205,106 @@ int radix_sort_impl(uint64_t *keys[2], uint32_t *vals[2], size_t n, const int *s
     return cur;
 }
 
+__global__ __launch_bounds__(kThreads) void plain_scatter_kernel(const uint32_t *__restrict__ idx,
+                                                                 const uint32_t *__restrict__ val, size_t count,
+                                                                 uint32_t *__restrict__ out, uint32_t n_out,
+                                                                 uint32_t num_tiles) {
+    const uint32_t tile = xcd_tile(blockIdx.x, num_tiles);
+    if (tile == 0xffffffffu) return;
+    const size_t base = (size_t)tile * kTile;
+#pragma unroll
+    for (int j = 0; j < kKeysPerThread; ++j) {
+        const size_t k = base + (size_t)j * kThreads + threadIdx.x;
+        if (k < count) {
+            const uint32_t i = idx[k];
+            if (i < n_out) out[i] = val[k];
+        }
+    }
+}
+
+constexpr int kWindowBitsMax = 14;  // 2^14 entries = 64 KiB of LDS
+
+// permutation scatter, final step: the pairs of window w sit at list positions [w*W, (w+1)*W)
+__global__ __launch_bounds__(kThreads) void window_scatter_kernel(const uint32_t *__restrict__ idx,
+                                                                  const uint32_t *__restrict__ val,
+                                                                  uint32_t *__restrict__ out, uint32_t n_out,
+                                                                  int window_bits) {
+    __shared__ uint32_t s_out[1 << kWindowBitsMax];
+    const uint32_t W = 1u << window_bits;
+    const size_t base = (size_t)blockIdx.x << window_bits;
+    const uint32_t len = (uint32_t)((n_out - base < (size_t)W) ? (n_out - base) : (size_t)W);
+    for (uint32_t t = threadIdx.x; t < len; t += kThreads) s_out[idx[base + t] - (uint32_t)base] = val[base + t];
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < len; t += kThreads) out[base + t] = s_out[t];
+}
+
 }  // namespace
 
-int radix_sort_pairs(uint64_t *keys[2], uint32_t *vals[2], size_t n, const int *shifts,
-                     int npasses, Arena &arena, hipStream_t stream, Profiler *prof) {
-    if (n == 0 || npasses == 0) return 0;
-    // tuning knob (bit 0: XCD-contiguous tile mapping, bit 1: 512-thread / 8192-key tiles);
-    // default = the fastest measured on MI355X: 256 threads, XCD mapping on
-    static const int variant = [] {
-        const char *e = getenv("NOLZSS_RS_VARIANT");
-        return e ? atoi(e) : 1;
-    }();
-    const bool remap = (variant & 1) != 0;
-    if (variant & 2) return radix_sort_impl<512>(keys, vals, n, shifts, npasses, arena, stream, prof, remap);
-    return radix_sort_impl<256>(keys, vals, n, shifts, npasses, arena, stream, prof, remap);
+void bucketed_scatter(uint32_t *idx[2], uint32_t *val[2], size_t count, uint32_t *out, uint32_t n_out,
+                      Arena &arena, hipStream_t stream, Profiler *prof, bool keep_input) {
+    if (count == 0) return;
+    const size_t amark = arena.mark();
+    int nbits = 1;
+    while (nbits < 32 && (1ull << nbits) < (uint64_t)n_out) ++nbits;
+    const bool big = (size_t)n_out * 4 > (size_t(64) << 20) && count > (size_t(1) << 22);
+    if (big && count == n_out && nbits <= 2 * kRadixBits + kWindowBitsMax) {
+        // idx is a permutation of [0, n_out): two radix passes leave window w = [w*W, (w+1)*W)
+        // exactly at list positions [w*W, (w+1)*W); each window is assembled in LDS and written
+        // out as full lines.
+        const int wb = nbits > 2 * kRadixBits + 10 ? nbits - 2 * kRadixBits : 10;
+        const int shifts[2] = {wb, wb + kRadixBits};
+        // pass 1: buffer 0 -> 1; pass 2: 1 -> 0, or 1 -> a third buffer if the input must survive
+        radix_sort_pairs(idx, val, count, shifts, 1, arena, stream, prof);
+        uint32_t *idx2[2] = {idx[1], keep_input ? arena.alloc<uint32_t>(count) : idx[0]};
+        uint32_t *val2[2] = {val[1], keep_input ? arena.alloc<uint32_t>(count) : val[0]};
+        radix_sort_pairs(idx2, val2, count, shifts + 1, 1, arena, stream, prof);
+        {
+            ProfScope ps(prof, "window_scatter", stream, 12.0 * (double)count);
+            const uint32_t W = 1u << wb;
+            window_scatter_kernel<<<(unsigned)div_up(n_out, W), kThreads, 0, stream>>>(idx2[1], val2[1], out, n_out,
+                                                                                    wb);
+            KERNEL_CHECK();
+        }
+        arena.rewind(amark);
+        return;
+    }
+    int cur = 0;
+    if (big) {
+        // partial scatter: partition so that all writes in flight fall into 2 MiB windows of the
+        // target, which one XCD's L2 can merge
+        const int window_bits = 19;
+        if (nbits > window_bits) {
+            int shift = window_bits;
+            radix_sort_pairs(idx, val, count, &shift, 1, arena, stream, prof);
+            cur = 1;
+            if (nbits > window_bits + kRadixBits) {
+                uint32_t *idx2[2] = {idx[1], keep_input ? arena.alloc<uint32_t>(count) : idx[0]};
+                uint32_t *val2[2] = {val[1], keep_input ? arena.alloc<uint32_t>(count) : val[0]};
+                shift = window_bits + kRadixBits;
+                radix_sort_pairs(idx2, val2, count, &shift, 1, arena, stream, prof);
+                idx[1] = idx2[1];  // (local copies of the caller's pointers)
+                val[1] = val2[1];
+            }
+        }
+    }
+    {
+        ProfScope ps(prof, "bucket_scatter", stream, 12.0 * (double)count);
+        const uint32_t num_tiles = (uint32_t)div_up(count, kTile);
+        const uint32_t grid = (uint32_t)div_up(num_tiles, 8) * 8;
+        plain_scatter_kernel<<<grid, kThreads, 0, stream>>>(idx[cur], val[cur], count, out, n_out, num_tiles);
+        KERNEL_CHECK();
+    }
+    arena.rewind(amark);
+}
+
+int radix_sort_pairs(uint64_t *keys[2], uint32_t *vals[2], size_t n, const int *shifts, int npasses,
+                     Arena &arena, hipStream_t stream, Profiler *prof) {
+    return radix_sort_impl<uint64_t>(keys, vals, n, shifts, npasses, arena, stream, prof);
+}
+
+int radix_sort_pairs(uint32_t *keys[2], uint32_t *vals[2], size_t n, const int *shifts, int npasses,
+                     Arena &arena, hipStream_t stream, Profiler *prof) {
+    return radix_sort_impl<uint32_t>(keys, vals, n, shifts, npasses, arena, stream, prof);
 }
 
 }  // namespace nolzss

@@ -1,4 +1,4 @@
-// radix_sort.hpp -- LSD radix sort of (u64 key, u32 value) pairs, 8-bit digits.
+// radix_sort.hpp -- LSD radix sort of (u64 or u32 key, u32 value) pairs, 8-bit digits.
 #pragma once
 #include "common.hpp"
 
@@ -13,5 +13,19 @@ constexpr int kRadixBits = 8;
 // prof (optional) receives per-kernel HIP-event timings: "rs_hist", "rs_scan", "rs_scatter".
 int radix_sort_pairs(uint64_t *keys[2], uint32_t *vals[2], size_t n, const int *shifts,
                      int npasses, Arena &arena, hipStream_t stream, Profiler *prof = nullptr);
+int radix_sort_pairs(uint32_t *keys[2], uint32_t *vals[2], size_t n, const int *shifts,
+                     int npasses, Arena &arena, hipStream_t stream, Profiler *prof = nullptr);
+
+// out[idx[k]] = val[k] for k < count, idx[k] < n_out (entries with idx >= n_out are dropped).
+// A random 4-byte scatter over an array much larger than the caches costs a read-modify-write
+// of a whole line per element at HBM.  For large targets the pairs are therefore first
+// partitioned by the top 8 bits of idx (one radix pass, coalesced), then written bucket by
+// bucket so that all writes in flight fall into a window of n_out/256 entries that L2 /
+// Infinity Cache can merge into full lines (a permutation of the whole target is assembled
+// window by window in LDS instead).  idx[0]/val[0] hold the input, idx[1]/val[1] are scratch of
+// the same size.  With keep_input the input arrays survive (a third pair of buffers is taken
+// from the arena); otherwise they are used as scratch too.  The pointer arrays may be updated.
+void bucketed_scatter(uint32_t *idx[2], uint32_t *val[2], size_t count, uint32_t *out, uint32_t n_out,
+                      Arena &arena, hipStream_t stream, Profiler *prof, bool keep_input);
 
 }  // namespace nolzss

@@ -18,6 +18,7 @@
 // depth, hence explicit, and fwd = L_f directly; only overlapping positions take the exact path.
 #include "nearest_lds.hpp"
 #include "pipeline.hpp"
+#include "radix_sort.hpp"
 
 namespace nolzss {
 namespace {
@@ -32,20 +33,21 @@ __device__ __forceinline__ uint32_t rc_select(uint32_t fwd, uint32_t rc) {
 
 // combine the forward neighbours (lp/jp above, ls/js below) and the reverse-complement length
 // into the factor code of position i, or queue i for the exact forward search
+// (*dst receives the code, or for queued positions a forward lower bound with P(bound) true)
 __device__ __forceinline__ void rc_decide(uint32_t i, uint32_t lp, uint32_t jp, uint32_t ls, uint32_t js,
-                                          uint32_t rc, uint32_t *__restrict__ code,
+                                          uint32_t rc, uint32_t *__restrict__ dst,
                                           uint32_t *__restrict__ queue, uint32_t *__restrict__ queue_rc,
                                           uint32_t *__restrict__ queue_count) {
     const uint32_t M = lp > ls ? lp : ls;
     const bool fwd_final = (M == 0) || (lp == M && i - jp >= M) || (ls == M && i - js >= M);
     if (fwd_final) {
-        code[i] = rc_select(M, rc);
+        *dst = rc_select(M, rc);
         return;
     }
     uint32_t lo = 0;
     if (lp > 0) { const uint32_t c = lp < i - jp ? lp : i - jp; lo = c > lo ? c : lo; }
     if (ls > 0) { const uint32_t c = ls < i - js ? ls : i - js; lo = c > lo ? c : lo; }
-    code[i] = lo;  // provisional: P(lo) holds
+    *dst = lo;  // provisional: P(lo) holds
     const uint32_t k = atomicAdd(queue_count, 1u);
     queue[k] = i;
     queue_rc[k] = rc;
@@ -54,7 +56,7 @@ __device__ __forceinline__ void rc_decide(uint32_t i, uint32_t lp, uint32_t jp, 
 // LDS-tiled candidate search (nearest_lds.hpp): four searches per rank of the original strand
 __global__ __launch_bounds__(kLdsThreads) void rc_tile_kernel(const uint32_t *__restrict__ sa,
                                                               const uint32_t *__restrict__ lcp, uint32_t m,
-                                                              uint32_t N, uint32_t *__restrict__ code,
+                                                              uint32_t N, uint32_t *__restrict__ code_by_rank,
                                                               uint32_t *__restrict__ queue,
                                                               uint32_t *__restrict__ queue_rc,
                                                               uint32_t *__restrict__ queue_count,
@@ -78,14 +80,19 @@ __global__ __launch_bounds__(kLdsThreads) void rc_tile_kernel(const uint32_t *__
         const uint64_t rr = (uint64_t)base + t;
         if (rr >= m) break;
         const uint32_t i = s_sa[t + kLdsReach];
-        if (i >= N) continue;  // only positions of the original strand are factorized (:241)
+        if (i >= N) {  // only positions of the original strand are factorized (:241)
+            code_by_rank[rr] = 0;
+            continue;
+        }
         const uint32_t lp = s_len[t], ls = s_len[kLdsTile + t];
         const uint32_t ru = s_len[2 * kLdsTile + t], rd = s_len[3 * kLdsTile + t];
         if (lp == kFarLen || ls == kFarLen || ru == kFarLen || rd == kFarLen) {
             far_queue[atomicAdd(far_count, 1u)] = (uint32_t)rr;  // finish from global memory
+            code_by_rank[rr] = 0;
             continue;
         }
-        rc_decide(i, lp, s_pos[t], ls, s_pos[kLdsTile + t], ru > rd ? ru : rd, code, queue, queue_rc, queue_count);
+        rc_decide(i, lp, s_pos[t], ls, s_pos[kLdsTile + t], ru > rd ? ru : rd, code_by_rank + rr, queue, queue_rc,
+                  queue_count);
     }
 }
 
@@ -108,7 +115,7 @@ __global__ __launch_bounds__(kThreads) void rc_far_kernel(
         uint32_t ru, rd, unused;
         nearest_up<true>(sa, lcp, Pmax, Plcp, r, thr, 2u, ru, unused);
         nearest_down<true>(sa, lcp, m, Pmax, Plcp, r, thr, ru > 2u ? ru : 2u, rd, unused);
-        rc_decide(i, lp, jp, ls, js, ru > rd ? ru : rd, code, queue, queue_rc, queue_count);
+        rc_decide(i, lp, jp, ls, js, ru > rd ? ru : rd, code + i, queue, queue_rc, queue_count);
     }
 }
 
@@ -163,19 +170,30 @@ uint32_t run_rc_pipeline(Context &ctx, const uint8_t *d_S, size_t m_sz, size_t s
         Pmax = build_pyramid(sa, m, true, arena, s);
         Plcp = build_pyramid(lcp, m + 1, false, arena, s);
     }
-    uint32_t *code = arena.alloc<uint32_t>(N);
+    // code[] spans all of S (entries >= N are unused) so that rank order -> text order is a
+    // permutation scatter
+    uint32_t *code = arena.alloc<uint32_t>(m);
     {
         const size_t mark = arena.mark();
         uint32_t *queue = arena.alloc<uint32_t>(N);
         uint32_t *queue_rc = arena.alloc<uint32_t>(N);
         uint32_t *far_queue = arena.alloc<uint32_t>(N);
         uint32_t *counts = arena.alloc<uint32_t>(2);  // [0] exact-search queue, [1] far queue
+        uint32_t *by_rank = arena.alloc<uint32_t>(m);
+        uint32_t *scratch_idx = arena.alloc<uint32_t>(m);
+        uint32_t *scratch_val = arena.alloc<uint32_t>(m);
         HIP_CHECK(hipMemsetAsync(counts, 0, 2 * sizeof(uint32_t), s));
         {
             ProfScope ps(ctx.profiler(), "rc_candidates", s);
-            rc_tile_kernel<<<(unsigned)div_up(m, kLdsTile), kLdsThreads, 0, s>>>(sa, lcp, m, N, code, queue, queue_rc,
-                                                                             counts, far_queue, counts + 1);
+            rc_tile_kernel<<<(unsigned)div_up(m, kLdsTile), kLdsThreads, 0, s>>>(sa, lcp, m, N, by_rank, queue,
+                                                                             queue_rc, counts, far_queue, counts + 1);
             KERNEL_CHECK();
+        }
+        {
+            ProfScope ps(ctx.profiler(), "rc_to_text_order", s);
+            uint32_t *idx[2] = {sa, scratch_idx};
+            uint32_t *val[2] = {by_rank, scratch_val};
+            bucketed_scatter(idx, val, m, code, m, arena, s, ctx.profiler(), true);
         }
         uint32_t h[2] = {0, 0};
         ctx.read_back(counts, h, 2);

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(kThreads) void commit_kernel(const uint64_t *__rest
                                                           const uint32_t *__restrict__ act_slot,
                                                           const uint32_t *__restrict__ head_of, uint32_t m,
                                                           uint32_t *__restrict__ sa,
-                                                          uint32_t *__restrict__ rank,
+                                                          uint32_t *__restrict__ rank_val,
                                                           uint32_t *__restrict__ keep,
                                                           uint32_t *__restrict__ lcp, int sym_bits, int tag_bits,
                                                           int bits) {
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(kThreads) void commit_kernel(const uint64_t *__rest
         const uint32_t slot = kRound0 ? (uint32_t)a : act_slot[a];
         const uint32_t i = vals[a];
         sa[slot] = i;
-        rank[i] = head_of[a] + 1u;
+        rank_val[a] = head_of[a] + 1u;  // goes to rank[i] through bucketed_scatter
         keep[a] = (head && next_head) ? 0u : 1u;
         if (kRound0) {
             // LCP of neighbours that round 0 already separates can be read off the two keys
@@ -331,10 +331,11 @@ void launch_initial_keys(Context &ctx, const PackedText &t, uint64_t *keys, uint
 
 // shared tail of every round: sorted view of m active elements -> sa / rank / next active list
 template <bool kRound0>
-uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *grp, const uint32_t *lo, const uint32_t *vals,
-                 const uint32_t *act_slot, uint32_t m, uint32_t *sa, uint32_t *rank, uint32_t *new_slot,
-                 uint32_t *new_grp, uint32_t *tmp_a, uint32_t *tmp_b, uint32_t *tmp_c, uint32_t *d_total,
-                 uint32_t *lcp = nullptr, int sym_bits = 0, int tag_bits = 0, int bits = 0) {
+uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *grp, const uint32_t *lo, uint32_t *vals,
+                 const uint32_t *act_slot, uint32_t m, uint32_t n, uint32_t *sa, uint32_t *rank, uint32_t *new_slot,
+                 uint32_t *new_grp, uint32_t *tmp_a, uint32_t *tmp_b, uint32_t *tmp_c, uint32_t *scratch_idx,
+                 uint32_t *scratch_val, uint32_t *rank_val, uint32_t *d_total, uint32_t *lcp = nullptr,
+                 int sym_bits = 0, int tag_bits = 0, int bits = 0) {
     hipStream_t s = ctx.stream;
     {
         ProfScope ps(ctx.profiler(), "sa_mark_heads", s);
@@ -348,9 +349,16 @@ uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *grp, const 
     {
         ProfScope ps(ctx.profiler(), "sa_commit", s);
         commit_kernel<kRound0><<<grid_for(m, kThreads), kThreads, 0, s>>>(keys, grp, lo, vals, act_slot, tmp_a, m,
-                                                                          sa, rank, tmp_b, lcp, sym_bits, tag_bits,
-                                                                          bits);
+                                                                          sa, rank_val, tmp_b, lcp, sym_bits,
+                                                                          tag_bits, bits);
         KERNEL_CHECK();
+    }
+    {
+        // rank[vals[a]] = rank_val[a]: the one truly random write of the round
+        ProfScope ps(ctx.profiler(), "sa_rank_scatter", s);
+        uint32_t *idx[2] = {vals, scratch_idx};
+        uint32_t *val[2] = {rank_val, scratch_val};
+        bucketed_scatter(idx, val, m, rank, n, ctx.arena, s, ctx.profiler(), false);
     }
     {
         ProfScope ps(ctx.profiler(), "sa_scan", s);
@@ -431,6 +439,9 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     uint32_t *tmp_a = arena.alloc<uint32_t>(n);
     uint32_t *tmp_b = arena.alloc<uint32_t>(n);
     uint32_t *tmp_c = arena.alloc<uint32_t>(n);
+    uint32_t *rank_val = arena.alloc<uint32_t>(n);
+    uint32_t *scratch_idx = arena.alloc<uint32_t>(n);
+    uint32_t *scratch_val = arena.alloc<uint32_t>(n);
     uint32_t *d_total = arena.alloc<uint32_t>(1);
     uint32_t *rank = isa;
 
@@ -453,9 +464,9 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     case 4: tag_bits = KeyLayout<4>::kTagBits; break;
     default: tag_bits = KeyLayout<8>::kTagBits; break;
     }
-    uint32_t m = regroup<true>(ctx, keys[cur], nullptr, nullptr, vals[cur], nullptr, n, sa, rank, act_slot[0],
-                               act_grp[0], tmp_a, tmp_b, tmp_c, d_total, lcp, k_syms * text.bits, tag_bits,
-                               text.bits);
+    uint32_t m = regroup<true>(ctx, keys[cur], nullptr, nullptr, vals[cur], nullptr, n, n, sa, rank, act_slot[0],
+                               act_grp[0], tmp_a, tmp_b, tmp_c, scratch_idx, scratch_val, rank_val, d_total, lcp,
+                               k_syms * text.bits, tag_bits, text.bits);
 
     // ---- doubling rounds ------------------------------------------------------------------
     // in the rounds the 8n-byte key buffers are reused as four u32 arrays
@@ -504,8 +515,8 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
             KERNEL_CHECK();
             arena.rewind(lmark);
         }
-        m = regroup<false>(ctx, nullptr, grp, out_lo, out_vals, slot, m, sa, rank, act_slot[a_cur ^ 1],
-                           act_grp[a_cur ^ 1], tmp_a, tmp_b, tmp_c, d_total);
+        m = regroup<false>(ctx, nullptr, grp, out_lo, out_vals, slot, m, n, sa, rank, act_slot[a_cur ^ 1],
+                           act_grp[a_cur ^ 1], tmp_a, tmp_b, tmp_c, scratch_idx, scratch_val, rank_val, d_total);
         a_cur ^= 1;
         h *= 2;
         ++rounds;
