@@ -174,7 +174,10 @@ __global__ __launch_bounds__(kThreads) void mark_heads_kernel(const uint64_t *__
     }
 }
 
+// LCP codes while the suffix array is being built: kLcpPending = same round-0 key, boundary not
+// seen yet; kLcpPending - 1 - j = boundary appeared in doubling round j (offset K << j).
 constexpr uint32_t kLcpPending = 0xffffffffu;
+constexpr uint32_t kLcpPendingMin = kLcpPending - 64u;
 
 // writes the new order and ranks; keep[a] = 1 while a's group still has more than one member
 template <bool kRound0>
@@ -198,6 +201,12 @@ __global__ __launch_bounds__(kThreads) void commit_kernel(const uint64_t *__rest
         sa[slot] = i;
         rank_val[a] = head_of[a] + 1u;  // goes to rank[i] through bucketed_scatter
         keep[a] = (head && next_head) ? 0u : 1u;
+        if (!kRound0) {
+            // a boundary that appears in the round with offset h = K << round separates two
+            // suffixes that agree on their first h symbols: remember the round so that
+            // lcp_finish_kernel can start comparing there
+            if (head && a > 0 && grp[a] == grp[a - 1]) lcp[slot] = kLcpPending - 1u - (uint32_t)bits;
+        }
         if (kRound0) {
             // LCP of neighbours that round 0 already separates can be read off the two keys
             // (symbol prefix, capped by both length tags); the rest is marked pending.
@@ -420,8 +429,16 @@ __global__ __launch_bounds__(kThreads) void lcp_finish_kernel(const uint64_t *__
     for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r <= n; r += stride) {
         if (r == n) {
             lcp[r] = 0;
-        } else if (lcp[r] == kLcpPending) {
-            lcp[r] = suffix_lcp<BITS>(words, n, sa[r - 1], sa[r], skip);
+        } else {
+            const uint32_t code = lcp[r];
+            if (code >= kLcpPendingMin) {
+                // both suffixes share their first (K << round) symbols, capped by the text end
+                uint64_t h0 = skip;
+                if (code != kLcpPending) h0 = (uint64_t)skip << (kLcpPending - 1u - code);
+                const uint32_t a = sa[r - 1], b = sa[r];
+                const uint32_t limit = n - (a > b ? a : b);
+                lcp[r] = suffix_lcp<BITS>(words, n, a, b, h0 < limit ? (uint32_t)h0 : limit);
+            }
         }
     }
 }
@@ -516,7 +533,8 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
             arena.rewind(lmark);
         }
         m = regroup<false>(ctx, nullptr, grp, out_lo, out_vals, slot, m, n, sa, rank, act_slot[a_cur ^ 1],
-                           act_grp[a_cur ^ 1], tmp_a, tmp_b, tmp_c, scratch_idx, scratch_val, rank_val, d_total);
+                           act_grp[a_cur ^ 1], tmp_a, tmp_b, tmp_c, scratch_idx, scratch_val, rank_val, d_total, lcp,
+                           0, 0, /*round index, carried in the `bits` slot*/ rounds);
         a_cur ^= 1;
         h *= 2;
         ++rounds;
