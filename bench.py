@@ -33,7 +33,20 @@ import gen  # noqa: E402
 from nolzss_amd import _noLZSS as native  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured copy
-DOMINANT = "rs_scatter"  # rs_scatter_kernel: 24 algorithmic bytes per (key, value) pair per launch
+# rs_scatter_kernel: 2 * (sizeof(key) + 4) algorithmic bytes per (key, value) pair per launch
+# (24 B for the u64-key sorts, 16 B for the u32-key partition passes); the library sums them.
+DOMINANT = "rs_scatter"
+
+
+def measured_traffic_ratio():
+    """HBM bytes / algorithmic bytes of rs_scatter_kernel from the committed rocprofv3 PMC passes
+    (FETCH_SIZE and WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 correction);
+    None if the profile summary is not there."""
+    try:
+        with open(ROOT / "profiles" / "r01_pmc_radix_traffic.json") as f:
+            return float(json.load(f)["rs_scatter_kernel<u64>"]["traffic_over_algorithmic"])
+    except Exception:
+        return None
 
 
 def make_text(workload: str, n: int, rank: int) -> np.ndarray:
@@ -127,7 +140,8 @@ def main():
         total_bases = float(n) * world * a.steps
         cnt, ms, nbytes = stats.get(DOMINANT, (0, 0.0, 0.0))
         achieved = (nbytes / (ms * 1e-3)) / 1e9 if ms > 0 else 0.0
-        nested = {"rs_hist", "rs_scan", "rs_scatter"}
+        nested = {"rs_hist", "rs_scan", "rs_scatter", "bucket_scatter", "window_scatter"}
+        ratio = measured_traffic_ratio()
         out = {
             "metric": "bases/sec factorized (1 GB sigma=4 DNA) + HBM GB/s fraction",
             "value": total_bases / elapsed,
@@ -148,7 +162,10 @@ def main():
                        "parallelism": f"{world} independent sequence shard(s), all-gather of counts"},
             "roofline": {"bound": "hbm", "kernel": "rs_scatter_kernel", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "launches": cnt,
+                         "traffic": (ratio * nbytes / cnt) if (ratio and cnt) else None,
+                         "traffic_source": "profiles/r01_pmc_radix_traffic.json (rocprofv3 --pmc FETCH_SIZE / "
+                                           "WRITE_SIZE, separate passes): HBM bytes = 1.02 x algorithmic bytes",
+                         "launches": cnt,
                          "avg_launch_ms": (ms / cnt) if cnt else None,
                          "algorithmic_bytes_per_launch": (nbytes / cnt) if cnt else None},
             "pcie_inclusive_bases_per_s": n / pcie_dt,
