@@ -191,7 +191,7 @@ __global__ __launch_bounds__(kThreads) void commit_kernel(const uint64_t *__rest
                                                           uint32_t *__restrict__ rank_val,
                                                           uint32_t *__restrict__ keep,
                                                           uint32_t *__restrict__ lcp, int sym_bits, int tag_bits,
-                                                          int bits) {
+                                                          int bits, const uint32_t *__restrict__ lcp_list) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x; a < m; a += stride) {
         const bool head = is_head<kRound0>(keys, grp, lo, a);
@@ -205,7 +205,8 @@ __global__ __launch_bounds__(kThreads) void commit_kernel(const uint64_t *__rest
             // a boundary that appears in the round with offset h = K << round separates two
             // suffixes that agree on their first h symbols: remember the round so that
             // lcp_finish_kernel can start comparing there
-            if (head && a > 0 && grp[a] == grp[a - 1]) lcp[slot] = kLcpPending - 1u - (uint32_t)bits;
+            if (head && a > 0 && grp[a] == grp[a - 1])
+                lcp[slot] = lcp_list ? lcp_list[a] : kLcpPending - 1u - (uint32_t)bits;
         }
         if (kRound0) {
             // LCP of neighbours that round 0 already separates can be read off the two keys
@@ -294,6 +295,75 @@ __global__ __launch_bounds__(kThreads) void small_sort_kernel(const uint32_t *__
     }
 }
 
+// First round after the key sort: members of a small group are ordered by comparing their
+// suffixes DIRECTLY in the packed text (they agree on the first h0 symbols; at most `cap` symbols
+// are inspected).  For sequence data nearly every group is a pair or a triple whose members
+// differ within a few hundred symbols, so this one pass finishes them -- order, new group
+// boundaries and the LCP to the predecessor -- where prefix doubling would need log2(LCP / h0)
+// gather + sort + scatter rounds.  Members that still agree after `cap` symbols stay grouped
+// (out_lo = number of strictly smaller members is equal for them) and go on to the doubling
+// rounds, as do groups larger than kSmallGroup (flagged for the radix path).
+template <int BITS>
+__global__ __launch_bounds__(kThreads) void direct_sort_kernel(
+    const uint32_t *__restrict__ act_slot, const uint32_t *__restrict__ act_grp, const uint32_t *__restrict__ sa,
+    const uint64_t *__restrict__ words, uint32_t n, uint32_t m, uint32_t h0, uint32_t cap,
+    uint32_t *__restrict__ out_lo, uint32_t *__restrict__ out_vals, uint32_t *__restrict__ lcp_list,
+    uint32_t *__restrict__ large_flag) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x; a < m; a += stride) {
+        const uint32_t g = act_grp[a];
+        const uint32_t slot = act_slot[a];
+        const size_t g0 = a - (slot - g);  // list index of the group's first member
+        const uint32_t i = sa[slot];
+        uint32_t below = 0, ties_before = 0, cnt = 0, lcp_pred = 0;
+        bool large = false;
+        for (size_t b = g0; b < m; ++b) {
+            if (act_grp[b] != g) break;
+            if (++cnt > kSmallGroup) {
+                large = true;
+                break;
+            }
+            if (b == a) continue;
+            const uint32_t j = sa[g + (uint32_t)(b - g0)];  // the group occupies consecutive slots
+            uint32_t l;
+            const int c = suffix_compare<BITS>(words, n, j, i, h0, cap, l);
+            if (c < 0) {
+                ++below;
+                lcp_pred = l > lcp_pred ? l : lcp_pred;
+            } else if (c == 0 && b < a) {
+                ++ties_before;
+            }
+        }
+        large_flag[a] = large ? 1u : 0u;
+        if (!large) {
+            const size_t pos = g0 + below + ties_before;
+            out_lo[pos] = below;
+            out_vals[pos] = i;
+            // LCP to the predecessor in the new order: the closest smaller member shares the
+            // longest prefix; a tied predecessor (only possible if this is not a new head) is
+            // left pending for the doubling rounds
+            lcp_list[pos] = ties_before ? kLcpPending : lcp_pred;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void gather_large_direct_kernel(
+    const uint32_t *__restrict__ large_flag, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ act_slot,
+    const uint32_t *__restrict__ act_grp, const uint32_t *__restrict__ sa, const uint32_t *__restrict__ rank,
+    uint32_t n, uint32_t h, uint32_t m, uint64_t *__restrict__ lkeys, uint32_t *__restrict__ lvals,
+    uint32_t *__restrict__ lidx) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x; a < m; a += stride)
+        if (large_flag[a]) {
+            const uint32_t k = idx[a];
+            const uint32_t i = sa[act_slot[a]];
+            const uint32_t lo = (n - i > h) ? rank[i + h] : 0u;
+            lkeys[k] = ((uint64_t)act_grp[a] << 32) | lo;
+            lvals[k] = i;
+            lidx[k] = (uint32_t)a;
+        }
+}
+
 __global__ __launch_bounds__(kThreads) void gather_large_kernel(const uint32_t *__restrict__ large_flag,
                                                                 const uint32_t *__restrict__ idx,
                                                                 const uint32_t *__restrict__ act_grp,
@@ -317,12 +387,14 @@ __global__ __launch_bounds__(kThreads) void scatter_large_kernel(const uint64_t 
                                                                  const uint32_t *__restrict__ lvals,
                                                                  const uint32_t *__restrict__ lidx, uint32_t count,
                                                                  uint32_t *__restrict__ out_lo,
-                                                                 uint32_t *__restrict__ out_vals) {
+                                                                 uint32_t *__restrict__ out_vals,
+                                                                 uint32_t *__restrict__ lcp_list, uint32_t lcp_code) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < count; k += stride) {
         const uint32_t a = lidx[k];
         out_lo[a] = (uint32_t)lkeys[k];
         out_vals[a] = lvals[k];
+        if (lcp_list) lcp_list[a] = lcp_code;
     }
 }
 
@@ -344,7 +416,7 @@ uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *grp, const 
                  const uint32_t *act_slot, uint32_t m, uint32_t n, uint32_t *sa, uint32_t *rank, uint32_t *new_slot,
                  uint32_t *new_grp, uint32_t *tmp_a, uint32_t *tmp_b, uint32_t *tmp_c, uint32_t *scratch_idx,
                  uint32_t *scratch_val, uint32_t *rank_val, uint32_t *d_total, uint32_t *lcp = nullptr,
-                 int sym_bits = 0, int tag_bits = 0, int bits = 0) {
+                 int sym_bits = 0, int tag_bits = 0, int bits = 0, const uint32_t *lcp_list = nullptr) {
     hipStream_t s = ctx.stream;
     {
         ProfScope ps(ctx.profiler(), "sa_mark_heads", s);
@@ -359,7 +431,7 @@ uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *grp, const 
         ProfScope ps(ctx.profiler(), "sa_commit", s);
         commit_kernel<kRound0><<<grid_for(m, kThreads), kThreads, 0, s>>>(keys, grp, lo, vals, act_slot, tmp_a, m,
                                                                           sa, rank_val, tmp_b, lcp, sym_bits,
-                                                                          tag_bits, bits);
+                                                                          tag_bits, bits, lcp_list);
         KERNEL_CHECK();
     }
     {
@@ -500,6 +572,57 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
 
     int rounds = 0, a_cur = 0;
     uint64_t h = (uint64_t)k_syms;
+
+    // ---- direct round: small groups are finished by comparing packed suffixes ---------------
+    if (m > 0 && h < n) {
+        const uint32_t *slot = act_slot[a_cur], *grp = act_grp[a_cur];
+        uint32_t *lcp_list = arena.alloc<uint32_t>(m);
+        const uint32_t cap = (uint32_t)k_syms + 64u * (64u / (uint32_t)text.bits);  // 64 words deep
+        {
+            ProfScope ps(ctx.profiler(), "sa_direct_sort", s);
+            const unsigned g = grid_for(m, kThreads, 256u * 32u);
+            switch (text.bits) {
+            case 2:
+                direct_sort_kernel<2><<<g, kThreads, 0, s>>>(slot, grp, sa, text.words, n, m, (uint32_t)h, cap, out_lo,
+                                                             out_vals, lcp_list, tmp_a);
+                break;
+            case 4:
+                direct_sort_kernel<4><<<g, kThreads, 0, s>>>(slot, grp, sa, text.words, n, m, (uint32_t)h, cap, out_lo,
+                                                             out_vals, lcp_list, tmp_a);
+                break;
+            default:
+                direct_sort_kernel<8><<<g, kThreads, 0, s>>>(slot, grp, sa, text.words, n, m, (uint32_t)h, cap, out_lo,
+                                                             out_vals, lcp_list, tmp_a);
+                break;
+            }
+            KERNEL_CHECK();
+            scan_exclusive_add_u32(tmp_a, tmp_b, m, d_total, arena, s);
+        }
+        uint32_t n_large = 0;
+        ctx.read_back(d_total, &n_large, 1);
+        if (n_large > 0) {  // groups larger than kSmallGroup take a doubling step instead
+            ProfScope ps(ctx.profiler(), "sa_sort_large", s);
+            const size_t lmark = arena.mark();
+            uint64_t *lk[2] = {keys[1], arena.alloc<uint64_t>(n_large)};
+            uint32_t *lv[2] = {arena.alloc<uint32_t>(n_large), arena.alloc<uint32_t>(n_large)};
+            uint32_t *lidx = tmp_c;
+            gather_large_direct_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(tmp_a, tmp_b, slot, grp, sa, rank, n,
+                                                                                  (uint32_t)h, m, lk[0], lv[0], lidx);
+            KERNEL_CHECK();
+            const int c = radix_sort_pairs(lk, lv, n_large, shifts, npasses, arena, s, ctx.profiler());
+            scatter_large_kernel<<<grid_for(n_large, kThreads), kThreads, 0, s>>>(lk[c], lv[c], lidx, n_large, out_lo,
+                                                                                  out_vals, lcp_list, kLcpPending - 1u);
+            KERNEL_CHECK();
+            arena.rewind(lmark);
+        }
+        m = regroup<false>(ctx, nullptr, grp, out_lo, out_vals, slot, m, n, sa, rank, act_slot[a_cur ^ 1],
+                           act_grp[a_cur ^ 1], tmp_a, tmp_b, tmp_c, scratch_idx, scratch_val, rank_val, d_total, lcp,
+                           0, 0, 0, lcp_list);
+        a_cur ^= 1;
+        h *= 2;
+        ++rounds;
+    }
+
     while (m > 0) {
         if (h >= n || rounds > 40) throw HipError("suffix array: prefix doubling failed to converge");
         const uint32_t *slot = act_slot[a_cur], *grp = act_grp[a_cur];
@@ -528,7 +651,7 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
             KERNEL_CHECK();
             const int c = radix_sort_pairs(lk, lv, n_large, shifts, npasses, arena, s, ctx.profiler());
             scatter_large_kernel<<<grid_for(n_large, kThreads), kThreads, 0, s>>>(lk[c], lv[c], lidx, n_large,
-                                                                                  out_lo, out_vals);
+                                                                                  out_lo, out_vals, nullptr, 0u);
             KERNEL_CHECK();
             arena.rewind(lmark);
         }

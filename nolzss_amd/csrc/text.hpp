@@ -54,4 +54,37 @@ __device__ __forceinline__ uint32_t suffix_lcp(const uint64_t *__restrict__ w, u
     return h < limit ? h : limit;
 }
 
+// Three-way comparison of suffixes a and b that are known to agree on their first h0 symbols,
+// looking at most `cap` symbols deep.  Returns -1 / +1 if suffix a is smaller / greater, 0 if
+// the first `cap` symbols are equal (undecided); lcp receives the common prefix length
+// (>= cap when undecided).  A suffix that ends first is the smaller one, as with the
+// reference's appended terminator.
+template <int BITS>
+__device__ __forceinline__ int suffix_compare(const uint64_t *__restrict__ w, uint32_t n, uint32_t a, uint32_t b,
+                                              uint32_t h0, uint32_t cap, uint32_t &lcp) {
+    constexpr uint32_t kPerWord = 64 / BITS;
+    const uint32_t limit = n - (a > b ? a : b);  // length of the shorter suffix
+    const uint32_t stop = limit < cap ? limit : cap;
+    uint32_t h = h0;
+    while (h < stop) {
+        const uint64_t x = sym_word<BITS>(w, (uint64_t)a + h);
+        const uint64_t y = sym_word<BITS>(w, (uint64_t)b + h);
+        if (x != y) {
+            const uint32_t d = h + (uint32_t)__clzll((long long)(x ^ y)) / BITS;
+            if (d < stop) {
+                lcp = d;
+                return x < y ? -1 : 1;
+            }
+            break;  // first difference lies past the shorter suffix or past the cap
+        }
+        h += kPerWord;
+    }
+    if (limit <= cap) {  // the shorter suffix is a prefix of the other one
+        lcp = limit;
+        return a > b ? -1 : 1;
+    }
+    lcp = cap;
+    return 0;
+}
+
 }  // namespace nolzss
