@@ -15,6 +15,8 @@
 #include "radix_sort.hpp"
 #include "scan.hpp"
 
+#include <cstdlib>
+
 namespace nolzss {
 
 void Context::read_back(const uint32_t *d_src, uint32_t *dst, int count) {
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(kThreads) void round_keys_kernel(const uint32_t *__
 // list and (for real sequence data) almost all tiny, so each element finds its place by
 // counting the smaller members of its own group -- one pass, no radix passes.  Members of
 // groups larger than kSmallGroup are flagged for the radix fallback instead.
-constexpr uint32_t kSmallGroup = 32;
+constexpr uint32_t kSmallGroup = 64;
 
 __global__ __launch_bounds__(kThreads) void small_sort_kernel(const uint32_t *__restrict__ act_slot,
                                                               const uint32_t *__restrict__ act_grp,
@@ -295,54 +297,173 @@ __global__ __launch_bounds__(kThreads) void small_sort_kernel(const uint32_t *__
     }
 }
 
-// First round after the key sort: members of a small group are ordered by comparing their
-// suffixes DIRECTLY in the packed text (they agree on the first h0 symbols; at most `cap` symbols
-// are inspected).  For sequence data nearly every group is a pair or a triple whose members
-// differ within a few hundred symbols, so this one pass finishes them -- order, new group
-// boundaries and the LCP to the predecessor -- where prefix doubling would need log2(LCP / h0)
-// gather + sort + scatter rounds.  Members that still agree after `cap` symbols stay grouped
-// (out_lo = number of strictly smaller members is equal for them) and go on to the doubling
-// rounds, as do groups larger than kSmallGroup (flagged for the radix path).
-template <int BITS>
-__global__ __launch_bounds__(kThreads) void direct_sort_kernel(
-    const uint32_t *__restrict__ act_slot, const uint32_t *__restrict__ act_grp, const uint32_t *__restrict__ sa,
-    const uint64_t *__restrict__ words, uint32_t n, uint32_t m, uint32_t h0, uint32_t cap,
-    uint32_t *__restrict__ out_lo, uint32_t *__restrict__ out_vals, uint32_t *__restrict__ lcp_list,
-    uint32_t *__restrict__ large_flag) {
+// First round after the key sort: members of a group are ordered by comparing their suffixes
+// DIRECTLY in the packed text (they agree on the first h0 symbols; at most `cap` symbols are
+// inspected).  For sequence data nearly every group is small and its members differ within a few
+// hundred symbols, so this one round finishes them -- order, new group boundaries and the LCP to
+// the predecessor -- where prefix doubling would need log2(LCP / h0) gather + sort + scatter
+// rounds.  Members that still agree after `cap` symbols stay grouped (out_lo = number of strictly
+// smaller members is equal for them) and go on to the doubling rounds; groups larger than
+// kSmallGroup are flagged for the radix path (one ordinary doubling step).
+
+// gsize[first list index of a group] = number of members
+__global__ __launch_bounds__(kThreads) void group_size_kernel(const uint32_t *__restrict__ act_slot,
+                                                              const uint32_t *__restrict__ act_grp, uint32_t m,
+                                                              uint32_t *__restrict__ gsize) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x; a < m; a += stride) {
         const uint32_t g = act_grp[a];
-        const uint32_t slot = act_slot[a];
-        const size_t g0 = a - (slot - g);  // list index of the group's first member
-        const uint32_t i = sa[slot];
-        uint32_t below = 0, ties_before = 0, cnt = 0, lcp_pred = 0;
-        bool large = false;
-        for (size_t b = g0; b < m; ++b) {
-            if (act_grp[b] != g) break;
-            if (++cnt > kSmallGroup) {
-                large = true;
-                break;
-            }
-            if (b == a) continue;
-            const uint32_t j = sa[g + (uint32_t)(b - g0)];  // the group occupies consecutive slots
-            uint32_t l;
-            const int c = suffix_compare<BITS>(words, n, j, i, h0, cap, l);
-            if (c < 0) {
-                ++below;
-                lcp_pred = l > lcp_pred ? l : lcp_pred;
-            } else if (c == 0 && b < a) {
-                ++ties_before;
+        if (a + 1 == m || act_grp[a + 1] != g) {  // last member
+            const size_t g0 = a - (act_slot[a] - g);
+            gsize[g0] = (uint32_t)(a - g0 + 1);
+        }
+    }
+}
+
+// One workgroup refines all groups that START inside its kRefineTile list positions; every member
+// is a thread, all state lives in LDS.  Per round each still-tied member fetches the next 128 bits
+// of its own suffix (one random line per member per round -- never a pairwise re-read), the
+// members of a group compare their windows through LDS, tie classes split, and the loop ends when
+// the workgroup has no tie left or the cap is reached.  cls = number of strictly smaller members.
+constexpr int kRefineTile = 1024;
+constexpr int kRefineSpan = kRefineTile + (int)kSmallGroup;
+
+template <int BITS>
+__global__ __launch_bounds__(kThreads) void group_refine_kernel(
+    const uint32_t *__restrict__ act_slot, const uint32_t *__restrict__ act_grp, const uint32_t *__restrict__ gsize,
+    const uint32_t *__restrict__ sa, const uint64_t *__restrict__ words, uint32_t n, uint32_t m, uint32_t h0,
+    uint32_t cap, uint32_t *__restrict__ out_lo, uint32_t *__restrict__ out_vals, uint32_t *__restrict__ lcp_list,
+    uint32_t *__restrict__ large_flag) {
+    constexpr uint32_t kPerWord = 64 / BITS;
+    constexpr int kPerThread = (kRefineSpan + kThreads - 1) / kThreads;
+    __shared__ uint64_t s_w0[kRefineSpan], s_w1[kRefineSpan];
+    __shared__ uint32_t s_pos[kRefineSpan];   // suffix start
+    __shared__ uint16_t s_cls[kRefineSpan];   // strictly smaller members so far
+    __shared__ uint8_t s_act[kRefineSpan];    // still tied with somebody
+    const size_t a0 = (size_t)blockIdx.x * kRefineTile;
+    const size_t a1 = (a0 + kRefineTile < m) ? a0 + kRefineTile : m;
+
+    uint32_t my_pos[kPerThread], my_lcp[kPerThread];
+    uint16_t my_gl[kPerThread];  // local index of the group's first member
+    uint8_t my_gs[kPerThread];   // group size (0: not handled here)
+#pragma unroll
+    for (int j = 0; j < kPerThread; ++j) {
+        const int t = j * kThreads + threadIdx.x;
+        const size_t a = a0 + t;
+        my_gs[j] = 0;
+        my_gl[j] = 0;
+        my_pos[j] = 0;
+        my_lcp[j] = 0;
+        bool mine = false;
+        if (t < kRefineSpan && a < m) {
+            const uint32_t g = act_grp[a];
+            const uint32_t slot = act_slot[a];
+            const size_t g0 = a - (slot - g);
+            const uint32_t sz = gsize[g0];
+            if (a < a1) large_flag[a] = sz > kSmallGroup ? 1u : 0u;
+            mine = g0 >= a0 && g0 < a1 && sz <= kSmallGroup;
+            if (mine) {
+                my_gs[j] = (uint8_t)sz;
+                my_gl[j] = (uint16_t)(g0 - a0);
+                my_pos[j] = sa[slot];
             }
         }
-        large_flag[a] = large ? 1u : 0u;
-        if (!large) {
-            const size_t pos = g0 + below + ties_before;
-            out_lo[pos] = below;
-            out_vals[pos] = i;
+        if (t < kRefineSpan) {
+            s_pos[t] = my_pos[j];
+            s_cls[t] = 0;
+            s_act[t] = mine ? 1 : 0;
+        }
+    }
+    __syncthreads();
+
+    for (uint32_t h = h0; h < cap; h += 2 * kPerWord) {
+        int any = 0;
+#pragma unroll
+        for (int j = 0; j < kPerThread; ++j) {
+            const int t = j * kThreads + threadIdx.x;
+            if (t < kRefineSpan && s_act[t]) {
+                s_w0[t] = sym_word<BITS>(words, (uint64_t)my_pos[j] + h);
+                s_w1[t] = sym_word<BITS>(words, (uint64_t)my_pos[j] + h + kPerWord);
+                any = 1;
+            }
+        }
+        if (!__syncthreads_or(any)) break;
+        uint16_t add[kPerThread];
+        uint8_t still[kPerThread];
+#pragma unroll
+        for (int j = 0; j < kPerThread; ++j) {
+            const int t = j * kThreads + threadIdx.x;
+            add[j] = 0;
+            still[j] = 0;
+            if (t < kRefineSpan && s_act[t]) {
+                const uint64_t x0 = s_w0[t], x1 = s_w1[t];
+                const uint32_t cls = s_cls[t];
+                const uint32_t rem_t = n - my_pos[j] - h;  // symbols left in my suffix (>= 1)
+                uint32_t best = 0;
+                for (int e = 0; e < my_gs[j]; ++e) {
+                    const int u = my_gl[j] + e;
+                    if (u == t || !s_act[u] || s_cls[u] != cls) continue;
+                    const uint64_t y0 = s_w0[u], y1 = s_w1[u];
+                    const uint32_t rem_u = n - s_pos[u] - h;
+                    uint32_t valid = rem_t < rem_u ? rem_t : rem_u;
+                    valid = valid < 2 * kPerWord ? valid : 2 * kPerWord;
+                    uint32_t d;
+                    bool u_smaller;
+                    if (x0 != y0) {
+                        d = (uint32_t)__clzll((long long)(x0 ^ y0)) / BITS;
+                        u_smaller = y0 < x0;
+                    } else if (x1 != y1) {
+                        d = kPerWord + (uint32_t)__clzll((long long)(x1 ^ y1)) / BITS;
+                        u_smaller = y1 < x1;
+                    } else {
+                        d = 2 * kPerWord;
+                        u_smaller = false;
+                    }
+                    if (d >= valid) {
+                        if (valid == 2 * kPerWord) {  // equal window, both suffixes go on: tie
+                            still[j] = 1;
+                            continue;
+                        }
+                        d = valid;  // the shorter suffix is a prefix of the other and sorts first
+                        u_smaller = rem_u < rem_t;
+                    }
+                    if (u_smaller) {
+                        ++add[j];
+                        best = (h + d) > best ? (h + d) : best;
+                    }
+                }
+                if (add[j]) my_lcp[j] = best;  // deeper rounds only ever find longer prefixes
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kPerThread; ++j) {
+            const int t = j * kThreads + threadIdx.x;
+            if (t < kRefineSpan && s_act[t]) {
+                s_cls[t] = (uint16_t)(s_cls[t] + add[j]);
+                s_act[t] = still[j];
+            }
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int j = 0; j < kPerThread; ++j) {
+        const int t = j * kThreads + threadIdx.x;
+        if (t < kRefineSpan && my_gs[j]) {
+            uint32_t ties_before = 0;
+            if (s_act[t]) {  // still tied at the cap: keep list order inside the class
+                for (int e = 0; e < my_gs[j]; ++e) {
+                    const int u = my_gl[j] + e;
+                    if (u < t && s_act[u] && s_cls[u] == s_cls[t]) ++ties_before;
+                }
+            }
+            const size_t pos = a0 + my_gl[j] + s_cls[t] + ties_before;
+            out_lo[pos] = s_cls[t];
+            out_vals[pos] = my_pos[j];
             // LCP to the predecessor in the new order: the closest smaller member shares the
-            // longest prefix; a tied predecessor (only possible if this is not a new head) is
-            // left pending for the doubling rounds
-            lcp_list[pos] = ties_before ? kLcpPending : lcp_pred;
+            // longest prefix; a tied predecessor (then this is not a new head) stays pending
+            lcp_list[pos] = ties_before ? kLcpPending : my_lcp[j];
         }
     }
 }
@@ -475,7 +596,7 @@ PackedText pack_text(Context &ctx, const uint8_t *d_text, size_t n) {
     for (int k = 0; k < 8; ++k) sigma += __builtin_popcount(bitsw[k]);
     t.sigma = sigma;
     t.bits = sigma <= 4 ? 2 : (sigma <= 16 ? 4 : 8);
-    const size_t nwords = div_up(n * (size_t)t.bits, 64) + 2;
+    const size_t nwords = div_up(n * (size_t)t.bits, 64) + 4;  // zero pad: windows read past the end
     uint64_t *words = ctx.arena.alloc<uint64_t>(nwords);
     {
         ProfScope ps(ctx.profiler(), "text_pack", s);
@@ -531,7 +652,7 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     uint32_t *rank_val = arena.alloc<uint32_t>(n);
     uint32_t *scratch_idx = arena.alloc<uint32_t>(n);
     uint32_t *scratch_val = arena.alloc<uint32_t>(n);
-    uint32_t *d_total = arena.alloc<uint32_t>(1);
+    uint32_t *d_total = arena.alloc<uint32_t>(2);
     uint32_t *rank = isa;
 
     // ---- round 0: order by the first K symbols -------------------------------------------
@@ -577,29 +698,37 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     if (m > 0 && h < n) {
         const uint32_t *slot = act_slot[a_cur], *grp = act_grp[a_cur];
         uint32_t *lcp_list = arena.alloc<uint32_t>(m);
-        const uint32_t cap = (uint32_t)k_syms + 64u * (64u / (uint32_t)text.bits);  // 64 words deep
+        static const uint32_t refine_words = [] {
+            const char *e = getenv("NOLZSS_REFINE_WORDS");
+            return e ? (uint32_t)atoi(e) : 64u;
+        }();
+        const uint32_t cap = (uint32_t)k_syms + refine_words * (64u / (uint32_t)text.bits);
+        uint32_t *gsize = arena.alloc<uint32_t>(m);
         {
             ProfScope ps(ctx.profiler(), "sa_direct_sort", s);
-            const unsigned g = grid_for(m, kThreads, 256u * 32u);
+            group_size_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(slot, grp, m, gsize);
+            KERNEL_CHECK();
+            const unsigned g = (unsigned)div_up(m, kRefineTile);
             switch (text.bits) {
             case 2:
-                direct_sort_kernel<2><<<g, kThreads, 0, s>>>(slot, grp, sa, text.words, n, m, (uint32_t)h, cap, out_lo,
-                                                             out_vals, lcp_list, tmp_a);
+                group_refine_kernel<2><<<g, kThreads, 0, s>>>(slot, grp, gsize, sa, text.words, n, m, (uint32_t)h, cap,
+                                                              out_lo, out_vals, lcp_list, tmp_a);
                 break;
             case 4:
-                direct_sort_kernel<4><<<g, kThreads, 0, s>>>(slot, grp, sa, text.words, n, m, (uint32_t)h, cap, out_lo,
-                                                             out_vals, lcp_list, tmp_a);
+                group_refine_kernel<4><<<g, kThreads, 0, s>>>(slot, grp, gsize, sa, text.words, n, m, (uint32_t)h, cap,
+                                                              out_lo, out_vals, lcp_list, tmp_a);
                 break;
             default:
-                direct_sort_kernel<8><<<g, kThreads, 0, s>>>(slot, grp, sa, text.words, n, m, (uint32_t)h, cap, out_lo,
-                                                             out_vals, lcp_list, tmp_a);
+                group_refine_kernel<8><<<g, kThreads, 0, s>>>(slot, grp, gsize, sa, text.words, n, m, (uint32_t)h, cap,
+                                                              out_lo, out_vals, lcp_list, tmp_a);
                 break;
             }
             KERNEL_CHECK();
             scan_exclusive_add_u32(tmp_a, tmp_b, m, d_total, arena, s);
         }
-        uint32_t n_large = 0;
-        ctx.read_back(d_total, &n_large, 1);
+        uint32_t counts2[1] = {0};
+        ctx.read_back(d_total, counts2, 1);
+        const uint32_t n_large = counts2[0];
         if (n_large > 0) {  // groups larger than kSmallGroup take a doubling step instead
             ProfScope ps(ctx.profiler(), "sa_sort_large", s);
             const size_t lmark = arena.mark();

@@ -10,7 +10,7 @@
 namespace nolzss {
 
 struct PackedText {
-    const uint64_t *words = nullptr;  // ceil(n*bits/64) + 2 zero pad words
+    const uint64_t *words = nullptr;  // ceil(n*bits/64) + 4 zero pad words
     uint32_t n = 0;
     int bits = 0;    // 2, 4 or 8
     int sigma = 0;   // distinct byte values present
