@@ -445,20 +445,47 @@ int nolzss_count_factors_multiple_dna_w_rc(const uint8_t *S, size_t S_len, size_
     });
 }
 
+// noLZSS::factorize_dna_w_rc: one sequence; the prepared string is built on the device so that only
+// the n input bytes cross PCIe
 static void dna_w_rc_common(const uint8_t *text, size_t n, int device, nolzss_factor **out, size_t *z) {
     *z = 0;
     if (out) *out = nullptr;
     if (n == 0) return;  // factorizer_core.hpp:143
     if (!text) throw std::invalid_argument("text pointer is null");
-    const char *seqs[1] = {reinterpret_cast<const char *>(text)};
-    const size_t lens[1] = {n};
-    std::vector<uint8_t> S;
-    std::vector<uint64_t> sent;
-    size_t orig = 0;
-    prepare_w_rc(seqs, lens, 1, S, orig, sent);  // factorizer_core.hpp:146
-    if (!rc_guards(S.size(), 0)) return;
+    const size_t m = 2 * n + 2;
+    if (m > kMaxText) throw std::invalid_argument("text too long: the device pipeline uses 32-bit indices");
+    if (!rc_guards(m, 0)) return;
     Session ses(device, nullptr);
-    *z = run_rc_host(ses.ctx(), S.data(), S.size(), 0, out);
+    Context &ctx = ses.ctx();
+    ctx.arena.reserve(arena_bytes_for(m) + m + n);
+    uint8_t *d_T = ctx.arena.alloc<uint8_t>(n);
+    uint8_t *d_S = ctx.arena.alloc<uint8_t>(m);
+    HIP_CHECK(hipMemcpyAsync(d_T, text, n, hipMemcpyHostToDevice, ctx.stream));
+    const uint32_t bad = prepare_single_rc_on_device(ctx, d_T, (uint32_t)n, d_S);
+    if (bad != 0xffffffffu)  // factorizer.cpp:86-95
+        throw std::runtime_error("Invalid nucleotide '" + std::string(1, (char)text[bad]) + "' found in sequence 0");
+    void *d_recs = nullptr;
+    const size_t count = run_rc_pipeline(ctx, d_S, m, 0, out ? &d_recs : nullptr);
+    if (out && count) {
+        nolzss_factor *h = static_cast<nolzss_factor *>(std::malloc(sizeof(nolzss_factor) * count));
+        if (!h) throw std::bad_alloc();
+        hipError_t e = hipMemcpyAsync(h, d_recs, sizeof(nolzss_factor) * count, hipMemcpyDeviceToHost, ctx.stream);
+        if (e != hipSuccess) {
+            std::free(h);
+            HIP_CHECK(e);
+        }
+        *out = h;
+    }
+    hipError_t e = hipStreamSynchronize(ctx.stream);
+    if (e != hipSuccess) {
+        if (out && *out) {
+            std::free(*out);
+            *out = nullptr;
+        }
+        HIP_CHECK(e);
+    }
+    ctx.prof.collect();
+    *z = count;
 }
 
 int nolzss_factorize_dna_w_rc(const uint8_t *text, size_t n, int device, nolzss_factor **out, size_t *z) {

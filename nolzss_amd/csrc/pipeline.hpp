@@ -42,5 +42,8 @@ uint32_t resolve_chain(Context &ctx, uint32_t n, uint32_t start_pos, const uint3
 
 // ---- reverse-complement mode (rc.hip): whole pipeline over the prepared string S -------------
 uint32_t run_rc_pipeline(Context &ctx, const uint8_t *d_S, size_t m, size_t start_pos, void **d_factors_out);
+// d_S (2n + 2 bytes) = prepared string of the single sequence d_T; returns the index of the first
+// invalid nucleotide or 0xffffffff.
+uint32_t prepare_single_rc_on_device(Context &ctx, const uint8_t *d_T, uint32_t n, uint8_t *d_S);
 
 }  // namespace nolzss

@@ -150,7 +150,52 @@ __global__ __launch_bounds__(kThreads) void rc_fallback_kernel(const uint32_t *_
     }
 }
 
+// S = upper(T) s0 revcomp(upper(T)) s1 for ONE sequence, built on the device
+// (prepare_multiple_dna_sequences_w_rc with k = 1, /root/reference/src/cpp/factorizer.cpp:54-172:
+// sentinels 1 and 2, :110-125).  first_bad = smallest index holding a non-ACGT byte (n if none).
+__global__ __launch_bounds__(kThreads) void rc_prepare_kernel(const uint8_t *__restrict__ T, uint32_t n,
+                                                              uint8_t *__restrict__ S,
+                                                              uint32_t *__restrict__ first_bad) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        uint8_t c = T[i];
+        if (c >= 'a' && c <= 'z') c = (uint8_t)(c - 'a' + 'A');
+        uint8_t comp;
+        switch (c) {
+        case 'A': comp = 'T'; break;
+        case 'C': comp = 'G'; break;
+        case 'G': comp = 'C'; break;
+        case 'T': comp = 'A'; break;
+        default:
+            comp = 0;
+            atomicMin(first_bad, (uint32_t)i);
+            break;
+        }
+        S[i] = c;
+        S[2 * (size_t)n - i] = comp;  // position n + 1 + (n - 1 - i)
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        S[n] = 1;
+        S[2 * (size_t)n + 1] = 2;
+    }
+}
+
 }  // namespace
+
+uint32_t prepare_single_rc_on_device(Context &ctx, const uint8_t *d_T, uint32_t n, uint8_t *d_S) {
+    uint32_t *first_bad = ctx.arena.alloc<uint32_t>(1);
+    HIP_CHECK(hipMemsetAsync(first_bad, 0xff, sizeof(uint32_t), ctx.stream));
+    {
+        ProfScope ps(ctx.profiler(), "rc_prepare", ctx.stream);
+        size_t g = div_up(n, kThreads);
+        if (g > 8192) g = 8192;
+        rc_prepare_kernel<<<(unsigned)g, kThreads, 0, ctx.stream>>>(d_T, n, d_S, first_bad);
+        KERNEL_CHECK();
+    }
+    uint32_t bad = 0;
+    ctx.read_back(first_bad, &bad, 1);
+    return bad;  // 0xffffffff when every byte is a nucleotide
+}
 
 uint32_t run_rc_pipeline(Context &ctx, const uint8_t *d_S, size_t m_sz, size_t start_pos, void **d_factors_out) {
     const uint32_t m = (uint32_t)m_sz;
