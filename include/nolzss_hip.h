@@ -97,6 +97,35 @@ int nolzss_factorize_dna_w_rc(const uint8_t *text, size_t n, int device, nolzss_
 /* reference: noLZSS::count_factors_dna_w_rc, factorizer.cpp:559-561; bindings.cpp:276-295 */
 int nolzss_count_factors_dna_w_rc(const uint8_t *text, size_t n, int device, size_t *z);
 
+/* ---- reference + target factorization (the chain simply starts at start_pos) */
+/* reference: noLZSS::factorize_w_reference, factorizer.cpp:940-955; bindings.cpp:868-880.
+ * combined = reference 0x01 target, factorized from |reference| + 1; positions are absolute. */
+int nolzss_factorize_w_reference(const uint8_t *reference_seq, size_t reference_len,
+                                 const uint8_t *target_seq, size_t target_len, int device,
+                                 nolzss_factor **out, size_t *z);
+/* reference: noLZSS::factorize_dna_w_reference_seq, factorizer.cpp:825-842; bindings.cpp:800-808.
+ * prepare({reference, target}) with reverse complements, factorized from |reference| + 1. */
+int nolzss_factorize_dna_w_reference_seq(const char *reference_seq, size_t reference_len,
+                                         const char *target_seq, size_t target_len, int device,
+                                         nolzss_factor **out, size_t *z);
+
+/* ---- v2 binary factor files -------------------------------------------- */
+/* File = z 24-byte records, optional metadata, 48-byte footer "noLZSSv2", num_factors,
+ * num_sequences, num_sentinels, footer_size, total_length (factorizer.hpp:64-77).
+ * reference: write_factors_binary_file, factorizer.cpp:424-459 (input FILE -> output file) */
+int nolzss_write_factors_binary_file(const char *in_path, const char *out_path, int device, size_t *z);
+/* reference: write_factors_binary_file_dna_w_rc, factorizer.cpp:597-635 */
+int nolzss_write_factors_binary_file_dna_w_rc(const char *in_path, const char *out_path, int device,
+                                              size_t *z);
+/* reference: factorize_w_reference_file, factorizer.cpp:980-1021 */
+int nolzss_factorize_w_reference_file(const uint8_t *reference_seq, size_t reference_len,
+                                      const uint8_t *target_seq, size_t target_len,
+                                      const char *out_path, int device, size_t *z);
+/* reference: factorize_dna_w_reference_seq_file, factorizer.cpp:851-883 */
+int nolzss_factorize_dna_w_reference_seq_file(const char *reference_seq, size_t reference_len,
+                                              const char *target_seq, size_t target_len,
+                                              const char *out_path, int device, size_t *z);
+
 /* ---- per-sequence batch (the FASTA shard unit) ------------------------------------------- */
 /* reference: the per-sequence factorize() loop of genomics.read_nucleotide_fasta,
  *            src/noLZSS/genomics/fasta.py:110-122 (C++ analogue:

@@ -6,10 +6,14 @@ Drop-in for the factorize path of OmerKerner/noLZSS: the same `factorize`, `fact
 by hand-written HIP kernels for gfx950 behind a C ABI (include/nolzss_hip.h).
 """
 from ._noLZSS import __version__
-from .core import factorize, factorize_file, count_factors, count_factors_file
-from .utils import NoLZSSError, InvalidInputError, validate_input
+from .core import (factorize, factorize_file, count_factors, count_factors_file, write_factors_binary_file,
+                   factorize_w_reference, factorize_w_reference_file)
+from .utils import (NoLZSSError, InvalidInputError, validate_input, read_factors_binary_file,
+                    read_binary_file_metadata, read_factors_binary_file_with_metadata)
 
 __all__ = [
-    "factorize", "factorize_file", "count_factors", "count_factors_file",
-    "NoLZSSError", "InvalidInputError", "validate_input", "__version__",
+    "factorize", "factorize_file", "count_factors", "count_factors_file", "write_factors_binary_file",
+    "factorize_w_reference", "factorize_w_reference_file",
+    "NoLZSSError", "InvalidInputError", "validate_input", "read_factors_binary_file",
+    "read_binary_file_metadata", "read_factors_binary_file_with_metadata", "__version__",
 ]

@@ -43,6 +43,13 @@ def _load():
     lib.nolzss_count_factors_multiple_dna_w_rc.argtypes = [vp, sz, sz, C.c_int, szp]
     lib.nolzss_factorize_dna_w_rc.argtypes = [vp, sz, C.c_int, vpp, szp]
     lib.nolzss_count_factors_dna_w_rc.argtypes = [vp, sz, C.c_int, szp]
+    lib.nolzss_factorize_w_reference.argtypes = [vp, sz, vp, sz, C.c_int, vpp, szp]
+    lib.nolzss_factorize_dna_w_reference_seq.argtypes = [C.c_char_p, sz, C.c_char_p, sz, C.c_int, vpp, szp]
+    lib.nolzss_write_factors_binary_file.argtypes = [C.c_char_p, C.c_char_p, C.c_int, szp]
+    lib.nolzss_write_factors_binary_file_dna_w_rc.argtypes = [C.c_char_p, C.c_char_p, C.c_int, szp]
+    lib.nolzss_factorize_w_reference_file.argtypes = [vp, sz, vp, sz, C.c_char_p, C.c_int, szp]
+    lib.nolzss_factorize_dna_w_reference_seq_file.argtypes = [C.c_char_p, sz, C.c_char_p, sz, C.c_char_p,
+                                                              C.c_int, szp]
     lib.nolzss_factorize_batch.argtypes = [
         C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), sz, C.POINTER(C.c_int), sz,
         C.POINTER(C.POINTER(C.c_void_p)), C.POINTER(C.POINTER(C.c_size_t))]
@@ -65,6 +72,9 @@ EXPORTED_SYMBOLS = [
     "nolzss_factorize_device", "nolzss_prepare_multiple_dna_w_rc",
     "nolzss_factorize_multiple_dna_w_rc", "nolzss_count_factors_multiple_dna_w_rc",
     "nolzss_factorize_dna_w_rc", "nolzss_count_factors_dna_w_rc", "nolzss_factorize_batch",
+    "nolzss_factorize_w_reference", "nolzss_factorize_dna_w_reference_seq",
+    "nolzss_write_factors_binary_file", "nolzss_write_factors_binary_file_dna_w_rc",
+    "nolzss_factorize_w_reference_file", "nolzss_factorize_dna_w_reference_seq_file",
     "nolzss_free_batch", "nolzss_profile_enable", "nolzss_profile_reset", "nolzss_profile_report",
     "nolzss_debug_arrays", "nolzss_debug_sort_pairs", "nolzss_debug_scan",
 ]

@@ -225,6 +225,67 @@ def prepare_multiple_dna_sequences_w_rc(sequences):
     return data.decode("utf-8"), orig, sent
 
 
+# ---- reference + target factorization and v2 binary files -----------
+def _str_arg(x, name):
+    """pybind11 std::string argument: str (UTF-8 encoded) or bytes."""
+    if isinstance(x, str):
+        return x.encode("utf-8")
+    if isinstance(x, (bytes, bytearray)):
+        return bytes(x)
+    raise TypeError(f"{name} must be str or bytes, not {type(x).__name__}")
+
+
+def factorize_w_reference(reference_seq, target_seq):
+    """reference: bindings.cpp:868-880 -> list[(start, length, ref)], absolute positions in
+    reference + '\\x01' + target."""
+    r, t = _str_arg(reference_seq, "reference_seq"), _str_arg(target_seq, "target_seq")
+    out, z = C.c_void_p(), C.c_size_t()
+    check(lib.nolzss_factorize_w_reference(r, len(r), t, len(t), _default_device, C.byref(out), C.byref(z)))
+    return _tuples3(_take(out, z.value))
+
+
+def factorize_w_reference_file(reference_seq, target_seq, out_path) -> int:
+    """reference: bindings.cpp:907-915"""
+    r, t = _str_arg(reference_seq, "reference_seq"), _str_arg(target_seq, "target_seq")
+    z = C.c_size_t()
+    check(lib.nolzss_factorize_w_reference_file(r, len(r), t, len(t), os.fsencode(out_path), _default_device,
+                                                C.byref(z)))
+    return z.value
+
+
+def factorize_dna_w_reference_seq(reference_seq, target_seq):
+    """reference: bindings.cpp:800-808 -> list[(start, length, ref & ~RC_MASK, is_rc)]"""
+    r, t = _str_arg(reference_seq, "reference_seq"), _str_arg(target_seq, "target_seq")
+    out, z = C.c_void_p(), C.c_size_t()
+    check(lib.nolzss_factorize_dna_w_reference_seq(r, len(r), t, len(t), _default_device, C.byref(out), C.byref(z)))
+    return _tuples4(_take(out, z.value))
+
+
+def factorize_dna_w_reference_seq_file(reference_seq, target_seq, out_path) -> int:
+    """reference: bindings.cpp:837-845"""
+    r, t = _str_arg(reference_seq, "reference_seq"), _str_arg(target_seq, "target_seq")
+    z = C.c_size_t()
+    check(lib.nolzss_factorize_dna_w_reference_seq_file(r, len(r), t, len(t), os.fsencode(out_path),
+                                                        _default_device, C.byref(z)))
+    return z.value
+
+
+def write_factors_binary_file(in_path, out_path) -> int:
+    """reference: bindings.cpp:180-187 (input is a FILE path; v2 footer at the end)"""
+    z = C.c_size_t()
+    check(lib.nolzss_write_factors_binary_file(_str_arg(in_path, "in_path"), _str_arg(out_path, "out_path"),
+                                               _default_device, C.byref(z)))
+    return z.value
+
+
+def write_factors_binary_file_dna_w_rc(in_path, out_path) -> int:
+    """reference: bindings.cpp (write_factors_binary_file_dna_w_rc), factorizer.cpp:597-635"""
+    z = C.c_size_t()
+    check(lib.nolzss_write_factors_binary_file_dna_w_rc(_str_arg(in_path, "in_path"), _str_arg(out_path, "out_path"),
+                                                        _default_device, C.byref(z)))
+    return z.value
+
+
 # ---- measurement hooks ----------------------------------------------------------------------
 def profile_enable(on: bool = True) -> None:
     check(lib.nolzss_profile_enable(_default_device, 1 if on else 0))
@@ -289,14 +350,12 @@ def _not_on_path(name):
 
 
 for _n in [
-    "write_factors_binary_file", "factorize_file_dna_w_rc", "count_factors_file_dna_w_rc",
-    "write_factors_binary_file_dna_w_rc", "factorize_file_multiple_dna_w_rc",
+    "factorize_file_dna_w_rc", "count_factors_file_dna_w_rc", "factorize_file_multiple_dna_w_rc",
     "count_factors_file_multiple_dna_w_rc", "write_factors_binary_file_multiple_dna_w_rc",
     "factorize_fasta_multiple_dna_w_rc", "factorize_dna_rc_w_ref_fasta_files",
     "factorize_fasta_multiple_dna_no_rc", "write_factors_binary_file_fasta_multiple_dna_w_rc",
     "write_factors_binary_file_fasta_multiple_dna_no_rc", "prepare_multiple_dna_sequences_no_rc",
-    "factorize_dna_w_reference_seq", "factorize_dna_w_reference_seq_file", "factorize_w_reference",
-    "factorize_w_reference_file", "write_factors_dna_w_reference_fasta_files_to_binary",
+    "write_factors_dna_w_reference_fasta_files_to_binary",
     "parallel_factorize_to_file", "parallel_factorize_file_to_file",
     "parallel_factorize_dna_w_rc_to_file", "parallel_factorize_file_dna_w_rc_to_file",
     "parallel_write_factors_binary_file_fasta_multiple_dna_w_rc",

@@ -502,6 +502,156 @@ int nolzss_count_factors_dna_w_rc(const uint8_t *text, size_t n, int device, siz
     });
 }
 
+// ---- reference + target factorization and v2 binary files ("next" rows) ---------
+namespace nolzss {
+namespace {
+
+#pragma pack(push, 1)
+struct FileFooter {  // FactorFileFooter, /root/reference/src/cpp/factorizer.hpp:64-77
+    char magic[8];
+    uint64_t num_factors, num_sequences, num_sentinels, footer_size, total_length;
+};
+#pragma pack(pop)
+static_assert(sizeof(FileFooter) == 48, "v2 footer is 48 bytes");
+
+// records, then `extra` metadata bytes, then the footer (footer_size counts extra + 48)
+void write_v2_file(const char *out_path, const nolzss_factor *f, size_t z, uint64_t num_sequences,
+                   uint64_t num_sentinels, uint64_t total_length, const std::string &extra) {
+    if (!out_path) throw std::invalid_argument("output path is null");
+    std::ofstream os(out_path, std::ios::binary);
+    if (!os) throw std::runtime_error(std::string("Cannot create output file: ") + out_path);
+    if (z) os.write(reinterpret_cast<const char *>(f), (std::streamsize)(sizeof(nolzss_factor) * z));
+    if (!extra.empty()) os.write(extra.data(), (std::streamsize)extra.size());
+    FileFooter ft;
+    std::memcpy(ft.magic, "noLZSSv2", 8);
+    ft.num_factors = z;
+    ft.num_sequences = num_sequences;
+    ft.num_sentinels = num_sentinels;
+    ft.footer_size = sizeof(FileFooter) + extra.size();
+    ft.total_length = total_length;
+    os.write(reinterpret_cast<const char *>(&ft), sizeof ft);
+    if (!os) throw std::runtime_error(std::string("Error writing output file: ") + out_path);
+}
+
+size_t w_reference(const uint8_t *ref, size_t ref_len, const uint8_t *tgt, size_t tgt_len, int device,
+                   nolzss_factor **out) {
+    if ((ref_len && !ref) || (tgt_len && !tgt)) throw std::invalid_argument("sequence pointer is null");
+    std::vector<uint8_t> combined;  // factorizer.cpp:942: reference + '\x01' + target
+    combined.reserve(ref_len + tgt_len + 1);
+    combined.insert(combined.end(), ref, ref + ref_len);
+    combined.push_back(1);
+    combined.insert(combined.end(), tgt, tgt + tgt_len);
+    check_text_args(combined.data(), combined.size(), ref_len + 1);
+    Session ses(device, nullptr);
+    return run_plain_host(ses.ctx(), combined.data(), combined.size(), ref_len + 1, out, nullptr);
+}
+
+size_t dna_w_reference(const char *ref, size_t ref_len, const char *tgt, size_t tgt_len, int device,
+                       nolzss_factor **out) {
+    if ((ref_len && !ref) || (tgt_len && !tgt)) throw std::invalid_argument("sequence pointer is null");
+    const char *seqs[2] = {ref, tgt};
+    const size_t lens[2] = {ref_len, tgt_len};
+    std::vector<uint8_t> S;
+    std::vector<uint64_t> sent;
+    size_t orig = 0;
+    prepare_w_rc(seqs, lens, 2, S, orig, sent);  // factorizer.cpp:827-828
+    const size_t start = ref_len + 1;            // :833
+    if (!rc_guards(S.size(), start)) return 0;
+    Session ses(device, nullptr);
+    return run_rc_host(ses.ctx(), S.data(), S.size(), start, out);
+}
+
+}  // namespace
+}  // namespace nolzss
+
+int nolzss_factorize_w_reference(const uint8_t *reference_seq, size_t reference_len, const uint8_t *target_seq,
+                                 size_t target_len, int device, nolzss_factor **out, size_t *z) {
+    return guarded([&] {
+        if (!out || !z) throw std::invalid_argument("output pointer is null");
+        *out = nullptr;
+        *z = w_reference(reference_seq, reference_len, target_seq, target_len, device, out);
+    });
+}
+
+int nolzss_factorize_dna_w_reference_seq(const char *reference_seq, size_t reference_len, const char *target_seq,
+                                         size_t target_len, int device, nolzss_factor **out, size_t *z) {
+    return guarded([&] {
+        if (!out || !z) throw std::invalid_argument("output pointer is null");
+        *out = nullptr;
+        *z = dna_w_reference(reference_seq, reference_len, target_seq, target_len, device, out);
+    });
+}
+
+int nolzss_write_factors_binary_file(const char *in_path, const char *out_path, int device, size_t *z) {
+    return guarded([&] {
+        if (!z) throw std::invalid_argument("output pointer is null");
+        *z = 0;
+        std::vector<uint8_t> data = read_file(in_path);
+        check_text_args(data.data(), data.size(), 0);
+        nolzss_factor *f = nullptr;
+        size_t count;
+        {
+            Session ses(device, nullptr);
+            count = run_plain_host(ses.ctx(), data.data(), data.size(), 0, &f, nullptr);
+        }
+        std::unique_ptr<nolzss_factor, decltype(&std::free)> hold(f, &std::free);
+        write_v2_file(out_path, f, count, 0, 0, data.size(), std::string());  // factorizer.cpp:447-456
+        *z = count;
+    });
+}
+
+int nolzss_write_factors_binary_file_dna_w_rc(const char *in_path, const char *out_path, int device, size_t *z) {
+    return guarded([&] {
+        if (!z) throw std::invalid_argument("output pointer is null");
+        *z = 0;
+        std::vector<uint8_t> data = read_file(in_path);
+        nolzss_factor *f = nullptr;
+        size_t count = 0;
+        dna_w_rc_common(data.data(), data.size(), device, &f, &count);
+        std::unique_ptr<nolzss_factor, decltype(&std::free)> hold(f, &std::free);
+        // one empty sequence name, num_sequences = 1 (factorizer.cpp:621-629)
+        write_v2_file(out_path, f, count, 1, 0, data.size(), std::string(1, '\0'));
+        *z = count;
+    });
+}
+
+int nolzss_factorize_w_reference_file(const uint8_t *reference_seq, size_t reference_len, const uint8_t *target_seq,
+                                      size_t target_len, const char *out_path, int device, size_t *z) {
+    return guarded([&] {
+        if (!z) throw std::invalid_argument("output pointer is null");
+        *z = 0;
+        if (!out_path) throw std::invalid_argument("output path is null");
+        {  // the reference opens the output first (factorizer.cpp:982-985)
+            std::ofstream probe(out_path, std::ios::binary);
+            if (!probe) throw std::runtime_error(std::string("Cannot create output file: ") + out_path);
+        }
+        nolzss_factor *f = nullptr;
+        const size_t count = w_reference(reference_seq, reference_len, target_seq, target_len, device, &f);
+        std::unique_ptr<nolzss_factor, decltype(&std::free)> hold(f, &std::free);
+        write_v2_file(out_path, f, count, 2, 1, target_len, std::string());  // :1005-1015
+        *z = count;
+    });
+}
+
+int nolzss_factorize_dna_w_reference_seq_file(const char *reference_seq, size_t reference_len,
+                                              const char *target_seq, size_t target_len, const char *out_path,
+                                              int device, size_t *z) {
+    return guarded([&] {
+        if (!z) throw std::invalid_argument("output pointer is null");
+        *z = 0;
+        if (!out_path) throw std::invalid_argument("output path is null");
+        {
+            std::ofstream probe(out_path, std::ios::binary);
+            if (!probe) throw std::runtime_error(std::string("Cannot create output file: ") + out_path);
+        }
+        nolzss_factor *f = nullptr;
+        const size_t count = dna_w_reference(reference_seq, reference_len, target_seq, target_len, device, &f);
+        std::unique_ptr<nolzss_factor, decltype(&std::free)> hold(f, &std::free);
+        write_v2_file(out_path, f, count, 2, 1, target_len, std::string());  // factorizer.cpp:866-876
+        *z = count;
+    });
+}
+
 int nolzss_factorize_batch(const uint8_t *const *texts, const size_t *lens, size_t m, const int *devices,
                            size_t n_dev, nolzss_factor ***out, size_t **z) {
     return guarded([&] {

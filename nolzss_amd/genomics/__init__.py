@@ -8,9 +8,11 @@ from .._noLZSS import (
     prepare_multiple_dna_sequences_w_rc,
 )
 from .fasta import FASTAError, read_nucleotide_fasta, shard_nucleotide_fasta
+from .sequences import is_dna_sequence, factorize_dna_w_reference_seq, factorize_dna_w_reference_seq_file
 
 __all__ = [
     "factorize_dna_w_rc", "count_factors_dna_w_rc", "factorize_multiple_dna_w_rc",
     "count_factors_multiple_dna_w_rc", "prepare_multiple_dna_sequences_w_rc",
     "FASTAError", "read_nucleotide_fasta", "shard_nucleotide_fasta",
+    "is_dna_sequence", "factorize_dna_w_reference_seq", "factorize_dna_w_reference_seq_file",
 ]

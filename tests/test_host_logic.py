@@ -41,7 +41,7 @@ def test_reference_module_names_exist():
                  "prepare_multiple_dna_sequences_w_rc", "Factor", "__version__"]:
         assert hasattr(_noLZSS, name), name
     with pytest.raises(NotImplementedError):
-        _noLZSS.write_factors_binary_file("a", "b")
+        _noLZSS.factorize_fasta_multiple_dna_w_rc("a.fasta")
 
 
 def test_validate_input_mirrors_reference():
@@ -164,3 +164,31 @@ def test_lpt_assignment_is_deterministic_and_balanced():
     assert max(loads) - min(loads) <= max(lens)
     assert lpt_assignment([5, 5, 5, 5], 4) == [0, 1, 2, 3]
     assert lpt_assignment([], 2) == []
+
+
+def test_v2_reader_against_hand_packed_files(tmp_path):
+    """reference: tests/test_utils.py:177-290 -- footers packed by hand"""
+    import struct
+    import nolzss_amd as pkg
+    factors = [(0, 1, 0), (1, 3, 0), (4, 2, (1 << 63) | 1)]
+    body = b"".join(struct.pack("<QQQ", *f) for f in factors)
+    names = b"chr1\x00chr2\x00"
+    sent = struct.pack("<Q", 1)
+    footer = struct.pack("<8sQQQQQ", b"noLZSSv2", 3, 2, 1, 48 + len(names) + len(sent), 6)
+    p = tmp_path / "f.bin"
+    p.write_bytes(body + names + sent + footer)
+    assert pkg.read_factors_binary_file(p) == factors
+    meta = pkg.read_factors_binary_file_with_metadata(p)
+    assert meta["sequence_names"] == ["chr1", "chr2"] and meta["sentinel_factor_indices"] == [1]
+    assert meta["num_factors"] == 3 and meta["total_length"] == 6
+    assert meta["factors"] == [(0, 1, 0, False), (1, 3, 0, False), (4, 2, 1, True)]
+    bad = tmp_path / "bad.bin"
+    bad.write_bytes(body + struct.pack("<8sQQQQQ", b"noLZSSv1", 3, 0, 0, 48, 6))
+    with pytest.raises(pkg.NoLZSSError):
+        pkg.read_factors_binary_file(bad)
+    with pytest.raises(pkg.NoLZSSError):
+        pkg.read_factors_binary_file(tmp_path / "missing.bin")
+    tiny = tmp_path / "tiny.bin"
+    tiny.write_bytes(b"abc")
+    with pytest.raises(pkg.NoLZSSError):
+        pkg.read_factors_binary_file(tiny)
