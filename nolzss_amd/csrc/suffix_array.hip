@@ -133,16 +133,29 @@ __global__ __launch_bounds__(kThreads) void pack_kernel(const uint8_t *__restric
 // ---------------------------------------------------------------------------------------
 template <int BITS>
 __global__ __launch_bounds__(kThreads) void initial_keys_kernel(const uint64_t *__restrict__ words,
-                                                                uint32_t n, uint64_t *__restrict__ keys,
+                                                                uint32_t n, TermTable terms, bool segmented,
+                                                                uint64_t *__restrict__ keys,
                                                                 uint32_t *__restrict__ vals) {
-    constexpr int K = KeyLayout<BITS>::kSyms;
-    constexpr int TAG = KeyLayout<BITS>::kTagBits;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const uint64_t w = sym_word<BITS>(words, i);
-        const uint32_t rem = n - (uint32_t)i;
-        const uint64_t tag = rem < (uint32_t)K ? rem : (uint32_t)K;
-        keys[i] = ((w >> (64 - K * BITS)) << TAG) | tag;
+        const uint32_t k = term_lower_bound(terms, (uint32_t)i);
+        const uint32_t lim = terms.pos[k] - (uint32_t)i;  // symbols before the next terminator
+        if (BITS == 2 && segmented) {
+            // [25 symbols][5-bit tag][8-bit terminator index]: a suffix that meets a terminator
+            // inside the key window gets a key of its own, so every group left after the sort
+            // consists of suffixes that agree on 25 real nucleotides
+            const uint32_t tag = lim < (uint32_t)kSegSyms ? lim : (uint32_t)kSegSyms;
+            uint64_t sym = w >> (64 - kSegSyms * 2);
+            if (tag < (uint32_t)kSegSyms) sym &= ~((1ull << (2 * (kSegSyms - tag))) - 1ull);
+            keys[i] = (sym << (kSegTagBits + kSegTermBits)) | ((uint64_t)tag << kSegTermBits) |
+                      (tag < (uint32_t)kSegSyms ? (uint64_t)(k & 255u) : 0ull);
+        } else {
+            constexpr int K = KeyLayout<BITS>::kSyms;
+            constexpr int TAG = KeyLayout<BITS>::kTagBits;
+            const uint64_t tag = lim < (uint32_t)K ? lim : (uint32_t)K;
+            keys[i] = ((w >> (64 - K * BITS)) << TAG) | tag;
+        }
         vals[i] = (uint32_t)i;
     }
 }
@@ -193,7 +206,8 @@ __global__ __launch_bounds__(kThreads) void commit_kernel(const uint64_t *__rest
                                                           uint32_t *__restrict__ rank_val,
                                                           uint32_t *__restrict__ keep,
                                                           uint32_t *__restrict__ lcp, int sym_bits, int tag_bits,
-                                                          int bits, const uint32_t *__restrict__ lcp_list) {
+                                                          int bits, const uint32_t *__restrict__ lcp_list,
+                                                          int low_bits) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x; a < m; a += stride) {
         const bool head = is_head<kRound0>(keys, grp, lo, a);
@@ -217,7 +231,7 @@ __global__ __launch_bounds__(kThreads) void commit_kernel(const uint64_t *__rest
             if (a == 0) {
                 l = 0;
             } else if (head) {
-                const uint64_t ka = keys[a], kb = keys[a - 1];
+                const uint64_t ka = keys[a] >> low_bits, kb = keys[a - 1] >> low_bits;
                 const uint64_t tmask = (1ull << tag_bits) - 1ull;
                 const uint32_t ta = (uint32_t)(ka & tmask), tb = (uint32_t)(kb & tmask);
                 const uint64_t x = (ka ^ kb) >> tag_bits << (64 - sym_bits);  // symbols, left-aligned
@@ -331,19 +345,20 @@ constexpr int kRefineSpan = kRefineTile + (int)kSmallGroup;
 template <int BITS>
 __global__ __launch_bounds__(kThreads) void group_refine_kernel(
     const uint32_t *__restrict__ act_slot, const uint32_t *__restrict__ act_grp, const uint32_t *__restrict__ gsize,
-    const uint32_t *__restrict__ sa, const uint64_t *__restrict__ words, uint32_t n, uint32_t m, uint32_t h0,
+    const uint32_t *__restrict__ sa, const uint64_t *__restrict__ words, TermTable terms, uint32_t m, uint32_t h0,
     uint32_t cap, uint32_t *__restrict__ out_lo, uint32_t *__restrict__ out_vals, uint32_t *__restrict__ lcp_list,
     uint32_t *__restrict__ large_flag) {
     constexpr uint32_t kPerWord = 64 / BITS;
     constexpr int kPerThread = (kRefineSpan + kThreads - 1) / kThreads;
     __shared__ uint64_t s_w0[kRefineSpan], s_w1[kRefineSpan];
-    __shared__ uint32_t s_pos[kRefineSpan];   // suffix start
+    __shared__ uint32_t s_lim[kRefineSpan];   // symbols before the member's next terminator
+    __shared__ uint16_t s_term[kRefineSpan];  // index of that terminator
     __shared__ uint16_t s_cls[kRefineSpan];   // strictly smaller members so far
     __shared__ uint8_t s_act[kRefineSpan];    // still tied with somebody
     const size_t a0 = (size_t)blockIdx.x * kRefineTile;
     const size_t a1 = (a0 + kRefineTile < m) ? a0 + kRefineTile : m;
 
-    uint32_t my_pos[kPerThread], my_lcp[kPerThread];
+    uint32_t my_pos[kPerThread], my_lcp[kPerThread], my_lim[kPerThread];
     uint16_t my_gl[kPerThread];  // local index of the group's first member
     uint8_t my_gs[kPerThread];   // group size (0: not handled here)
 #pragma unroll
@@ -354,6 +369,8 @@ __global__ __launch_bounds__(kThreads) void group_refine_kernel(
         my_gl[j] = 0;
         my_pos[j] = 0;
         my_lcp[j] = 0;
+        my_lim[j] = 0;
+        uint32_t my_term = 0;
         bool mine = false;
         if (t < kRefineSpan && a < m) {
             const uint32_t g = act_grp[a];
@@ -366,10 +383,13 @@ __global__ __launch_bounds__(kThreads) void group_refine_kernel(
                 my_gs[j] = (uint8_t)sz;
                 my_gl[j] = (uint16_t)(g0 - a0);
                 my_pos[j] = sa[slot];
+                my_term = term_lower_bound(terms, my_pos[j]);
+                my_lim[j] = terms.pos[my_term] - my_pos[j];
             }
         }
         if (t < kRefineSpan) {
-            s_pos[t] = my_pos[j];
+            s_lim[t] = my_lim[j];
+            s_term[t] = (uint16_t)my_term;
             s_cls[t] = 0;
             s_act[t] = mine ? 1 : 0;
         }
@@ -398,13 +418,13 @@ __global__ __launch_bounds__(kThreads) void group_refine_kernel(
             if (t < kRefineSpan && s_act[t]) {
                 const uint64_t x0 = s_w0[t], x1 = s_w1[t];
                 const uint32_t cls = s_cls[t];
-                const uint32_t rem_t = n - my_pos[j] - h;  // symbols left in my suffix (>= 1)
+                const uint32_t rem_t = my_lim[j] - h;  // symbols left before my terminator
                 uint32_t best = 0;
                 for (int e = 0; e < my_gs[j]; ++e) {
                     const int u = my_gl[j] + e;
                     if (u == t || !s_act[u] || s_cls[u] != cls) continue;
                     const uint64_t y0 = s_w0[u], y1 = s_w1[u];
-                    const uint32_t rem_u = n - s_pos[u] - h;
+                    const uint32_t rem_u = s_lim[u] - h;
                     uint32_t valid = rem_t < rem_u ? rem_t : rem_u;
                     valid = valid < 2 * kPerWord ? valid : 2 * kPerWord;
                     uint32_t d;
@@ -424,8 +444,8 @@ __global__ __launch_bounds__(kThreads) void group_refine_kernel(
                             still[j] = 1;
                             continue;
                         }
-                        d = valid;  // the shorter suffix is a prefix of the other and sorts first
-                        u_smaller = rem_u < rem_t;
+                        d = valid;  // a terminator is reached: nearer one first, then lower index
+                        u_smaller = rem_u != rem_t ? rem_u < rem_t : s_term[u] < s_term[t];
                     }
                     if (u_smaller) {
                         ++add[j];
@@ -527,7 +547,8 @@ __global__ __launch_bounds__(kThreads) void rank_to_isa_kernel(uint32_t *__restr
 template <int BITS>
 void launch_initial_keys(Context &ctx, const PackedText &t, uint64_t *keys, uint32_t *vals) {
     ProfScope ps(ctx.profiler(), "sa_initial_keys", ctx.stream);
-    initial_keys_kernel<BITS><<<grid_for(t.n, kThreads), kThreads, 0, ctx.stream>>>(t.words, t.n, keys, vals);
+    initial_keys_kernel<BITS><<<grid_for(t.n, kThreads), kThreads, 0, ctx.stream>>>(t.words, t.n, t.terms, t.segmented,
+                                                                                keys, vals);
     KERNEL_CHECK();
 }
 
@@ -537,7 +558,8 @@ uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *grp, const 
                  const uint32_t *act_slot, uint32_t m, uint32_t n, uint32_t *sa, uint32_t *rank, uint32_t *new_slot,
                  uint32_t *new_grp, uint32_t *tmp_a, uint32_t *tmp_b, uint32_t *tmp_c, uint32_t *scratch_idx,
                  uint32_t *scratch_val, uint32_t *rank_val, uint32_t *d_total, uint32_t *lcp = nullptr,
-                 int sym_bits = 0, int tag_bits = 0, int bits = 0, const uint32_t *lcp_list = nullptr) {
+                 int sym_bits = 0, int tag_bits = 0, int bits = 0, const uint32_t *lcp_list = nullptr,
+                 int low_bits = 0) {
     hipStream_t s = ctx.stream;
     {
         ProfScope ps(ctx.profiler(), "sa_mark_heads", s);
@@ -552,7 +574,7 @@ uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *grp, const 
         ProfScope ps(ctx.profiler(), "sa_commit", s);
         commit_kernel<kRound0><<<grid_for(m, kThreads), kThreads, 0, s>>>(keys, grp, lo, vals, act_slot, tmp_a, m,
                                                                           sa, rank_val, tmp_b, lcp, sym_bits,
-                                                                          tag_bits, bits, lcp_list);
+                                                                          tag_bits, bits, lcp_list, low_bits);
         KERNEL_CHECK();
     }
     {
@@ -579,23 +601,45 @@ uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *grp, const 
 
 }  // namespace
 
-PackedText pack_text(Context &ctx, const uint8_t *d_text, size_t n) {
+PackedText pack_text(Context &ctx, const uint8_t *d_text, size_t n, const std::vector<uint32_t> *terminators) {
     hipStream_t s = ctx.stream;
     PackedText t;
     t.n = (uint32_t)n;
     unsigned long long *presence = ctx.arena.alloc<unsigned long long>(4);
-    HIP_CHECK(hipMemsetAsync(presence, 0, 32, s));
-    {
-        ProfScope ps(ctx.profiler(), "text_presence", s);
-        presence_kernel<<<grid_for(div_up(n, 16), kThreads, 2048), kThreads, 0, s>>>(d_text, n, presence);
-        KERNEL_CHECK();
+    if (terminators) {
+        // segmented text: only the nucleotides are symbols (A < C < G < T -> 0..3); the unique
+        // terminator bytes pack as code 0 and are never compared
+        unsigned long long h_presence[4] = {0, 0, 0, 0};
+        for (unsigned char c : {'A', 'C', 'G', 'T'}) h_presence[c >> 6] |= 1ull << (c & 63);
+        HIP_CHECK(hipMemcpyAsync(presence, h_presence, 32, hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipStreamSynchronize(s));  // h_presence is a stack buffer
+        t.sigma = 4;
+        t.bits = 2;
+        t.segmented = true;
+    } else {
+        HIP_CHECK(hipMemsetAsync(presence, 0, 32, s));
+        {
+            ProfScope ps(ctx.profiler(), "text_presence", s);
+            presence_kernel<<<grid_for(div_up(n, 16), kThreads, 2048), kThreads, 0, s>>>(d_text, n, presence);
+            KERNEL_CHECK();
+        }
+        uint32_t bitsw[8];
+        ctx.read_back(reinterpret_cast<const uint32_t *>(presence), bitsw, 8);
+        int sigma = 0;
+        for (int k = 0; k < 8; ++k) sigma += __builtin_popcount(bitsw[k]);
+        t.sigma = sigma;
+        t.bits = sigma <= 4 ? 2 : (sigma <= 16 ? 4 : 8);
     }
-    uint32_t bitsw[8];
-    ctx.read_back(reinterpret_cast<const uint32_t *>(presence), bitsw, 8);
-    int sigma = 0;
-    for (int k = 0; k < 8; ++k) sigma += __builtin_popcount(bitsw[k]);
-    t.sigma = sigma;
-    t.bits = sigma <= 4 ? 2 : (sigma <= 16 ? 4 : 8);
+    // terminator table: the given positions (sorted) and always the end of the text
+    std::vector<uint32_t> table;
+    if (terminators) table = *terminators;
+    table.push_back((uint32_t)n);
+    uint32_t *d_terms = ctx.arena.alloc<uint32_t>(table.size());
+    HIP_CHECK(hipMemcpyAsync(d_terms, table.data(), table.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipStreamSynchronize(s));  // table is a local vector
+    t.terms.pos = d_terms;
+    t.terms.count = (uint32_t)table.size();
+
     const size_t nwords = div_up(n * (size_t)t.bits, 64) + 4;  // zero pad: windows read past the end
     uint64_t *words = ctx.arena.alloc<uint64_t>(nwords);
     {
@@ -616,8 +660,8 @@ PackedText pack_text(Context &ctx, const uint8_t *d_text, size_t n) {
 // `skip` symbols, so the packed-word comparison starts there
 template <int BITS>
 __global__ __launch_bounds__(kThreads) void lcp_finish_kernel(const uint64_t *__restrict__ words, uint32_t n,
-                                                              const uint32_t *__restrict__ sa, uint32_t skip,
-                                                              uint32_t *__restrict__ lcp) {
+                                                              TermTable terms, const uint32_t *__restrict__ sa,
+                                                              uint32_t skip, uint32_t *__restrict__ lcp) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r <= n; r += stride) {
         if (r == n) {
@@ -628,9 +672,8 @@ __global__ __launch_bounds__(kThreads) void lcp_finish_kernel(const uint64_t *__
                 // both suffixes share their first (K << round) symbols, capped by the text end
                 uint64_t h0 = skip;
                 if (code != kLcpPending) h0 = (uint64_t)skip << (kLcpPending - 1u - code);
-                const uint32_t a = sa[r - 1], b = sa[r];
-                const uint32_t limit = n - (a > b ? a : b);
-                lcp[r] = suffix_lcp<BITS>(words, n, a, b, h0 < limit ? (uint32_t)h0 : limit);
+                lcp[r] = suffix_lcp<BITS>(words, terms, sa[r - 1], sa[r],
+                                          h0 < 0xffffffffull ? (uint32_t)h0 : 0xffffffffu);
             }
         }
     }
@@ -668,15 +711,20 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         ProfScope ps(ctx.profiler(), "sa_sort_initial", s);
         cur = radix_sort_pairs(keys, vals, n, shifts, 8, arena, s, ctx.profiler());
     }
-    int tag_bits = 0;
+    int tag_bits = 0, low_bits = 0;
     switch (text.bits) {
     case 2: tag_bits = KeyLayout<2>::kTagBits; break;
     case 4: tag_bits = KeyLayout<4>::kTagBits; break;
     default: tag_bits = KeyLayout<8>::kTagBits; break;
     }
+    if (text.segmented) {  // [25 symbols][5-bit tag][8-bit terminator index]
+        k_syms = kSegSyms;
+        tag_bits = kSegTagBits;
+        low_bits = kSegTermBits;
+    }
     uint32_t m = regroup<true>(ctx, keys[cur], nullptr, nullptr, vals[cur], nullptr, n, n, sa, rank, act_slot[0],
                                act_grp[0], tmp_a, tmp_b, tmp_c, scratch_idx, scratch_val, rank_val, d_total, lcp,
-                               k_syms * text.bits, tag_bits, text.bits);
+                               k_syms * text.bits, tag_bits, text.bits, nullptr, low_bits);
 
     // ---- doubling rounds ------------------------------------------------------------------
     // in the rounds the 8n-byte key buffers are reused as four u32 arrays
@@ -711,15 +759,15 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
             const unsigned g = (unsigned)div_up(m, kRefineTile);
             switch (text.bits) {
             case 2:
-                group_refine_kernel<2><<<g, kThreads, 0, s>>>(slot, grp, gsize, sa, text.words, n, m, (uint32_t)h, cap,
+                group_refine_kernel<2><<<g, kThreads, 0, s>>>(slot, grp, gsize, sa, text.words, text.terms, m, (uint32_t)h, cap,
                                                               out_lo, out_vals, lcp_list, tmp_a);
                 break;
             case 4:
-                group_refine_kernel<4><<<g, kThreads, 0, s>>>(slot, grp, gsize, sa, text.words, n, m, (uint32_t)h, cap,
+                group_refine_kernel<4><<<g, kThreads, 0, s>>>(slot, grp, gsize, sa, text.words, text.terms, m, (uint32_t)h, cap,
                                                               out_lo, out_vals, lcp_list, tmp_a);
                 break;
             default:
-                group_refine_kernel<8><<<g, kThreads, 0, s>>>(slot, grp, gsize, sa, text.words, n, m, (uint32_t)h, cap,
+                group_refine_kernel<8><<<g, kThreads, 0, s>>>(slot, grp, gsize, sa, text.words, text.terms, m, (uint32_t)h, cap,
                                                               out_lo, out_vals, lcp_list, tmp_a);
                 break;
             }
@@ -800,9 +848,9 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         ProfScope ps(ctx.profiler(), "lcp_finish", s);
         const unsigned g = grid_for((size_t)n + 1, kThreads, 256u * 32u);
         switch (text.bits) {
-        case 2: lcp_finish_kernel<2><<<g, kThreads, 0, s>>>(text.words, n, sa, (uint32_t)k_syms, lcp); break;
-        case 4: lcp_finish_kernel<4><<<g, kThreads, 0, s>>>(text.words, n, sa, (uint32_t)k_syms, lcp); break;
-        default: lcp_finish_kernel<8><<<g, kThreads, 0, s>>>(text.words, n, sa, (uint32_t)k_syms, lcp); break;
+        case 2: lcp_finish_kernel<2><<<g, kThreads, 0, s>>>(text.words, n, text.terms, sa, (uint32_t)k_syms, lcp); break;
+        case 4: lcp_finish_kernel<4><<<g, kThreads, 0, s>>>(text.words, n, text.terms, sa, (uint32_t)k_syms, lcp); break;
+        default: lcp_finish_kernel<8><<<g, kThreads, 0, s>>>(text.words, n, text.terms, sa, (uint32_t)k_syms, lcp); break;
         }
         KERNEL_CHECK();
     }

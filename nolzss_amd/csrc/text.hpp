@@ -9,12 +9,42 @@
 
 namespace nolzss {
 
+// Terminators cut the text into segments that no match may cross: the end of the text (always the
+// last entry, position n) and, in SEGMENTED texts, the unique sentinel bytes of a prepared
+// multi-sequence / reverse-complement string (/root/reference/src/cpp/factorizer.cpp:110-147).
+// A segmented text packs only its nucleotides (2 bits); a suffix comparison runs at most to the
+// nearer terminator, and at a terminator the suffix that reaches it first is the smaller one
+// (equal distance: the lower terminator index) -- the order the reference's unique sentinels give
+// up to a relabelling of symbols, which the factorization does not depend on.
+struct TermTable {
+    const uint32_t *pos = nullptr;  // sorted terminator positions, pos[count-1] = n
+    uint32_t count = 0;
+};
+
+// smallest k with pos[k] >= p (exists for every suffix start p < n)
+__device__ __forceinline__ uint32_t term_lower_bound(const TermTable &t, uint32_t p) {
+    uint32_t lo = 0, hi = t.count - 1;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (t.pos[mid] >= p)
+            hi = mid;
+        else
+            lo = mid + 1;
+    }
+    return lo;
+}
+
 struct PackedText {
     const uint64_t *words = nullptr;  // ceil(n*bits/64) + 4 zero pad words
     uint32_t n = 0;
     int bits = 0;    // 2, 4 or 8
     int sigma = 0;   // distinct byte values present
+    TermTable terms;
+    bool segmented = false;  // terminators inside the text (packed as code 0, never compared)
 };
+
+// segmented texts: key = [25 symbols][5-bit length tag][8-bit terminator index]
+constexpr int kSegSyms = 25, kSegTagBits = 5, kSegTermBits = 8;
 
 // Symbols per initial sort key and width of the length tag that breaks ties between a
 // suffix that ends inside the key window and its zero-padded longer neighbours.
@@ -35,12 +65,16 @@ __device__ __forceinline__ uint64_t sym_word(const uint64_t *__restrict__ w, uin
 }
 
 // Common prefix length of suffixes a and b of the packed text, starting the comparison at
-// offset h0 (caller guarantees the first h0 symbols match), capped at n - max(a, b).
+// offset h0 (caller guarantees the first min(h0, limit) symbols match), capped at the nearer
+// terminator.
 template <int BITS>
-__device__ __forceinline__ uint32_t suffix_lcp(const uint64_t *__restrict__ w, uint32_t n,
+__device__ __forceinline__ uint32_t suffix_lcp(const uint64_t *__restrict__ w, const TermTable &terms,
                                                uint32_t a, uint32_t b, uint32_t h0) {
     constexpr uint32_t kPerWord = 64 / BITS;
-    const uint32_t limit = n - (a > b ? a : b);
+    const uint32_t la = terms.pos[term_lower_bound(terms, a)] - a;
+    const uint32_t lb = terms.pos[term_lower_bound(terms, b)] - b;
+    const uint32_t limit = la < lb ? la : lb;
+    if (h0 >= limit) return limit;
     uint32_t h = h0;
     while (h < limit) {
         const uint64_t x = sym_word<BITS>(w, (uint64_t)a + h);
@@ -57,13 +91,15 @@ __device__ __forceinline__ uint32_t suffix_lcp(const uint64_t *__restrict__ w, u
 // Three-way comparison of suffixes a and b that are known to agree on their first h0 symbols,
 // looking at most `cap` symbols deep.  Returns -1 / +1 if suffix a is smaller / greater, 0 if
 // the first `cap` symbols are equal (undecided); lcp receives the common prefix length
-// (>= cap when undecided).  A suffix that ends first is the smaller one, as with the
-// reference's appended terminator.
+// (>= cap when undecided).  A suffix that reaches its terminator first is the smaller one, as
+// with the reference's appended terminator.
 template <int BITS>
-__device__ __forceinline__ int suffix_compare(const uint64_t *__restrict__ w, uint32_t n, uint32_t a, uint32_t b,
-                                              uint32_t h0, uint32_t cap, uint32_t &lcp) {
+__device__ __forceinline__ int suffix_compare(const uint64_t *__restrict__ w, const TermTable &terms, uint32_t a,
+                                              uint32_t b, uint32_t h0, uint32_t cap, uint32_t &lcp) {
     constexpr uint32_t kPerWord = 64 / BITS;
-    const uint32_t limit = n - (a > b ? a : b);  // length of the shorter suffix
+    const uint32_t ka = term_lower_bound(terms, a), kb = term_lower_bound(terms, b);
+    const uint32_t la = terms.pos[ka] - a, lb = terms.pos[kb] - b;
+    const uint32_t limit = la < lb ? la : lb;  // symbols before the nearer terminator
     const uint32_t stop = limit < cap ? limit : cap;
     uint32_t h = h0;
     while (h < stop) {
@@ -79,9 +115,10 @@ __device__ __forceinline__ int suffix_compare(const uint64_t *__restrict__ w, ui
         }
         h += kPerWord;
     }
-    if (limit <= cap) {  // the shorter suffix is a prefix of the other one
+    if (limit <= cap) {  // a terminator is reached: nearer one first, then lower index first
         lcp = limit;
-        return a > b ? -1 : 1;
+        if (la != lb) return la < lb ? -1 : 1;
+        return ka < kb ? -1 : 1;
     }
     lcp = cap;
     return 0;
