@@ -48,10 +48,10 @@ __device__ __forceinline__ void stage_tile(const uint32_t *__restrict__ sa, cons
 // One round of kLdsStep steps of one search, branch-free.  li = local index of rank r in the
 // staged tile, s0 = steps already taken, m = running LCP minimum (in/out).
 // Returns 0 = finished without a match (len 0), 1 = match (m = its LCP, pos = its suffix start),
-// 2 = still searching.
-__device__ __forceinline__ int lds_scan_round(const uint32_t *s_sa, const uint32_t *s_lcp, uint32_t n, uint32_t r,
-                                              int li, int s0, bool greater, bool up, uint32_t x, uint32_t &m,
-                                              uint32_t &pos) {
+// 2 = still searching.  No bounds logic is needed: LCP[0] = LCP[n] = 0 (and 0 is staged outside
+// the array), so the running minimum dies exactly when a search would leave the array.
+__device__ __forceinline__ int lds_scan_round(const uint32_t *s_sa, const uint32_t *s_lcp, int li, int s0,
+                                              bool greater, bool up, uint32_t x, uint32_t &m, uint32_t &pos) {
     uint32_t c[kLdsStep], v[kLdsStep];
     const int dir = up ? -1 : 1;
 #pragma unroll
@@ -60,19 +60,25 @@ __device__ __forceinline__ int lds_scan_round(const uint32_t *s_sa, const uint32
         c[k] = s_lcp[q + (up ? 1 : 0)];
         v[k] = s_sa[q];
     }
-    int status = 2;
+    // "v > x" as "~v < ~x": one comparison form for both kinds of search
+    const uint32_t flip = greater ? 0xffffffffu : 0u;
+    const uint32_t xf = x ^ flip;
 #pragma unroll
-    for (int k = 0; k < kLdsStep; ++k) {
-        const uint32_t s = (uint32_t)(s0 + k + 1);
-        const bool oob = up ? (r < s) : ((uint64_t)r + s >= n);
-        const uint32_t mk = c[k] < m ? c[k] : m;
-        const bool open = status == 2;
-        const bool dead = oob || mk == 0;
-        const bool hit = !dead && (greater ? (v[k] > x) : (v[k] < x));
-        m = open ? mk : m;
-        pos = (open && hit) ? v[k] : pos;
-        status = open ? (dead ? 0 : (hit ? 1 : 2)) : status;
+    for (int k = 0; k < kLdsStep; ++k) {  // running minima
+        m = c[k] < m ? c[k] : m;
+        c[k] = m;
     }
+    int status = 2;
+    uint32_t len = m;
+#pragma unroll
+    for (int k = kLdsStep - 1; k >= 0; --k) {  // the earliest stopping step wins
+        const bool dead = c[k] == 0;
+        const bool stop = dead || (v[k] ^ flip) < xf;
+        status = stop ? (dead ? 0 : 1) : status;
+        len = stop ? c[k] : len;
+        pos = stop ? v[k] : pos;
+    }
+    m = len;
     return status;
 }
 
@@ -106,7 +112,7 @@ __device__ __forceinline__ void lds_search_wave(const uint32_t *s_sa, const uint
             const bool greater = k >= 2, up = (k & 1) == 0;
             uint32_t m = 0xffffffffu, pos = kNoPos;
             int st = 0;
-            if (valid) st = lds_scan_round(s_sa, s_lcp, n, (uint32_t)rr, li, 0, greater, up, greater ? thr_gt(i) : i, m, pos);
+            if (valid) st = lds_scan_round(s_sa, s_lcp, li, 0, greater, up, greater ? thr_gt(i) : i, m, pos);
             res_len[k * kLdsTile + t] = (st == 0) ? 0u : m;
             if (k < NP) res_pos[k * kLdsTile + t] = (st == 1) ? pos : kNoPos;
             const bool pending = st == 2;
@@ -128,14 +134,13 @@ __device__ __forceinline__ void lds_search_wave(const uint32_t *s_sa, const uint
             const uint32_t item = have ? lists[cur][c0 + lane] : 0u;
             const int tl = item & 255, k = (item >> 8) & 3, chunk = (int)(item >> 10);
             const int t = w * kLdsPerWave + tl;
-            const uint32_t r = base + (uint32_t)t;
             const int li = t + kLdsReach;
             const bool greater = k >= 2, up = (k & 1) == 0;
             bool pending = false;
             if (have) {
                 const uint32_t i = s_sa[li];
                 uint32_t m = res_len[k * kLdsTile + t], pos = kNoPos;
-                const int st = lds_scan_round(s_sa, s_lcp, n, r, li, chunk * kLdsStep, greater, up,
+                const int st = lds_scan_round(s_sa, s_lcp, li, chunk * kLdsStep, greater, up,
                                               greater ? thr_gt(i) : i, m, pos);
                 const bool at_reach = (chunk + 1) * kLdsStep >= kLdsReach;
                 pending = st == 2 && !at_reach;
@@ -161,7 +166,6 @@ __device__ __forceinline__ void lds_search_wave(const uint32_t *s_sa, const uint
         const int tl = item & 255, k = (item >> 8) & 3;
         int s0 = (int)(item >> 10) * kLdsStep;
         const int t = w * kLdsPerWave + tl;
-        const uint32_t r = base + (uint32_t)t;
         const int li = t + kLdsReach;
         const bool greater = k >= 2, up = (k & 1) == 0;
         const uint32_t i = s_sa[li];
@@ -174,10 +178,9 @@ __device__ __forceinline__ void lds_search_wave(const uint32_t *s_sa, const uint
             const int q = inside ? (up ? li - step : li + step) : li;
             const uint32_t c = inside ? s_lcp[q + (up ? 1 : 0)] : 0xffffffffu;
             const uint32_t v = s_sa[q];
-            const bool oob = up ? (r < (uint32_t)step) : ((uint64_t)r + (uint32_t)step >= n);
             uint32_t mk = wave_scan_inclusive_dpp(c, 0xffffffffu, OpMinU32());
             mk = mk < m ? mk : m;
-            const bool dead = inside && (oob || mk == 0);
+            const bool dead = inside && mk == 0;  // LCP[0] = LCP[n] = 0 end every search in range
             const bool hit = inside && !dead && (greater ? (v > x) : (v < x));
             const uint64_t stop = __ballot(dead || hit || !inside);
             if (stop) {

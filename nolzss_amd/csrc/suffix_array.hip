@@ -339,7 +339,7 @@ __global__ __launch_bounds__(kThreads) void group_size_kernel(const uint32_t *__
 // of its own suffix (one random line per member per round -- never a pairwise re-read), the
 // members of a group compare their windows through LDS, tie classes split, and the loop ends when
 // the workgroup has no tie left or the cap is reached.  cls = number of strictly smaller members.
-constexpr int kRefineTile = 1024;
+constexpr int kRefineTile = 256;
 constexpr int kRefineSpan = kRefineTile + (int)kSmallGroup;
 
 template <int BITS>
