@@ -12,6 +12,7 @@
 // "past the end of the text", which sorts before every real suffix exactly as the reference's
 // appended terminator does.
 #include "pipeline.hpp"
+#include "pyramid.hpp"
 #include "radix_sort.hpp"
 #include "scan.hpp"
 
@@ -189,8 +190,8 @@ __global__ __launch_bounds__(kThreads) void mark_heads_kernel(const uint64_t *__
     }
 }
 
-// LCP codes while the suffix array is being built: kLcpPending = same round-0 key, boundary not
-// seen yet; kLcpPending - 1 - j = boundary appeared in doubling round j (offset K << j).
+// LCP code while the suffix array is being built: the boundary has not appeared yet (values
+// >= kLcpPendingMin act as +infinity in range minima).
 constexpr uint32_t kLcpPending = 0xffffffffu;
 constexpr uint32_t kLcpPendingMin = kLcpPending - 64u;
 
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(kThreads) void commit_kernel(const uint64_t *__rest
                                                           uint32_t *__restrict__ keep,
                                                           uint32_t *__restrict__ lcp, int sym_bits, int tag_bits,
                                                           int bits, const uint32_t *__restrict__ lcp_list,
-                                                          int low_bits) {
+                                                          int low_bits, uint32_t dbl_h, Pyramid Plcp) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x; a < m; a += stride) {
         const bool head = is_head<kRound0>(keys, grp, lo, a);
@@ -218,11 +219,20 @@ __global__ __launch_bounds__(kThreads) void commit_kernel(const uint64_t *__rest
         rank_val[a] = head_of[a] + 1u;  // goes to rank[i] through bucketed_scatter
         keep[a] = (head && next_head) ? 0u : 1u;
         if (!kRound0) {
-            // a boundary that appears in the round with offset h = K << round separates two
-            // suffixes that agree on their first h symbols: remember the round so that
-            // lcp_finish_kernel can start comparing there
-            if (head && a > 0 && grp[a] == grp[a - 1])
-                lcp[slot] = lcp_list ? lcp_list[a] : kLcpPending - 1u - (uint32_t)bits;
+            // a new boundary inside an old group
+            if (head && a > 0 && grp[a] == grp[a - 1]) {
+                uint32_t v = lcp_list ? lcp_list[a] : kLcpPending;
+                if (v >= kLcpPendingMin) {
+                    // created by a doubling step with offset h: the two suffixes agree on h symbols
+                    // and continue with suffixes of DIFFERENT h-groups, whose LCP is the minimum of
+                    // the boundaries already decided between those groups (undecided entries hold
+                    // pending codes, i.e. +infinity):  lcp = h + min LCP(head1 .. head2]
+                    const uint32_t p = lo[a - 1], q = lo[a];  // rank codes: group head slot + 1
+                    v = dbl_h;
+                    if (p != 0) v += pyr_range<false>(Plcp, p, q - 1);
+                }
+                lcp[slot] = v;
+            }
         }
         if (kRound0) {
             // LCP of neighbours that round 0 already separates can be read off the two keys
@@ -456,15 +466,21 @@ __global__ __launch_bounds__(kThreads) void group_refine_kernel(
             }
         }
         __syncthreads();
+        int tied = 0;
 #pragma unroll
         for (int j = 0; j < kPerThread; ++j) {
             const int t = j * kThreads + threadIdx.x;
             if (t < kRefineSpan && s_act[t]) {
                 s_cls[t] = (uint16_t)(s_cls[t] + add[j]);
                 s_act[t] = still[j];
+                tied |= still[j];
             }
         }
-        __syncthreads();
+        // A workgroup that is still mostly tied after 256 symbols sits on a long exact repeat:
+        // comparing on to the cap would cost a line fetch per member per round for nothing.
+        // Leave those ties to the doubling rounds, which need only log2(LCP) steps.
+        const int busy = __syncthreads_count(tied);
+        if (h >= h0 + 3 * 2 * kPerWord && busy > kThreads / 4) break;
     }
 
 #pragma unroll
@@ -559,8 +575,14 @@ uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *grp, const 
                  uint32_t *new_grp, uint32_t *tmp_a, uint32_t *tmp_b, uint32_t *tmp_c, uint32_t *scratch_idx,
                  uint32_t *scratch_val, uint32_t *rank_val, uint32_t *d_total, uint32_t *lcp = nullptr,
                  int sym_bits = 0, int tag_bits = 0, int bits = 0, const uint32_t *lcp_list = nullptr,
-                 int low_bits = 0) {
+                 int low_bits = 0, uint32_t dbl_h = 0) {
     hipStream_t s = ctx.stream;
+    const size_t pmark = ctx.arena.mark();
+    Pyramid Plcp{};
+    if (!kRound0) {  // doubling boundaries read range minima of the LCP values decided so far
+        ProfScope ps(ctx.profiler(), "sa_lcp_pyramid", s);
+        Plcp = build_pyramid(lcp, n + 1, false, ctx.arena, s);
+    }
     {
         ProfScope ps(ctx.profiler(), "sa_mark_heads", s);
         mark_heads_kernel<kRound0><<<grid_for(m, kThreads), kThreads, 0, s>>>(keys, grp, lo, act_slot, m, tmp_a);
@@ -574,9 +596,11 @@ uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *grp, const 
         ProfScope ps(ctx.profiler(), "sa_commit", s);
         commit_kernel<kRound0><<<grid_for(m, kThreads), kThreads, 0, s>>>(keys, grp, lo, vals, act_slot, tmp_a, m,
                                                                           sa, rank_val, tmp_b, lcp, sym_bits,
-                                                                          tag_bits, bits, lcp_list, low_bits);
+                                                                          tag_bits, bits, lcp_list, low_bits, dbl_h,
+                                                                          Plcp);
         KERNEL_CHECK();
     }
+    ctx.arena.rewind(pmark);
     {
         // rank[vals[a]] = rank_val[a]: the one truly random write of the round
         ProfScope ps(ctx.profiler(), "sa_rank_scatter", s);
@@ -667,14 +691,9 @@ __global__ __launch_bounds__(kThreads) void lcp_finish_kernel(const uint64_t *__
         if (r == n) {
             lcp[r] = 0;
         } else {
-            const uint32_t code = lcp[r];
-            if (code >= kLcpPendingMin) {
-                // both suffixes share their first (K << round) symbols, capped by the text end
-                uint64_t h0 = skip;
-                if (code != kLcpPending) h0 = (uint64_t)skip << (kLcpPending - 1u - code);
-                lcp[r] = suffix_lcp<BITS>(words, terms, sa[r - 1], sa[r],
-                                          h0 < 0xffffffffull ? (uint32_t)h0 : 0xffffffffu);
-            }
+            // safety net: every boundary is decided by the keys, the direct round or a doubling
+            // step; anything still pending is compared in the packed text
+            if (lcp[r] >= kLcpPendingMin) lcp[r] = suffix_lcp<BITS>(words, terms, sa[r - 1], sa[r], skip);
         }
     }
 }
@@ -788,13 +807,13 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
             KERNEL_CHECK();
             const int c = radix_sort_pairs(lk, lv, n_large, shifts, npasses, arena, s, ctx.profiler());
             scatter_large_kernel<<<grid_for(n_large, kThreads), kThreads, 0, s>>>(lk[c], lv[c], lidx, n_large, out_lo,
-                                                                                  out_vals, lcp_list, kLcpPending - 1u);
+                                                                                  out_vals, lcp_list, kLcpPending);
             KERNEL_CHECK();
             arena.rewind(lmark);
         }
         m = regroup<false>(ctx, nullptr, grp, out_lo, out_vals, slot, m, n, sa, rank, act_slot[a_cur ^ 1],
                            act_grp[a_cur ^ 1], tmp_a, tmp_b, tmp_c, scratch_idx, scratch_val, rank_val, d_total, lcp,
-                           0, 0, 0, lcp_list);
+                           0, 0, 0, lcp_list, 0, (uint32_t)h);
         a_cur ^= 1;
         h *= 2;
         ++rounds;
@@ -834,7 +853,7 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         }
         m = regroup<false>(ctx, nullptr, grp, out_lo, out_vals, slot, m, n, sa, rank, act_slot[a_cur ^ 1],
                            act_grp[a_cur ^ 1], tmp_a, tmp_b, tmp_c, scratch_idx, scratch_val, rank_val, d_total, lcp,
-                           0, 0, /*round index, carried in the `bits` slot*/ rounds);
+                           0, 0, 0, nullptr, 0, (uint32_t)h);
         a_cur ^= 1;
         h *= 2;
         ++rounds;

@@ -122,3 +122,59 @@ def test_config5_rc_256Mi_properties(native):
     _check_matches(text, f, 50_000, np.random.default_rng(2), rc_mode=True)
     assert (f["ref"] >> np.uint64(63)).any(), "no reverse-complement factor at all?"
     assert native.count_factors_dna_w_rc(text) == len(f)
+
+
+def _fib(n):
+    a, b = b"a", b"ab"
+    while len(b) < n:
+        a, b = b, b + a
+    return b[:n]
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("name", ["allA_8M", "period3_4M", "fib_4M", "abracadabra_x400k", "two_long_copies_8M",
+                                  "long_copy_with_edits_6M"])
+def test_pathological_repeats(native, name):
+    """Huge LCPs (runs, periodic texts, long exact duplications): the direct round bails out,
+    doubling rounds + range-minimum LCPs take over; results must still be bit-exact and fast."""
+    import time
+    if name == "allA_8M":
+        t = b"A" * (1 << 23)
+    elif name == "period3_4M":
+        t = (b"ACG" * ((1 << 22) // 3 + 1))[:1 << 22]
+    elif name == "fib_4M":
+        t = _fib(1 << 22)
+    elif name == "abracadabra_x400k":
+        t = b"abracadabra" * 400_000
+    elif name == "two_long_copies_8M":
+        x = gen.random_dna(1 << 22, 71).tobytes()
+        t = x + x
+    else:
+        x = bytearray(gen.random_dna(3 << 20, 72).tobytes())
+        y = bytearray(x)
+        for p in range(1000, len(y), 400_003):   # a handful of point edits in the second copy
+            y[p] = ord("A") if y[p] != ord("A") else ord("C")
+        t = bytes(x + y)
+    native.count_factors(b"ACGT" * 100)
+    t0 = time.time()
+    got = native.factorize_array(t)
+    dt = time.time() - t0
+    exp = oracle.factors_array(t)
+    assert len(got) == len(exp)
+    for k in ("start", "length", "ref"):
+        assert np.array_equal(got[k], exp[k]), k
+    assert dt < 5.0, f"{name}: {dt:.2f} s"
+
+
+@pytest.mark.timeout(900)
+def test_rc_long_palindromic_repeat(native):
+    """reverse-complement mode with a long exact inverted repeat (LCP in the joint text ~ 1 Mi)"""
+    x = gen.random_dna(1 << 20, 73)
+    t = np.concatenate([x, gen.random_dna(1000, 74), COMP[x[::-1]]])
+    got = native.factorize_dna_w_rc_array(t)
+    S, _, _ = oracle.prepare_multiple_dna_w_rc([t.tobytes()])
+    exp = oracle.factors_array_multiple_dna_w_rc(S)
+    assert len(got) == len(exp)
+    for k in ("start", "length", "ref"):
+        assert np.array_equal(got[k], exp[k]), k
+    assert (got["ref"] >> np.uint64(63)).sum() >= 1
