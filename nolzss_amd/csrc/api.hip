@@ -3,6 +3,7 @@
 #include "../../include/nolzss_hip.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -40,13 +41,16 @@ constexpr size_t kMaxText = 0xffffffffull - (1ull << 16);  // 32-bit index pipel
 
 size_t arena_bytes_for(size_t n) { return 100 * n + (size_t(64) << 20); }
 
-DeviceContext &get_context(int device) {
+constexpr int kMaxLanes = 16;  // concurrent pipelines (stream + arena each) per device
+
+DeviceContext &get_context(int device, int lane = 0) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
         throw HipError("no HIP device available: libnolzss_hip has no CPU fallback");
     if (device < 0 || device >= count) throw std::invalid_argument("device ordinal out of range");
+    if (lane < 0 || lane >= kMaxLanes) throw std::invalid_argument("lane out of range");
     std::lock_guard<std::mutex> lk(g_ctx_mu);
-    auto &slot = g_ctx[device];
+    auto &slot = g_ctx[device * kMaxLanes + lane];
     if (!slot) slot = std::make_unique<DeviceContext>();
     return *slot;
 }
@@ -56,7 +60,7 @@ struct Session {
     DeviceContext &dc;
     std::unique_lock<std::mutex> lk;
     hipStream_t own_stream;
-    Session(int device, void *user_stream) : dc(get_context(device)), lk(dc.mu) {
+    Session(int device, void *user_stream, int lane = 0) : dc(get_context(device, lane)), lk(dc.mu) {
         HIP_CHECK(hipSetDevice(device));
         if (!dc.ready) {
             dc.ctx.device = device;
@@ -680,24 +684,39 @@ int nolzss_factorize_batch(const uint8_t *const *texts, const size_t *lens, size
             plan[d].push_back(j);
             load[d] += lens[j];
         }
-        std::vector<int> status(n_dev, NOLZSS_OK);
-        std::vector<std::string> messages(n_dev);
-        auto worker = [&](size_t d) {
-            status[d] = guarded([&] {
-                Session ses(devices[d], nullptr);
-                for (size_t j : plan[d])
+        // Several pipelines per device: a 4 Mi-base sequence neither fills the GPU for long nor
+        // hides its own launch / read-back gaps, so each device runs `lanes` sequences at a time,
+        // every lane with its own stream and arena, fed from the device's queue.
+        static const size_t lanes = [] {
+            const char *e = getenv("NOLZSS_BATCH_LANES");
+            const long v = e ? atol(e) : 4;
+            return (size_t)(v < 1 ? 1 : (v > kMaxLanes ? kMaxLanes : v));
+        }();
+        std::vector<int> status(n_dev * lanes, NOLZSS_OK);
+        std::vector<std::string> messages(n_dev * lanes);
+        std::vector<std::atomic<size_t>> next(n_dev);
+        for (auto &a : next) a.store(0);
+        auto worker = [&](size_t d, size_t lane) {
+            const size_t w = d * lanes + lane;
+            status[w] = guarded([&] {
+                Session ses(devices[d], nullptr, (int)lane);
+                for (;;) {
+                    const size_t k = next[d].fetch_add(1);
+                    if (k >= plan[d].size()) break;
+                    const size_t j = plan[d][k];
                     zs[j] = run_plain_host(ses.ctx(), texts[j], lens[j], 0, fs ? &fs[j] : nullptr, nullptr);
+                }
             });
-            if (status[d] != NOLZSS_OK) messages[d] = g_error;
+            if (status[w] != NOLZSS_OK) messages[w] = g_error;
         };
-        if (n_dev == 1) {
-            worker(0);
-        } else {
+        {
             std::vector<std::thread> threads;
-            for (size_t d = 0; d < n_dev; ++d) threads.emplace_back(worker, d);
+            for (size_t d = 0; d < n_dev; ++d)
+                for (size_t lane = 0; lane < lanes; ++lane)
+                    if (lane < plan[d].size()) threads.emplace_back(worker, d, lane);
             for (auto &t : threads) t.join();
         }
-        for (size_t d = 0; d < n_dev; ++d)
+        for (size_t d = 0; d < status.size(); ++d)
             if (status[d] != NOLZSS_OK) {
                 if (fs) {
                     for (size_t j = 0; j < m; ++j) std::free(fs[j]);
