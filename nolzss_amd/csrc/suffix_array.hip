@@ -726,9 +726,18 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     }
     int cur;
     {
-        const int shifts[8] = {0, 8, 16, 24, 32, 40, 48, 56};
+        // only the low key_bits of the key are populated
+        int key_bits = k_syms * text.bits;
+        switch (text.bits) {
+        case 2: key_bits += KeyLayout<2>::kTagBits; break;
+        case 4: key_bits += KeyLayout<4>::kTagBits; break;
+        default: key_bits += KeyLayout<8>::kTagBits; break;
+        }
+        if (text.segmented) key_bits = kSegSyms * 2 + kSegTagBits + kSegTermBits;
+        int shifts0[8], np0 = 0;
+        for (int b = 0; b < key_bits && np0 < 8; b += kRadixBits) shifts0[np0++] = b;
         ProfScope ps(ctx.profiler(), "sa_sort_initial", s);
-        cur = radix_sort_pairs(keys, vals, n, shifts, 8, arena, s, ctx.profiler());
+        cur = radix_sort_pairs(keys, vals, n, shifts0, np0, arena, s, ctx.profiler());
     }
     int tag_bits = 0, low_bits = 0;
     switch (text.bits) {
