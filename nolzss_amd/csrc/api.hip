@@ -39,7 +39,7 @@ std::map<int, std::unique_ptr<DeviceContext>> g_ctx;
 
 constexpr size_t kMaxText = 0xffffffffull - (1ull << 16);  // 32-bit index pipeline
 
-size_t arena_bytes_for(size_t n) { return 100 * n + (size_t(64) << 20); }
+size_t arena_bytes_for(size_t n) { return 108 * n + (size_t(64) << 20); }
 
 constexpr int kMaxLanes = 16;  // concurrent pipelines (stream + arena each) per device
 

@@ -208,7 +208,8 @@ __global__ __launch_bounds__(kThreads) void commit_kernel(const uint64_t *__rest
                                                           uint32_t *__restrict__ keep,
                                                           uint32_t *__restrict__ lcp, int sym_bits, int tag_bits,
                                                           int bits, const uint32_t *__restrict__ lcp_list,
-                                                          int low_bits, uint32_t dbl_h, Pyramid Plcp) {
+                                                          int low_bits, uint32_t dbl_h, Pyramid Plcp,
+                                                          uint32_t *__restrict__ rank_by_slot) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x; a < m; a += stride) {
         const bool head = is_head<kRound0>(keys, grp, lo, a);
@@ -216,7 +217,10 @@ __global__ __launch_bounds__(kThreads) void commit_kernel(const uint64_t *__rest
         const uint32_t slot = kRound0 ? (uint32_t)a : act_slot[a];
         const uint32_t i = vals[a];
         sa[slot] = i;
-        rank_val[a] = head_of[a] + 1u;  // goes to rank[i] through bucketed_scatter
+        if (rank_by_slot)
+            rank_by_slot[slot] = head_of[a] + 1u;  // rank[] itself is written later, in one pass
+        else
+            rank_val[a] = head_of[a] + 1u;  // goes to rank[i] through bucketed_scatter
         keep[a] = (head && next_head) ? 0u : 1u;
         if (!kRound0) {
             // a new boundary inside an old group
@@ -356,8 +360,8 @@ template <int BITS>
 __global__ __launch_bounds__(kThreads) void group_refine_kernel(
     const uint32_t *__restrict__ act_slot, const uint32_t *__restrict__ act_grp, const uint32_t *__restrict__ gsize,
     const uint32_t *__restrict__ sa, const uint64_t *__restrict__ words, TermTable terms, uint32_t m, uint32_t h0,
-    uint32_t cap, uint32_t *__restrict__ out_lo, uint32_t *__restrict__ out_vals, uint32_t *__restrict__ lcp_list,
-    uint32_t *__restrict__ large_flag) {
+    uint32_t cap, uint32_t *__restrict__ out_lo, uint32_t *__restrict__ out_vals,
+    uint32_t *__restrict__ lcp_list) {
     constexpr uint32_t kPerWord = 64 / BITS;
     constexpr int kPerThread = (kRefineSpan + kThreads - 1) / kThreads;
     __shared__ uint64_t s_w0[kRefineSpan], s_w1[kRefineSpan];
@@ -387,7 +391,10 @@ __global__ __launch_bounds__(kThreads) void group_refine_kernel(
             const uint32_t slot = act_slot[a];
             const size_t g0 = a - (slot - g);
             const uint32_t sz = gsize[g0];
-            if (a < a1) large_flag[a] = sz > kSmallGroup ? 1u : 0u;
+            if (a < a1 && sz > kSmallGroup) {  // too large for this round: stays one group, in place
+                out_lo[a] = 0;
+                out_vals[a] = sa[slot];
+            }
             mine = g0 >= a0 && g0 < a1 && sz <= kSmallGroup;
             if (mine) {
                 my_gs[j] = (uint8_t)sz;
@@ -504,23 +511,6 @@ __global__ __launch_bounds__(kThreads) void group_refine_kernel(
     }
 }
 
-__global__ __launch_bounds__(kThreads) void gather_large_direct_kernel(
-    const uint32_t *__restrict__ large_flag, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ act_slot,
-    const uint32_t *__restrict__ act_grp, const uint32_t *__restrict__ sa, const uint32_t *__restrict__ rank,
-    uint32_t n, uint32_t h, uint32_t m, uint64_t *__restrict__ lkeys, uint32_t *__restrict__ lvals,
-    uint32_t *__restrict__ lidx) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x; a < m; a += stride)
-        if (large_flag[a]) {
-            const uint32_t k = idx[a];
-            const uint32_t i = sa[act_slot[a]];
-            const uint32_t lo = (n - i > h) ? rank[i + h] : 0u;
-            lkeys[k] = ((uint64_t)act_grp[a] << 32) | lo;
-            lvals[k] = i;
-            lidx[k] = (uint32_t)a;
-        }
-}
-
 __global__ __launch_bounds__(kThreads) void gather_large_kernel(const uint32_t *__restrict__ large_flag,
                                                                 const uint32_t *__restrict__ idx,
                                                                 const uint32_t *__restrict__ act_grp,
@@ -575,7 +565,7 @@ uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *grp, const 
                  uint32_t *new_grp, uint32_t *tmp_a, uint32_t *tmp_b, uint32_t *tmp_c, uint32_t *scratch_idx,
                  uint32_t *scratch_val, uint32_t *rank_val, uint32_t *d_total, uint32_t *lcp = nullptr,
                  int sym_bits = 0, int tag_bits = 0, int bits = 0, const uint32_t *lcp_list = nullptr,
-                 int low_bits = 0, uint32_t dbl_h = 0) {
+                 int low_bits = 0, uint32_t dbl_h = 0, uint32_t *rank_by_slot = nullptr) {
     hipStream_t s = ctx.stream;
     const size_t pmark = ctx.arena.mark();
     Pyramid Plcp{};
@@ -597,11 +587,11 @@ uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *grp, const 
         commit_kernel<kRound0><<<grid_for(m, kThreads), kThreads, 0, s>>>(keys, grp, lo, vals, act_slot, tmp_a, m,
                                                                           sa, rank_val, tmp_b, lcp, sym_bits,
                                                                           tag_bits, bits, lcp_list, low_bits, dbl_h,
-                                                                          Plcp);
+                                                                          Plcp, rank_by_slot);
         KERNEL_CHECK();
     }
     ctx.arena.rewind(pmark);
-    {
+    if (!rank_by_slot) {
         // rank[vals[a]] = rank_val[a]: the one truly random write of the round
         ProfScope ps(ctx.profiler(), "sa_rank_scatter", s);
         uint32_t *idx[2] = {vals, scratch_idx};
@@ -712,6 +702,7 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     uint32_t *tmp_b = arena.alloc<uint32_t>(n);
     uint32_t *tmp_c = arena.alloc<uint32_t>(n);
     uint32_t *rank_val = arena.alloc<uint32_t>(n);
+    uint32_t *rank_by_slot = arena.alloc<uint32_t>(n);
     uint32_t *scratch_idx = arena.alloc<uint32_t>(n);
     uint32_t *scratch_val = arena.alloc<uint32_t>(n);
     uint32_t *d_total = arena.alloc<uint32_t>(2);
@@ -752,7 +743,7 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     }
     uint32_t m = regroup<true>(ctx, keys[cur], nullptr, nullptr, vals[cur], nullptr, n, n, sa, rank, act_slot[0],
                                act_grp[0], tmp_a, tmp_b, tmp_c, scratch_idx, scratch_val, rank_val, d_total, lcp,
-                               k_syms * text.bits, tag_bits, text.bits, nullptr, low_bits);
+                               k_syms * text.bits, tag_bits, text.bits, nullptr, low_bits, 0, rank_by_slot);
 
     // ---- doubling rounds ------------------------------------------------------------------
     // in the rounds the 8n-byte key buffers are reused as four u32 arrays
@@ -770,7 +761,17 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     int rounds = 0, a_cur = 0;
     uint64_t h = (uint64_t)k_syms;
 
+    // one pass writes rank[] for everybody: rank[sa[slot]] = rank_by_slot[slot]
+    auto write_all_ranks = [&] {
+        ProfScope ps(ctx.profiler(), "sa_rank_scatter", s);
+        uint32_t *idx[2] = {sa, scratch_idx};
+        uint32_t *val[2] = {rank_by_slot, scratch_val};
+        bucketed_scatter(idx, val, n, rank, n, arena, s, ctx.profiler(), true);
+    };
+
     // ---- direct round: small groups are finished by comparing packed suffixes ---------------
+    // (groups larger than kSmallGroup stay as they are; rank[] is not needed before the doubling
+    // rounds, so it is written once, after this round, instead of after each of the two)
     if (m > 0 && h < n) {
         const uint32_t *slot = act_slot[a_cur], *grp = act_grp[a_cur];
         uint32_t *lcp_list = arena.alloc<uint32_t>(m);
@@ -788,45 +789,26 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
             switch (text.bits) {
             case 2:
                 group_refine_kernel<2><<<g, kThreads, 0, s>>>(slot, grp, gsize, sa, text.words, text.terms, m, (uint32_t)h, cap,
-                                                              out_lo, out_vals, lcp_list, tmp_a);
+                                                              out_lo, out_vals, lcp_list);
                 break;
             case 4:
                 group_refine_kernel<4><<<g, kThreads, 0, s>>>(slot, grp, gsize, sa, text.words, text.terms, m, (uint32_t)h, cap,
-                                                              out_lo, out_vals, lcp_list, tmp_a);
+                                                              out_lo, out_vals, lcp_list);
                 break;
             default:
                 group_refine_kernel<8><<<g, kThreads, 0, s>>>(slot, grp, gsize, sa, text.words, text.terms, m, (uint32_t)h, cap,
-                                                              out_lo, out_vals, lcp_list, tmp_a);
+                                                              out_lo, out_vals, lcp_list);
                 break;
             }
             KERNEL_CHECK();
-            scan_exclusive_add_u32(tmp_a, tmp_b, m, d_total, arena, s);
-        }
-        uint32_t counts2[1] = {0};
-        ctx.read_back(d_total, counts2, 1);
-        const uint32_t n_large = counts2[0];
-        if (n_large > 0) {  // groups larger than kSmallGroup take a doubling step instead
-            ProfScope ps(ctx.profiler(), "sa_sort_large", s);
-            const size_t lmark = arena.mark();
-            uint64_t *lk[2] = {keys[1], arena.alloc<uint64_t>(n_large)};
-            uint32_t *lv[2] = {arena.alloc<uint32_t>(n_large), arena.alloc<uint32_t>(n_large)};
-            uint32_t *lidx = tmp_c;
-            gather_large_direct_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(tmp_a, tmp_b, slot, grp, sa, rank, n,
-                                                                                  (uint32_t)h, m, lk[0], lv[0], lidx);
-            KERNEL_CHECK();
-            const int c = radix_sort_pairs(lk, lv, n_large, shifts, npasses, arena, s, ctx.profiler());
-            scatter_large_kernel<<<grid_for(n_large, kThreads), kThreads, 0, s>>>(lk[c], lv[c], lidx, n_large, out_lo,
-                                                                                  out_vals, lcp_list, kLcpPending);
-            KERNEL_CHECK();
-            arena.rewind(lmark);
         }
         m = regroup<false>(ctx, nullptr, grp, out_lo, out_vals, slot, m, n, sa, rank, act_slot[a_cur ^ 1],
                            act_grp[a_cur ^ 1], tmp_a, tmp_b, tmp_c, scratch_idx, scratch_val, rank_val, d_total, lcp,
-                           0, 0, 0, lcp_list, 0, (uint32_t)h);
+                           0, 0, 0, lcp_list, 0, (uint32_t)h, rank_by_slot);
         a_cur ^= 1;
-        h *= 2;
-        ++rounds;
+        // h stays K: the large groups are only K-sorted
     }
+    write_all_ranks();
 
     while (m > 0) {
         if (h >= n || rounds > 40) throw HipError("suffix array: prefix doubling failed to converge");
