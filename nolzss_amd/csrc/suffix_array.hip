@@ -143,9 +143,9 @@ __global__ __launch_bounds__(kThreads) void initial_keys_kernel(const uint64_t *
         const uint32_t k = term_lower_bound(terms, (uint32_t)i);
         const uint32_t lim = terms.pos[k] - (uint32_t)i;  // symbols before the next terminator
         if (BITS == 2 && segmented) {
-            // [25 symbols][5-bit tag][8-bit terminator index]: a suffix that meets a terminator
+            // [kSegSyms symbols][5-bit tag][8-bit terminator index]: a suffix that meets a terminator
             // inside the key window gets a key of its own, so every group left after the sort
-            // consists of suffixes that agree on 25 real nucleotides
+            // consists of suffixes that agree on kSegSyms real nucleotides
             const uint32_t tag = lim < (uint32_t)kSegSyms ? lim : (uint32_t)kSegSyms;
             uint64_t sym = w >> (64 - kSegSyms * 2);
             if (tag < (uint32_t)kSegSyms) sym &= ~((1ull << (2 * (kSegSyms - tag))) - 1ull);
@@ -736,7 +736,7 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     case 4: tag_bits = KeyLayout<4>::kTagBits; break;
     default: tag_bits = KeyLayout<8>::kTagBits; break;
     }
-    if (text.segmented) {  // [25 symbols][5-bit tag][8-bit terminator index]
+    if (text.segmented) {  // [kSegSyms symbols][5-bit tag][8-bit terminator index]
         k_syms = kSegSyms;
         tag_bits = kSegTagBits;
         low_bits = kSegTermBits;

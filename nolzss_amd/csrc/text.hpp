@@ -43,8 +43,8 @@ struct PackedText {
     bool segmented = false;  // terminators inside the text (packed as code 0, never compared)
 };
 
-// segmented texts: key = [25 symbols][5-bit length tag][8-bit terminator index]
-constexpr int kSegSyms = 25, kSegTagBits = 5, kSegTermBits = 8;
+// segmented texts: key = [17 symbols][5-bit length tag][8-bit terminator index]
+constexpr int kSegSyms = 17, kSegTagBits = 5, kSegTermBits = 8;  // 47 key bits: 6 radix passes
 
 // Symbols per initial sort key and width of the length tag that breaks ties between a
 // suffix that ends inside the key window and its zero-padded longer neighbours.
