@@ -153,6 +153,8 @@ int nolzss_debug_arrays(const uint8_t *text, size_t n, int device, uint32_t *sa,
 int nolzss_debug_sort_pairs(uint64_t *keys, uint32_t *vals, size_t n, int device);
 /* mode 0: exclusive add-scan, mode 1: inclusive max-scan, in place. */
 int nolzss_debug_scan(uint32_t *data, size_t n, int mode, int device);
+/* Capacity and high-water mark (bytes) of the device arena of `device` (lane 0). */
+int nolzss_debug_arena(int device, size_t *capacity, size_t *peak);
 
 #ifdef __cplusplus
 }

@@ -61,6 +61,7 @@ def _load():
     lib.nolzss_debug_arrays.argtypes = [vp, sz, C.c_int, vp, vp, vp, vp]
     lib.nolzss_debug_sort_pairs.argtypes = [vp, vp, sz, C.c_int]
     lib.nolzss_debug_scan.argtypes = [vp, sz, C.c_int, C.c_int]
+    lib.nolzss_debug_arena.argtypes = [C.c_int, szp, szp]
     return lib
 
 
@@ -76,7 +77,7 @@ EXPORTED_SYMBOLS = [
     "nolzss_write_factors_binary_file", "nolzss_write_factors_binary_file_dna_w_rc",
     "nolzss_factorize_w_reference_file", "nolzss_factorize_dna_w_reference_seq_file",
     "nolzss_free_batch", "nolzss_profile_enable", "nolzss_profile_reset", "nolzss_profile_report",
-    "nolzss_debug_arrays", "nolzss_debug_sort_pairs", "nolzss_debug_scan",
+    "nolzss_debug_arrays", "nolzss_debug_sort_pairs", "nolzss_debug_scan", "nolzss_debug_arena",
 ]
 
 

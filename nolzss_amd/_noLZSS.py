@@ -333,6 +333,13 @@ def debug_sort_pairs(keys, vals):
     return keys, vals
 
 
+def debug_arena():
+    """(capacity, high-water mark) in bytes of the device arena."""
+    cap, peak = C.c_size_t(), C.c_size_t()
+    check(lib.nolzss_debug_arena(_default_device, C.byref(cap), C.byref(peak)))
+    return cap.value, peak.value
+
+
 def debug_scan(data, mode: int):
     data = np.ascontiguousarray(data, dtype=np.uint32).copy()
     check(lib.nolzss_debug_scan(data.ctypes.data, data.size, mode, _default_device))

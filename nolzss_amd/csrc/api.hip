@@ -806,6 +806,15 @@ int nolzss_debug_sort_pairs(uint64_t *keys, uint32_t *vals, size_t n, int device
     });
 }
 
+int nolzss_debug_arena(int device, size_t *capacity, size_t *peak) {
+    return guarded([&] {
+        if (!capacity || !peak) throw std::invalid_argument("output pointer is null");
+        Session ses(device, nullptr);
+        *capacity = ses.ctx().arena.capacity();
+        *peak = ses.ctx().arena.peak();
+    });
+}
+
 int nolzss_debug_scan(uint32_t *data, size_t n, int mode, int device) {
     return guarded([&] {
         if (n == 0) return;

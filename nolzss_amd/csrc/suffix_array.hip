@@ -16,8 +16,6 @@
 #include "radix_sort.hpp"
 #include "scan.hpp"
 
-#include <cstdlib>
-
 namespace nolzss {
 
 void Context::read_back(const uint32_t *d_src, uint32_t *dst, int count) {
@@ -775,11 +773,8 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     if (m > 0 && h < n) {
         const uint32_t *slot = act_slot[a_cur], *grp = act_grp[a_cur];
         uint32_t *lcp_list = arena.alloc<uint32_t>(m);
-        static const uint32_t refine_words = [] {
-            const char *e = getenv("NOLZSS_REFINE_WORDS");
-            return e ? (uint32_t)atoi(e) : 64u;
-        }();
-        const uint32_t cap = (uint32_t)k_syms + refine_words * (64u / (uint32_t)text.bits);
+        // at most 64 words (2048 bases) deep; longer ties are cheaper in the doubling rounds
+        const uint32_t cap = (uint32_t)k_syms + 64u * (64u / (uint32_t)text.bits);
         uint32_t *gsize = arena.alloc<uint32_t>(m);
         {
             ProfScope ps(ctx.profiler(), "sa_direct_sort", s);

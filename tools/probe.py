@@ -38,13 +38,15 @@ def main():
         rep_stats = native.profile_report()
         print(f"rep {rep}: z={z} wall={dt*1e3:.1f} ms  {n/dt/1e6:.1f} Mbases/s", flush=True)
     tot = 0.0
-    nested = {"rs_hist", "rs_scan", "rs_scatter"}
+    nested = {"rs_hist", "rs_scan", "rs_scatter", "bucket_scatter", "window_scatter"}
     for name, (cnt, ms, nbytes) in sorted(rep_stats.items(), key=lambda kv: -kv[1][1]):
         extra = f"  {nbytes/ms/1e6:8.1f} GB/s" if nbytes else ""
         print(f"  {name:18s} x{cnt:4d} {ms:10.3f} ms{extra}")
         if name not in nested:
             tot += ms
     print(f"  sum of top-level stages {tot:.1f} ms")
+    cap, peak = native.debug_arena()
+    print(f"  arena: capacity {cap/2**30:.2f} GiB, peak {peak/2**30:.2f} GiB = {peak/n:.1f} bytes/base")
     native.profile_enable(False)
     if a.check:
         import oracle_lib as oracle
