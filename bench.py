@@ -78,17 +78,22 @@ def main():
     ap.add_argument("--log2n", type=int, default=30, help="bases per GPU = 2^log2n (default 2^30)")
     ap.add_argument("--cpu-sample-log2", type=int, default=26)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for N > 1 (nccl = RCCL over xGMI; gloo only for rehearsals)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="rehearsal on a one-GPU box: every rank uses cuda:0 (needs --backend gloo)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if a.same_device else int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local_rank)
     native.set_device(local_rank)
@@ -96,8 +101,9 @@ def main():
     n = 1 << a.log2n
     text = make_text(a.workload, n, rank)
     d_text = torch.from_numpy(text).to(dev)
-    counts = torch.zeros(world, dtype=torch.int64, device=dev)
-    mine = torch.zeros(1, dtype=torch.int64, device=dev)
+    cdev = dev if a.backend == "nccl" else torch.device("cpu")
+    counts = torch.zeros(world, dtype=torch.int64, device=cdev)
+    mine = torch.zeros(1, dtype=torch.int64, device=cdev)
 
     def barrier():
         if world > 1:
@@ -124,7 +130,7 @@ def main():
     stats = native.profile_report()
     native.profile_enable(False)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
