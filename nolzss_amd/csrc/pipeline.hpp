@@ -19,10 +19,9 @@ struct Context {
 
 // ---- stage 1: text packing -------------------------------------------------------------
 // Scans the byte text for its alphabet, builds dense codes and packs it (2/4/8 bits/symbol).
-// With a terminator list (sorted positions of unique non-nucleotide bytes in an otherwise ACGT
-// text) the text is packed SEGMENTED at 2 bits per base (text.hpp).
-PackedText pack_text(Context &ctx, const uint8_t *d_text, size_t n,
-                     const std::vector<uint32_t> *terminators = nullptr);
+// A text of upper-case nucleotides plus at most 250 byte values that occur exactly once each is
+// packed SEGMENTED at 2 bits per base, the unique bytes becoming terminators (text.hpp).
+PackedText pack_text(Context &ctx, const uint8_t *d_text, size_t n);
 
 // ---- stages 2+3: suffix array (prefix doubling over radix sorts) and LCP array -------------
 // sa[r] = start of the r-th smallest suffix, isa[i] = rank of suffix i (n u32 each);

@@ -16,8 +16,6 @@
 //   selection  (:338-352)  forward wins ties; RC must beat the forward match, or 1 if none.
 // When the best forward neighbour does not overlap position i (the common case) L_f is an LCA
 // depth, hence explicit, and fwd = L_f directly; only overlapping positions take the exact path.
-#include <algorithm>
-
 #include "nearest_lds.hpp"
 #include "pipeline.hpp"
 #include "radix_sort.hpp"
@@ -182,57 +180,6 @@ __global__ __launch_bounds__(kThreads) void rc_prepare_kernel(const uint8_t *__r
     }
 }
 
-// positions and byte values of everything that is not an upper-case nucleotide (at most
-// kMaxTermScan are recorded; the count keeps running)
-constexpr uint32_t kMaxTermScan = 512;
-
-__global__ __launch_bounds__(kThreads) void find_terminators_kernel(const uint8_t *__restrict__ S, uint32_t m,
-                                                                    uint32_t *__restrict__ count,
-                                                                    uint32_t *__restrict__ pos_out,
-                                                                    uint32_t *__restrict__ byte_out) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
-        const uint8_t c = S[i];
-        if (c != 'A' && c != 'C' && c != 'G' && c != 'T') {
-            const uint32_t k = atomicAdd(count, 1u);
-            if (k < kMaxTermScan) {
-                pos_out[k] = (uint32_t)i;
-                byte_out[k] = c;
-            }
-        }
-    }
-}
-
-// Terminator positions of a prepared string if it has the shape the reference's prepare step
-// produces -- nucleotides plus at most 250 pairwise distinct other bytes -- else empty (the
-// caller then packs the text as ordinary bytes, which is correct for any input).
-std::vector<uint32_t> detect_terminators(Context &ctx, const uint8_t *d_S, uint32_t m, bool &ok) {
-    uint32_t *count = ctx.arena.alloc<uint32_t>(1);
-    uint32_t *pos = ctx.arena.alloc<uint32_t>(kMaxTermScan);
-    uint32_t *byt = ctx.arena.alloc<uint32_t>(kMaxTermScan);
-    HIP_CHECK(hipMemsetAsync(count, 0, sizeof(uint32_t), ctx.stream));
-    size_t g = div_up(m, kThreads);
-    if (g > 8192) g = 8192;
-    find_terminators_kernel<<<(unsigned)g, kThreads, 0, ctx.stream>>>(d_S, m, count, pos, byt);
-    KERNEL_CHECK();
-    uint32_t h_count = 0;
-    ctx.read_back(count, &h_count, 1);
-    ok = false;
-    std::vector<uint32_t> res;
-    if (h_count == 0 || h_count > 250) return res;
-    std::vector<uint32_t> h_pos(h_count), h_byte(h_count);
-    HIP_CHECK(hipMemcpy(h_pos.data(), pos, h_count * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    HIP_CHECK(hipMemcpy(h_byte.data(), byt, h_count * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    bool seen[256] = {false};
-    for (uint32_t b : h_byte) {
-        if (seen[b & 255]) return res;  // a repeated non-nucleotide byte can match itself
-        seen[b & 255] = true;
-    }
-    std::sort(h_pos.begin(), h_pos.end());
-    ok = true;
-    return h_pos;
-}
-
 }  // namespace
 
 uint32_t prepare_single_rc_on_device(Context &ctx, const uint8_t *d_T, uint32_t n, uint8_t *d_S) {
@@ -256,9 +203,7 @@ uint32_t run_rc_pipeline(Context &ctx, const uint8_t *d_S, size_t m_sz, size_t s
     hipStream_t s = ctx.stream;
     Arena &arena = ctx.arena;
 
-    bool segmented = false;
-    const std::vector<uint32_t> terminators = detect_terminators(ctx, d_S, m, segmented);
-    PackedText text = pack_text(ctx, d_S, m, segmented ? &terminators : nullptr);
+    PackedText text = pack_text(ctx, d_S, m);  // segmented 2-bit packing is detected there
     uint32_t *sa = arena.alloc<uint32_t>(m);
     uint32_t *isa = arena.alloc<uint32_t>(m);
     uint32_t *lcp = arena.alloc<uint32_t>((size_t)m + 1);

@@ -16,6 +16,8 @@
 #include "radix_sort.hpp"
 #include "scan.hpp"
 
+#include <algorithm>
+
 namespace nolzss {
 
 void Context::read_back(const uint32_t *d_src, uint32_t *dst, int count) {
@@ -72,6 +74,23 @@ __global__ __launch_bounds__(kThreads) void presence_kernel(const uint8_t *__res
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) v |= __shfl_xor(v, d, 64);
         if (lane_id() == 0 && v) atomicOr(&presence[k], (unsigned long long)v);
+    }
+}
+
+// positions of everything that is not an upper-case nucleotide (at most kMaxTermScan are
+// recorded; the count keeps running)
+constexpr uint32_t kMaxTermScan = 512;
+
+__global__ __launch_bounds__(kThreads) void find_terminators_kernel(const uint8_t *__restrict__ text, uint32_t n,
+                                                                    uint32_t *__restrict__ count,
+                                                                    uint32_t *__restrict__ pos_out) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint8_t c = text[i];
+        if (c != 'A' && c != 'C' && c != 'G' && c != 'T') {
+            const uint32_t k = atomicAdd(count, 1u);
+            if (k < kMaxTermScan) pos_out[k] = (uint32_t)i;
+        }
     }
 }
 
@@ -613,38 +632,62 @@ uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *grp, const 
 
 }  // namespace
 
-PackedText pack_text(Context &ctx, const uint8_t *d_text, size_t n, const std::vector<uint32_t> *terminators) {
+PackedText pack_text(Context &ctx, const uint8_t *d_text, size_t n) {
     hipStream_t s = ctx.stream;
     PackedText t;
     t.n = (uint32_t)n;
     unsigned long long *presence = ctx.arena.alloc<unsigned long long>(4);
-    if (terminators) {
-        // segmented text: only the nucleotides are symbols (A < C < G < T -> 0..3); the unique
-        // terminator bytes pack as code 0 and are never compared
-        unsigned long long h_presence[4] = {0, 0, 0, 0};
-        for (unsigned char c : {'A', 'C', 'G', 'T'}) h_presence[c >> 6] |= 1ull << (c & 63);
-        HIP_CHECK(hipMemcpyAsync(presence, h_presence, 32, hipMemcpyHostToDevice, s));
-        HIP_CHECK(hipStreamSynchronize(s));  // h_presence is a stack buffer
-        t.sigma = 4;
-        t.bits = 2;
-        t.segmented = true;
-    } else {
-        HIP_CHECK(hipMemsetAsync(presence, 0, 32, s));
-        {
-            ProfScope ps(ctx.profiler(), "text_presence", s);
-            presence_kernel<<<grid_for(div_up(n, 16), kThreads, 2048), kThreads, 0, s>>>(d_text, n, presence);
-            KERNEL_CHECK();
+    HIP_CHECK(hipMemsetAsync(presence, 0, 32, s));
+    {
+        ProfScope ps(ctx.profiler(), "text_presence", s);
+        presence_kernel<<<grid_for(div_up(n, 16), kThreads, 2048), kThreads, 0, s>>>(d_text, n, presence);
+        KERNEL_CHECK();
+    }
+    uint32_t bitsw[8];
+    ctx.read_back(reinterpret_cast<const uint32_t *>(presence), bitsw, 8);
+    int sigma = 0;
+    for (int k = 0; k < 8; ++k) sigma += __builtin_popcount(bitsw[k]);
+    t.sigma = sigma;
+    t.bits = sigma <= 4 ? 2 : (sigma <= 16 ? 4 : 8);
+
+    // Segmented text?  Upper-case nucleotides plus at most 250 other byte values that occur
+    // exactly ONCE each (the shape of the reference's prepared multi-sequence / reverse-
+    // complement strings, and of reference + '\\x01' + target): a byte that occurs once can match
+    // nothing, so it only terminates matches and the text packs at 2 bits per base.
+    std::vector<uint32_t> terminators;
+    {
+        uint32_t acgt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (unsigned char c : {'A', 'C', 'G', 'T'}) acgt[c >> 5] |= 1u << (c & 31);
+        int others = 0, nucleotides = 0;
+        for (int k = 0; k < 8; ++k) {
+            others += __builtin_popcount(bitsw[k] & ~acgt[k]);
+            nucleotides += __builtin_popcount(bitsw[k] & acgt[k]);
         }
-        uint32_t bitsw[8];
-        ctx.read_back(reinterpret_cast<const uint32_t *>(presence), bitsw, 8);
-        int sigma = 0;
-        for (int k = 0; k < 8; ++k) sigma += __builtin_popcount(bitsw[k]);
-        t.sigma = sigma;
-        t.bits = sigma <= 4 ? 2 : (sigma <= 16 ? 4 : 8);
+        if (others >= 1 && others <= 250 && nucleotides >= 1) {
+            uint32_t *count = ctx.arena.alloc<uint32_t>(1);
+            uint32_t *pos = ctx.arena.alloc<uint32_t>(kMaxTermScan);
+            HIP_CHECK(hipMemsetAsync(count, 0, sizeof(uint32_t), s));
+            size_t g = div_up(n, kThreads);
+            if (g > 8192) g = 8192;
+            find_terminators_kernel<<<(unsigned)g, kThreads, 0, s>>>(d_text, (uint32_t)n, count, pos);
+            KERNEL_CHECK();
+            uint32_t h_count = 0;
+            ctx.read_back(count, &h_count, 1);
+            if (h_count == (uint32_t)others) {  // every non-nucleotide byte value occurs exactly once
+                terminators.resize(h_count);
+                HIP_CHECK(hipMemcpy(terminators.data(), pos, h_count * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                std::sort(terminators.begin(), terminators.end());
+                unsigned long long h_presence[4] = {0, 0, 0, 0};
+                for (unsigned char c : {'A', 'C', 'G', 'T'}) h_presence[c >> 6] |= 1ull << (c & 63);
+                HIP_CHECK(hipMemcpy(presence, h_presence, 32, hipMemcpyHostToDevice));
+                t.sigma = 4;
+                t.bits = 2;
+                t.segmented = true;
+            }
+        }
     }
     // terminator table: the given positions (sorted) and always the end of the text
-    std::vector<uint32_t> table;
-    if (terminators) table = *terminators;
+    std::vector<uint32_t> table = terminators;
     table.push_back((uint32_t)n);
     uint32_t *d_terms = ctx.arena.alloc<uint32_t>(table.size());
     HIP_CHECK(hipMemcpyAsync(d_terms, table.data(), table.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
