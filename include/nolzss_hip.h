@@ -126,6 +126,41 @@ int nolzss_factorize_dna_w_reference_seq_file(const char *reference_seq, size_t 
                                               const char *target_seq, size_t target_len,
                                               const char *out_path, int device, size_t *z);
 
+/* Writes z records + `extra` metadata bytes (may be NULL) + the 48-byte v2 footer. */
+int nolzss_write_factor_file(const char *out_path, const nolzss_factor *factors, size_t z,
+                             uint64_t num_sequences, uint64_t num_sentinels, uint64_t total_length,
+                             const void *extra, size_t extra_len);
+
+/* ---- concatenated multi-sequence FASTA with sentinel bookkeeping ---------- */
+/* reference: prepare_multiple_dna_sequences_no_rc, factorizer.cpp:199-294; bindings.cpp (same shape
+ * as the w_rc variant): S = T1 s0 T2 s1 ... Tk (no sentinel after the last sequence), <= 250. */
+int nolzss_prepare_multiple_dna_no_rc(const char *const *seqs, const size_t *lens, size_t k,
+                                      uint8_t **S, size_t *S_len, size_t *original_length,
+                                      uint64_t **sentinel_positions, size_t *n_sentinels);
+
+typedef struct nolzss_fasta_result {   /* FastaFactorizationResult, fasta_processor.hpp */
+    nolzss_factor *factors;
+    size_t num_factors;
+    uint64_t *sentinel_factor_indices; /* indices into factors[] of the sentinel literals */
+    size_t num_sentinels;
+    char *sequence_ids;                /* num_sequences NUL-terminated ids, back to back */
+    size_t sequence_ids_bytes;
+    size_t num_sequences;
+} nolzss_fasta_result;
+
+/* reference: factorize_fasta_multiple_dna_w_rc / _no_rc, fasta_processor.cpp:298-341 over
+ * parse_fasta_sequences_and_ids (:28-128) and identify_sentinel_factors (:131-163).
+ * sanitize_mode: 0 = "remove_ambiguous" (default of the bindings), 1 = "strict". */
+int nolzss_factorize_fasta_multiple_dna(const char *fasta_path, int with_rc, int sanitize_mode,
+                                        int device, nolzss_fasta_result *out);
+void nolzss_free_fasta_result(nolzss_fasta_result *r);
+/* reference: write_factors_binary_file_fasta_multiple_dna_w_rc / _no_rc (fasta_processor.cpp:345-360
+ * -> parallel_fasta_processor.cpp:64-257): records, names, sentinel indices, footer with
+ * total_length = sum of factor lengths. */
+int nolzss_write_factors_binary_file_fasta_multiple_dna(const char *fasta_path, const char *out_path,
+                                                        int with_rc, int sanitize_mode, int device,
+                                                        size_t *z);
+
 /* ---- per-sequence batch (the FASTA shard unit) ------------------------------------------- */
 /* reference: the per-sequence factorize() loop of genomics.read_nucleotide_fasta,
  *            src/noLZSS/genomics/fasta.py:110-122 (C++ analogue:

@@ -13,6 +13,14 @@ LIB_PATH = _PKG / "libnolzss_hip.so"
 OK, ERR_INVALID_ARGUMENT, ERR_RUNTIME, ERR_NOMEM, ERR_DEVICE, ERR_IO = range(6)
 
 
+class FastaResult(C.Structure):
+    """Mirror of nolzss_fasta_result (include/nolzss_hip.h)."""
+    _fields_ = [("factors", C.c_void_p), ("num_factors", C.c_size_t),
+                ("sentinel_factor_indices", C.c_void_p), ("num_sentinels", C.c_size_t),
+                ("sequence_ids", C.c_void_p), ("sequence_ids_bytes", C.c_size_t),
+                ("num_sequences", C.c_size_t)]
+
+
 class Factor(C.Structure):
     """Mirror of nolzss_factor / the reference's struct Factor (factorizer.hpp:147-151)."""
     _fields_ = [("start", C.c_uint64), ("length", C.c_uint64), ("ref", C.c_uint64)]
@@ -50,6 +58,15 @@ def _load():
     lib.nolzss_factorize_w_reference_file.argtypes = [vp, sz, vp, sz, C.c_char_p, C.c_int, szp]
     lib.nolzss_factorize_dna_w_reference_seq_file.argtypes = [C.c_char_p, sz, C.c_char_p, sz, C.c_char_p,
                                                               C.c_int, szp]
+    lib.nolzss_write_factor_file.argtypes = [C.c_char_p, vp, sz, C.c_uint64, C.c_uint64, C.c_uint64, vp, sz]
+    lib.nolzss_prepare_multiple_dna_no_rc.argtypes = [
+        C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), sz, vpp, szp, szp, vpp, szp]
+    lib.nolzss_factorize_fasta_multiple_dna.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int,
+                                                        C.POINTER(FastaResult)]
+    lib.nolzss_free_fasta_result.argtypes = [C.POINTER(FastaResult)]
+    lib.nolzss_free_fasta_result.restype = None
+    lib.nolzss_write_factors_binary_file_fasta_multiple_dna.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int,
+                                                                        C.c_int, szp]
     lib.nolzss_factorize_batch.argtypes = [
         C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), sz, C.POINTER(C.c_int), sz,
         C.POINTER(C.POINTER(C.c_void_p)), C.POINTER(C.POINTER(C.c_size_t))]
@@ -76,6 +93,8 @@ EXPORTED_SYMBOLS = [
     "nolzss_factorize_w_reference", "nolzss_factorize_dna_w_reference_seq",
     "nolzss_write_factors_binary_file", "nolzss_write_factors_binary_file_dna_w_rc",
     "nolzss_factorize_w_reference_file", "nolzss_factorize_dna_w_reference_seq_file",
+    "nolzss_write_factor_file", "nolzss_prepare_multiple_dna_no_rc", "nolzss_factorize_fasta_multiple_dna",
+    "nolzss_free_fasta_result", "nolzss_write_factors_binary_file_fasta_multiple_dna",
     "nolzss_free_batch", "nolzss_profile_enable", "nolzss_profile_reset", "nolzss_profile_report",
     "nolzss_debug_arrays", "nolzss_debug_sort_pairs", "nolzss_debug_scan", "nolzss_debug_arena",
 ]

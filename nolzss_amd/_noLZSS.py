@@ -286,6 +286,149 @@ def write_factors_binary_file_dna_w_rc(in_path, out_path) -> int:
     return z.value
 
 
+# ---- concatenated multi-sequence FASTA ---------------------------------------
+def _sanitize_mode(mode: str) -> int:
+    """reference: parse_fasta_sanitization_mode, bindings.cpp:29-37"""
+    if mode == "remove_ambiguous":
+        return 0
+    if mode == "strict":
+        return 1
+    raise ValueError(f"Invalid sanitize_mode: '{mode}'. Expected 'remove_ambiguous' or 'strict'.")
+
+
+def prepare_multiple_dna_sequences_no_rc_bytes(sequences):
+    seqs = [s.encode("latin-1") if isinstance(s, str) else bytes(s) for s in sequences]
+    k = len(seqs)
+    arr = (C.c_char_p * max(k, 1))(*seqs)
+    lens = (C.c_size_t * max(k, 1))(*[len(s) for s in seqs])
+    S, S_len, orig = C.c_void_p(), C.c_size_t(), C.c_size_t()
+    sp, ns = C.c_void_p(), C.c_size_t()
+    check(lib.nolzss_prepare_multiple_dna_no_rc(arr, lens, k, C.byref(S), C.byref(S_len), C.byref(orig),
+                                                C.byref(sp), C.byref(ns)))
+    try:
+        data = C.string_at(S, S_len.value) if S.value else b""
+        sent = []
+        if sp.value and ns.value:
+            sent = np.ctypeslib.as_array(C.cast(sp, C.POINTER(C.c_uint64)), shape=(ns.value,)).tolist()
+    finally:
+        lib.nolzss_free(S)
+        lib.nolzss_free(sp)
+    return data, orig.value, sent
+
+
+def prepare_multiple_dna_sequences_no_rc(sequences):
+    """reference: bindings.cpp (prepare_multiple_dna_sequences_no_rc) -> (str, original_length,
+    sentinel_positions); sentinel bytes >= 128 raise UnicodeDecodeError as they do through pybind11."""
+    data, orig, sent = prepare_multiple_dna_sequences_no_rc_bytes(sequences)
+    return data.decode("utf-8"), orig, sent
+
+
+def _fasta_multiple(fasta_path, sanitize_mode, with_rc):
+    res = _lib.FastaResult()
+    check(lib.nolzss_factorize_fasta_multiple_dna(_str_arg(fasta_path, "fasta_path"), 1 if with_rc else 0,
+                                                  _sanitize_mode(sanitize_mode), _default_device, C.byref(res)))
+    try:
+        z = res.num_factors
+        if z:
+            raw = np.ctypeslib.as_array(C.cast(res.factors, C.POINTER(C.c_uint64)), shape=(z * 3,)).copy()
+            factors = _tuples4(raw.view(FACTOR_DTYPE))
+        else:
+            factors = []
+        sent = []
+        if res.num_sentinels:
+            sent = np.ctypeslib.as_array(C.cast(res.sentinel_factor_indices, C.POINTER(C.c_uint64)),
+                                         shape=(res.num_sentinels,)).tolist()
+        blob = C.string_at(res.sequence_ids, res.sequence_ids_bytes) if res.sequence_ids_bytes else b""
+        ids = [x.decode("utf-8") for x in blob.split(b"\x00")[:res.num_sequences]]
+    finally:
+        lib.nolzss_free_fasta_result(C.byref(res))
+    return factors, sent, ids
+
+
+def factorize_fasta_multiple_dna_w_rc(fasta_path, sanitize_mode: str = "remove_ambiguous"):
+    """reference: bindings.cpp:511-536 -> (factors as (start, length, ref, is_rc), sentinel factor
+    indices, sequence ids)."""
+    return _fasta_multiple(fasta_path, sanitize_mode, True)
+
+
+def factorize_fasta_multiple_dna_no_rc(fasta_path, sanitize_mode: str = "remove_ambiguous"):
+    """reference: bindings.cpp:611-636"""
+    return _fasta_multiple(fasta_path, sanitize_mode, False)
+
+
+def _write_fasta_multiple(fasta_path, out_path, sanitize_mode, with_rc):
+    z = C.c_size_t()
+    check(lib.nolzss_write_factors_binary_file_fasta_multiple_dna(
+        _str_arg(fasta_path, "fasta_path"), _str_arg(out_path, "out_path"), 1 if with_rc else 0,
+        _sanitize_mode(sanitize_mode), _default_device, C.byref(z)))
+    return z.value
+
+
+def write_factors_binary_file_fasta_multiple_dna_w_rc(fasta_path, out_path, sanitize_mode: str = "remove_ambiguous"):
+    """reference: fasta_processor.cpp:345-351"""
+    return _write_fasta_multiple(fasta_path, out_path, sanitize_mode, True)
+
+
+def write_factors_binary_file_fasta_multiple_dna_no_rc(fasta_path, out_path, sanitize_mode: str = "remove_ambiguous"):
+    """reference: fasta_processor.cpp:353-359"""
+    return _write_fasta_multiple(fasta_path, out_path, sanitize_mode, False)
+
+
+# ---- thread-parallel API (SURVEY.md 8f.4): same results, num_threads is irrelevant on the GPU ---
+def _write_arrays(out_path, f, total_length):
+    f = np.ascontiguousarray(f)
+    check(lib.nolzss_write_factor_file(os.fsencode(out_path), f.ctypes.data if len(f) else None, len(f), 0, 0,
+                                       int(total_length), None, 0))
+    return len(f)
+
+
+def parallel_factorize_to_file(text, output_path, num_threads: int = 0, start_pos: int = 0) -> int:
+    """reference: bindings.cpp:978-979 over parallel_factorizer.cpp:55-144 (footer :761-765:
+    total_length = sum of factor lengths)."""
+    data = _str_arg(text, "text")
+    if len(data) == 0:
+        return 0                                            # parallel_factorizer.cpp:57
+    if start_pos >= len(data):
+        raise ValueError("start_pos must be less than text length")   # :59-61
+    f = factorize_array(data, start_pos=start_pos)
+    return _write_arrays(output_path, f, int(f["length"].sum()))
+
+
+def parallel_factorize_file_to_file(input_path, output_path, num_threads: int = 0, start_pos: int = 0) -> int:
+    with open(os.fsdecode(_str_arg(input_path, "input_path")), "rb") as fh:
+        return parallel_factorize_to_file(fh.read(), output_path, num_threads, start_pos)
+
+
+def parallel_factorize_dna_w_rc_to_file(text, output_path, num_threads: int = 0) -> int:
+    """reference: parallel_factorizer.cpp:1001-1017"""
+    data = _str_arg(text, "text")
+    if len(data) == 0:
+        return 0
+    f = factorize_dna_w_rc_array(data)
+    return _write_arrays(output_path, f, int(f["length"].sum()))
+
+
+def parallel_factorize_file_dna_w_rc_to_file(input_path, output_path, num_threads: int = 0) -> int:
+    """reference: parallel_factorizer.cpp:1031-1041"""
+    path = os.fsdecode(_str_arg(input_path, "input_path"))
+    try:
+        with open(path, "rb") as fh:
+            data = fh.read()
+    except OSError:
+        raise RuntimeError(f"Cannot open input file: {path}")
+    return parallel_factorize_dna_w_rc_to_file(data, output_path, num_threads)
+
+
+def parallel_write_factors_binary_file_fasta_multiple_dna_w_rc(fasta_path, out_path, num_threads: int = 0,
+                                                               sanitize_mode: str = "remove_ambiguous"):
+    return _write_fasta_multiple(fasta_path, out_path, sanitize_mode, True)
+
+
+def parallel_write_factors_binary_file_fasta_multiple_dna_no_rc(fasta_path, out_path, num_threads: int = 0,
+                                                                sanitize_mode: str = "remove_ambiguous"):
+    return _write_fasta_multiple(fasta_path, out_path, sanitize_mode, False)
+
+
 # ---- measurement hooks ----------------------------------------------------------------------
 def profile_enable(on: bool = True) -> None:
     check(lib.nolzss_profile_enable(_default_device, 1 if on else 0))
@@ -359,14 +502,7 @@ def _not_on_path(name):
 for _n in [
     "factorize_file_dna_w_rc", "count_factors_file_dna_w_rc", "factorize_file_multiple_dna_w_rc",
     "count_factors_file_multiple_dna_w_rc", "write_factors_binary_file_multiple_dna_w_rc",
-    "factorize_fasta_multiple_dna_w_rc", "factorize_dna_rc_w_ref_fasta_files",
-    "factorize_fasta_multiple_dna_no_rc", "write_factors_binary_file_fasta_multiple_dna_w_rc",
-    "write_factors_binary_file_fasta_multiple_dna_no_rc", "prepare_multiple_dna_sequences_no_rc",
-    "write_factors_dna_w_reference_fasta_files_to_binary",
-    "parallel_factorize_to_file", "parallel_factorize_file_to_file",
-    "parallel_factorize_dna_w_rc_to_file", "parallel_factorize_file_dna_w_rc_to_file",
-    "parallel_write_factors_binary_file_fasta_multiple_dna_w_rc",
-    "parallel_write_factors_binary_file_fasta_multiple_dna_no_rc",
+    "factorize_dna_rc_w_ref_fasta_files", "write_factors_dna_w_reference_fasta_files_to_binary",
     "parallel_write_factors_dna_w_reference_fasta_files_to_binary",
     "factorize_fasta_dna_w_rc_per_sequence", "factorize_fasta_dna_no_rc_per_sequence",
     "write_factors_binary_file_fasta_dna_w_rc_per_sequence",

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cctype>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -506,6 +507,8 @@ int nolzss_count_factors_dna_w_rc(const uint8_t *text, size_t n, int device, siz
     });
 }
 
+}  // extern "C"
+
 // ---- reference + target factorization and v2 binary files ("next" rows) ---------
 namespace nolzss {
 namespace {
@@ -567,6 +570,8 @@ size_t dna_w_reference(const char *ref, size_t ref_len, const char *tgt, size_t 
 
 }  // namespace
 }  // namespace nolzss
+
+extern "C" {
 
 int nolzss_factorize_w_reference(const uint8_t *reference_seq, size_t reference_len, const uint8_t *target_seq,
                                  size_t target_len, int device, nolzss_factor **out, size_t *z) {
@@ -653,6 +658,261 @@ int nolzss_factorize_dna_w_reference_seq_file(const char *reference_seq, size_t 
         std::unique_ptr<nolzss_factor, decltype(&std::free)> hold(f, &std::free);
         write_v2_file(out_path, f, count, 2, 1, target_len, std::string());  // factorizer.cpp:866-876
         *z = count;
+    });
+}
+
+}  // extern "C"
+
+// ---- concatenated multi-sequence FASTA -----------------------------------------
+namespace nolzss {
+namespace {
+
+struct FastaParse {
+    std::vector<std::string> sequences, ids;
+};
+
+inline bool is_canonical_dna(char c) {
+    return c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 'a' || c == 'c' || c == 'g' || c == 't';
+}
+
+// restates parse_fasta_sequences_and_ids, /root/reference/src/cpp/fasta_processor.cpp:28-128
+FastaParse parse_fasta(const char *path, bool strict) {
+    if (!path) throw std::invalid_argument("path is null");
+    std::ifstream file(path);
+    if (!file.is_open()) throw std::runtime_error(std::string("Cannot open FASTA file: ") + path);
+    FastaParse res;
+    std::string line, cur_seq, cur_id;
+    size_t empty_count = 0, removed = 0;
+    auto finish = [&] {
+        if (cur_id.empty()) return;
+        if (!cur_seq.empty()) {
+            res.sequences.push_back(cur_seq);
+            res.ids.push_back(cur_id);
+        } else {
+            fprintf(stderr, "Warning: Skipping empty sequence with ID: %s\n", cur_id.c_str());
+            ++empty_count;
+        }
+        cur_seq.clear();
+    };
+    while (std::getline(file, line)) {
+        while (!line.empty() && std::isspace((unsigned char)line.back())) line.pop_back();
+        if (line.empty()) continue;
+        if (line[0] == '>') {
+            finish();
+            size_t start = 1;
+            while (start < line.size() && std::isspace((unsigned char)line[start])) ++start;
+            size_t end = start;
+            while (end < line.size() && !std::isspace((unsigned char)line[end])) ++end;
+            if (start >= line.size()) throw std::runtime_error("Empty sequence header in FASTA file");
+            cur_id = line.substr(start, end - start);
+        } else {
+            for (char c : line) {
+                if (std::isspace((unsigned char)c)) continue;
+                if (is_canonical_dna(c))
+                    cur_seq += (char)upper_base((uint8_t)c);
+                else if (strict)
+                    throw std::runtime_error("Invalid nucleotide '" + std::string(1, c) +
+                                             "' found in sequence with ID: " + cur_id);
+                else
+                    ++removed;
+            }
+        }
+    }
+    finish();
+    if (empty_count) fprintf(stderr, "Warning: Skipped %zu empty sequence(s) in FASTA file\n", empty_count);
+    if (!strict && removed)
+        fprintf(stderr, "Warning: Removed %zu ambiguous nucleotide(s) from FASTA input\n", removed);
+    if (res.sequences.empty()) throw std::runtime_error("No valid sequences found in FASTA file");
+    return res;
+}
+
+// restates prepare_multiple_dna_sequences_no_rc, /root/reference/src/cpp/factorizer.cpp:199-294
+void prepare_no_rc(const char *const *seqs, const size_t *lens, size_t k, std::vector<uint8_t> &S,
+                   size_t &original_length, std::vector<uint64_t> &sentinels) {
+    S.clear();
+    sentinels.clear();
+    original_length = 0;
+    if (k == 0) return;
+    size_t non_empty = 0, empty = 0, total = 0;
+    for (size_t i = 0; i < k; ++i) (lens[i] ? ++non_empty : ++empty);
+    if (empty)
+        fprintf(stderr, "Warning: Skipping %zu empty sequence(s) in prepare_multiple_dna_sequences_no_rc\n", empty);
+    if (non_empty == 0) throw std::runtime_error("All sequences are empty - cannot prepare for factorization");
+    if (non_empty > 250)
+        throw std::invalid_argument(
+            "Too many sequences: maximum 250 sequences supported (due to sentinel character limitations)");
+    for (size_t i = 0; i < k; ++i)
+        for (size_t j = 0; j < lens[i]; ++j)
+            if (!is_canonical_dna(seqs[i][j]))
+                throw std::runtime_error("Invalid nucleotide '" + std::string(1, seqs[i][j]) +
+                                         "' found in sequence " + std::to_string(i));
+    for (size_t i = 0; i < k; ++i) total += lens[i];
+    S.reserve(total + non_empty);
+    size_t sidx = 0, done = 0;
+    for (size_t i = 0; i < k; ++i) {
+        if (!lens[i]) continue;
+        for (size_t j = 0; j < lens[i]; ++j) S.push_back(upper_base((uint8_t)seqs[i][j]));
+        if (++done < non_empty) {  // sentinels only BETWEEN sequences (:280-288)
+            sentinels.push_back(S.size());
+            S.push_back(rc_sentinel(sidx++));
+        }
+    }
+    original_length = S.size();
+}
+
+// restates identify_sentinel_factors, fasta_processor.cpp:131-163
+std::vector<uint64_t> sentinel_factors(const nolzss_factor *f, size_t z, const std::vector<uint64_t> &positions) {
+    std::vector<uint64_t> idx;
+    size_t s = 0;
+    for (size_t i = 0; i < z; ++i) {
+        while (s < positions.size() && positions[s] < f[i].start) ++s;
+        if (s < positions.size() && f[i].start == positions[s]) {
+            if (f[i].length != 1)
+                throw std::runtime_error("Sentinel factor has unexpected length: " + std::to_string(f[i].length));
+            if (f[i].ref != f[i].start)
+                throw std::runtime_error("Sentinel factor reference mismatch: ref=" + std::to_string(f[i].ref) +
+                                         ", pos=" + std::to_string(f[i].start));
+            idx.push_back(i);
+            ++s;
+        }
+    }
+    return idx;
+}
+
+struct FastaFactors {
+    FastaParse parse;
+    nolzss_factor *factors = nullptr;
+    size_t z = 0;
+    std::vector<uint64_t> sentinel_idx;
+    ~FastaFactors() { std::free(factors); }
+};
+
+void factorize_fasta(const char *path, bool with_rc, bool strict, int device, FastaFactors &out) {
+    out.parse = parse_fasta(path, strict);
+    std::vector<const char *> ptrs;
+    std::vector<size_t> lens;
+    for (const auto &q : out.parse.sequences) {
+        ptrs.push_back(q.data());
+        lens.push_back(q.size());
+    }
+    std::vector<uint8_t> S;
+    std::vector<uint64_t> sent;
+    size_t orig = 0;
+    if (with_rc) {
+        prepare_w_rc(ptrs.data(), lens.data(), ptrs.size(), S, orig, sent);  // fasta_processor.cpp:308
+        if (rc_guards(S.size(), 0)) {
+            Session ses(device, nullptr);
+            out.z = run_rc_host(ses.ctx(), S.data(), S.size(), 0, &out.factors);  // :311
+        }
+    } else {
+        prepare_no_rc(ptrs.data(), lens.data(), ptrs.size(), S, orig, sent);  // :331
+        check_text_args(S.data(), S.size(), 0);
+        Session ses(device, nullptr);
+        out.z = run_plain_host(ses.ctx(), S.data(), S.size(), 0, &out.factors, nullptr);  // :334
+    }
+    out.sentinel_idx = sentinel_factors(out.factors, out.z, sent);  // :314 / :337
+}
+
+}  // namespace
+}  // namespace nolzss
+
+extern "C" {
+
+int nolzss_write_factor_file(const char *out_path, const nolzss_factor *factors, size_t z, uint64_t num_sequences,
+                             uint64_t num_sentinels, uint64_t total_length, const void *extra, size_t extra_len) {
+    return guarded([&] {
+        if (z && !factors) throw std::invalid_argument("factor array is null");
+        write_v2_file(out_path, factors, z, num_sequences, num_sentinels, total_length,
+                      std::string(static_cast<const char *>(extra ? extra : ""), extra ? extra_len : 0));
+    });
+}
+
+int nolzss_prepare_multiple_dna_no_rc(const char *const *seqs, const size_t *lens, size_t k, uint8_t **S,
+                                      size_t *S_len, size_t *original_length, uint64_t **sentinel_positions,
+                                      size_t *n_sentinels) {
+    return guarded([&] {
+        if (!S || !S_len || !original_length || !sentinel_positions || !n_sentinels)
+            throw std::invalid_argument("output pointer is null");
+        *S = nullptr;
+        *sentinel_positions = nullptr;
+        *S_len = *original_length = *n_sentinels = 0;
+        if (k && (!seqs || !lens)) throw std::invalid_argument("sequence array is null");
+        std::vector<uint8_t> buf;
+        std::vector<uint64_t> sent;
+        size_t orig = 0;
+        prepare_no_rc(seqs, lens, k, buf, orig, sent);
+        uint8_t *s = static_cast<uint8_t *>(std::malloc(buf.size() ? buf.size() : 1));
+        uint64_t *p = static_cast<uint64_t *>(std::malloc(sent.size() ? sent.size() * sizeof(uint64_t) : 8));
+        if (!s || !p) {
+            std::free(s);
+            std::free(p);
+            throw std::bad_alloc();
+        }
+        if (!buf.empty()) std::memcpy(s, buf.data(), buf.size());
+        if (!sent.empty()) std::memcpy(p, sent.data(), sent.size() * sizeof(uint64_t));
+        *S = s;
+        *S_len = buf.size();
+        *original_length = orig;
+        *sentinel_positions = p;
+        *n_sentinels = sent.size();
+    });
+}
+
+int nolzss_factorize_fasta_multiple_dna(const char *fasta_path, int with_rc, int sanitize_mode, int device,
+                                        nolzss_fasta_result *out) {
+    return guarded([&] {
+        if (!out) throw std::invalid_argument("output pointer is null");
+        std::memset(out, 0, sizeof *out);
+        if (sanitize_mode != 0 && sanitize_mode != 1) throw std::invalid_argument("sanitize_mode must be 0 or 1");
+        FastaFactors ff;
+        factorize_fasta(fasta_path, with_rc != 0, sanitize_mode == 1, device, ff);
+        std::string blob;
+        for (const auto &id : ff.parse.ids) blob.append(id).push_back('\0');
+        uint64_t *sidx = static_cast<uint64_t *>(std::malloc(ff.sentinel_idx.size() * sizeof(uint64_t) + 8));
+        char *ids = static_cast<char *>(std::malloc(blob.size() + 1));
+        if (!sidx || !ids) {
+            std::free(sidx);
+            std::free(ids);
+            throw std::bad_alloc();
+        }
+        if (!ff.sentinel_idx.empty())
+            std::memcpy(sidx, ff.sentinel_idx.data(), ff.sentinel_idx.size() * sizeof(uint64_t));
+        std::memcpy(ids, blob.data(), blob.size());
+        out->factors = ff.factors;
+        ff.factors = nullptr;  // ownership moves to the caller
+        out->num_factors = ff.z;
+        out->sentinel_factor_indices = sidx;
+        out->num_sentinels = ff.sentinel_idx.size();
+        out->sequence_ids = ids;
+        out->sequence_ids_bytes = blob.size();
+        out->num_sequences = ff.parse.ids.size();
+    });
+}
+
+void nolzss_free_fasta_result(nolzss_fasta_result *r) {
+    if (!r) return;
+    std::free(r->factors);
+    std::free(r->sentinel_factor_indices);
+    std::free(r->sequence_ids);
+    std::memset(r, 0, sizeof *r);
+}
+
+int nolzss_write_factors_binary_file_fasta_multiple_dna(const char *fasta_path, const char *out_path, int with_rc,
+                                                        int sanitize_mode, int device, size_t *z) {
+    return guarded([&] {
+        if (!z) throw std::invalid_argument("output pointer is null");
+        *z = 0;
+        if (sanitize_mode != 0 && sanitize_mode != 1) throw std::invalid_argument("sanitize_mode must be 0 or 1");
+        FastaFactors ff;
+        factorize_fasta(fasta_path, with_rc != 0, sanitize_mode == 1, device, ff);
+        // write_fasta_metadata, parallel_fasta_processor.cpp:29-62: names, sentinel indices, footer
+        std::string extra;
+        for (const auto &id : ff.parse.ids) extra.append(id).push_back('\0');
+        extra.append(reinterpret_cast<const char *>(ff.sentinel_idx.data()), ff.sentinel_idx.size() * sizeof(uint64_t));
+        uint64_t total = 0;
+        for (size_t i = 0; i < ff.z; ++i) total += ff.factors[i].length;
+        write_v2_file(out_path, ff.factors, ff.z, ff.parse.ids.size(), ff.sentinel_idx.size(), total, extra);
+        *z = ff.z;
     });
 }
 

@@ -120,3 +120,87 @@ def test_reference_files(pkg, tmp_path):
     # reader rejects them (the reference's own reader, utils.py:214-221, does the same)
     with pytest.raises(pkg.NoLZSSError):
         pkg.read_binary_file_metadata(out2)
+
+
+def _write_fasta(path, recs, width=60):
+    with open(path, "w") as f:
+        for rid, seq in recs:
+            f.write(f">{rid} some description\n")
+            for i in range(0, len(seq), width):
+                f.write(seq[i:i + width] + "\n")
+
+
+def test_factorize_fasta_multiple_dna(pkg, tmp_path):
+    """fasta_processor.cpp:28-163, 298-341 -- parse, prepare, factorize the
+    concatenation, identify the sentinel literals"""
+    from nolzss_amd import _noLZSS
+    rng = random.Random(9)
+    recs = [(f"chr{k}", "".join(rng.choice("ACGT") for _ in range(rng.randint(50, 900)))) for k in range(6)]
+    recs[3] = (recs[3][0], recs[1][1][10:300] + recs[3][1])       # shared material across sequences
+    path = tmp_path / "multi.fa"
+    _write_fasta(path, recs)
+    seqs = [s for _, s in recs]
+
+    factors, sentinels, ids = _noLZSS.factorize_fasta_multiple_dna_w_rc(str(path))
+    S, orig, sent_pos = oracle.prepare_multiple_dna_w_rc(seqs)
+    assert factors == oracle.factorize_multiple_dna_w_rc(S)
+    assert ids == [rid for rid, _ in recs]
+    assert [factors[i][0] for i in sentinels] == sent_pos[:len(seqs) - 1]   # those inside [0, N)
+    assert all(factors[i][1] == 1 and factors[i][2] == factors[i][0] for i in sentinels)
+
+    factors2, sentinels2, ids2 = _noLZSS.factorize_fasta_multiple_dna_no_rc(str(path))
+    S2, _, sent2 = _noLZSS.prepare_multiple_dna_sequences_no_rc_bytes(seqs)
+    assert [(s, l, r) for s, l, r, rc in factors2] == oracle.factorize(S2)
+    assert not any(rc for _, _, _, rc in factors2)
+    assert [factors2[i][0] for i in sentinels2] == sent2 and ids2 == ids
+
+    # sanitisation modes (fasta_processor.cpp:86-98)
+    dirty = tmp_path / "dirty.fa"
+    dirty.write_text(">a\nACGTNNACGT\n>b\nacgtRYacgt\n>empty\n>c\nGGGG\n")
+    f3, s3, ids3 = _noLZSS.factorize_fasta_multiple_dna_no_rc(str(dirty))
+    assert ids3 == ["a", "b", "c"]
+    S3, _, _ = _noLZSS.prepare_multiple_dna_sequences_no_rc_bytes(["ACGTACGT", "ACGTACGT", "GGGG"])
+    assert [(s, l, r) for s, l, r, _ in f3] == oracle.factorize(S3)
+    with pytest.raises(RuntimeError, match="Invalid nucleotide"):
+        _noLZSS.factorize_fasta_multiple_dna_no_rc(str(dirty), "strict")
+    hdr = tmp_path / "hdr.fa"
+    hdr.write_text(">\nACGT\n")
+    with pytest.raises(RuntimeError, match="Empty sequence header"):
+        _noLZSS.factorize_fasta_multiple_dna_w_rc(str(hdr))
+
+
+def test_fasta_binary_files_and_parallel_aliases(pkg, tmp_path):
+    """write_fasta_metadata (parallel_fasta_processor.cpp:29-62) and SURVEY 8f.4: the parallel
+    entry points give the sequential result (reference: tests/test_parallel_fasta.py:294-323)"""
+    from nolzss_amd import _noLZSS, parallel
+    recs = [(f"s{k}", gen.random_dna(3000 + 411 * k, 500 + k).tobytes().decode()) for k in range(3)]
+    path = tmp_path / "three.fa"
+    _write_fasta(path, recs)
+    out = tmp_path / "three.bin"
+    z = _noLZSS.write_factors_binary_file_fasta_multiple_dna_w_rc(str(path), str(out))
+    factors, sentinels, ids = _noLZSS.factorize_fasta_multiple_dna_w_rc(str(path))
+    meta = pkg.read_factors_binary_file_with_metadata(out)
+    assert z == len(factors) and meta["factors"] == factors
+    assert meta["sequence_names"] == ids and meta["sentinel_factor_indices"] == sentinels
+    assert meta["total_length"] == sum(f[1] for f in factors)
+    out2 = tmp_path / "three_par.bin"
+    assert _noLZSS.parallel_write_factors_binary_file_fasta_multiple_dna_w_rc(str(path), str(out2), 4) == z
+    assert out2.read_bytes() == out.read_bytes()
+
+    text = gen.repeat_dna(250_000, 77, lo=16, hi=2048).tobytes()
+    seq = oracle.factorize(text)
+    got = parallel.parallel_factorize(text, num_threads=4)
+    assert [tuple(f) for f in got] == seq
+    pout = tmp_path / "par.bin"
+    n_par = parallel.parallel_factorize_to_file(text, pout, num_threads=3, start_pos=1000)
+    assert n_par == len(oracle.factorize(text, start_pos=1000))
+    raw = pout.read_bytes()
+    magic, nf, nseq, nsent, fsize, total = struct.unpack("<8sQQQQQ", raw[-48:])
+    assert (magic, nseq, nsent, fsize, total) == (b"noLZSSv2", 0, 0, 48, len(text) - 1000)
+    with pytest.raises(ValueError):
+        _noLZSS.parallel_factorize_to_file(b"ACGT", str(pout), 2, 4)
+    dout = tmp_path / "par_rc.bin"
+    zr = parallel.parallel_factorize_dna_w_rc_to_file(text[:50_000], dout, num_threads=2)
+    rc_mask = 1 << 63
+    got_rc = [(s, l, r & (rc_mask - 1), bool(r & rc_mask)) for s, l, r in pkg.read_factors_binary_file(dout)]
+    assert zr == len(got_rc) and got_rc == oracle.factorize_dna_w_rc(text[:50_000])

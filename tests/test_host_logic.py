@@ -41,7 +41,11 @@ def test_reference_module_names_exist():
                  "prepare_multiple_dna_sequences_w_rc", "Factor", "__version__"]:
         assert hasattr(_noLZSS, name), name
     with pytest.raises(NotImplementedError):
-        _noLZSS.factorize_fasta_multiple_dna_w_rc("a.fasta")
+        _noLZSS.factorize_fasta_dna_w_rc_per_sequence("a.fasta")
+    with pytest.raises(RuntimeError, match="Cannot open FASTA file"):      # fasta_processor.cpp:33-35
+        _noLZSS.factorize_fasta_multiple_dna_w_rc("/nonexistent/a.fasta")
+    with pytest.raises(ValueError, match="Invalid sanitize_mode"):          # bindings.cpp:36
+        _noLZSS.factorize_fasta_multiple_dna_w_rc("a.fasta", "lenient")
 
 
 def test_validate_input_mirrors_reference():
@@ -192,3 +196,17 @@ def test_v2_reader_against_hand_packed_files(tmp_path):
     tiny.write_bytes(b"abc")
     with pytest.raises(pkg.NoLZSSError):
         pkg.read_factors_binary_file(tiny)
+
+
+def test_prepare_no_rc_host_side():
+    """prepare_multiple_dna_sequences_no_rc, factorizer.cpp:199-294: sentinels only BETWEEN sequences"""
+    from nolzss_amd import _noLZSS
+    assert _noLZSS.prepare_multiple_dna_sequences_no_rc(["ACGT", "gg", "T"]) == ("ACGT\x01GG\x02T", 9, [4, 7])
+    assert _noLZSS.prepare_multiple_dna_sequences_no_rc(["ACGT"]) == ("ACGT", 4, [])
+    assert _noLZSS.prepare_multiple_dna_sequences_no_rc([]) == ("", 0, [])
+    s, n, sent = _noLZSS.prepare_multiple_dna_sequences_no_rc_bytes(["A"] * 250)
+    assert len(s) == 499 and len(sent) == 249 and len(set(s[1::2])) == 249
+    with pytest.raises(ValueError):
+        _noLZSS.prepare_multiple_dna_sequences_no_rc(["A"] * 251)
+    with pytest.raises(RuntimeError):
+        _noLZSS.prepare_multiple_dna_sequences_no_rc(["ACGU"])
