@@ -161,6 +161,36 @@ int nolzss_write_factors_binary_file_fasta_multiple_dna(const char *fasta_path, 
                                                         int with_rc, int sanitize_mode, int device,
                                                         size_t *z);
 
+/* reference: factorize_dna_rc_w_ref_fasta_files, fasta_processor.cpp:362-378 over
+ * prepare_ref_target_dna_w_rc_from_fasta (:240-287): all reference records, then all target records,
+ * prepared with reverse complements; factorization starts at the first target base. */
+int nolzss_factorize_dna_rc_w_ref_fasta_files(const char *reference_fasta_path, const char *target_fasta_path,
+                                              int sanitize_mode, int device, nolzss_fasta_result *out);
+/* reference: write_factors_dna_w_reference_fasta_files_to_binary, fasta_processor.cpp:381-390 */
+int nolzss_write_factors_dna_w_reference_fasta_files_to_binary(const char *reference_fasta_path,
+                                                               const char *target_fasta_path,
+                                                               const char *out_path, int sanitize_mode,
+                                                               int device, size_t *z);
+
+/* Per-sequence FASTA factorization (each record on its own; no concatenation).
+ * reference: factorize_/count_factors_/write_factors_binary_file_fasta_dna_{w,no}_rc_per_sequence,
+ * fasta_processor.cpp:430-561, parallel_fasta_processor.cpp:262-465.  factors[j] / counts[j] per
+ * record (factors is NULL when want_factors == 0); with out_dir != NULL every record is also
+ * written to out_dir/<sanitised id>.bin (one name, no sentinels, total_length = sum of lengths).
+ * Kept from the reference: the no-rc variants drop the last base of every record
+ * (fasta_processor.cpp:469-471). */
+typedef struct nolzss_fasta_per_sequence_result {
+    nolzss_factor **factors;
+    size_t *counts;
+    char *sequence_ids;
+    size_t sequence_ids_bytes;
+    size_t num_sequences;
+} nolzss_fasta_per_sequence_result;
+int nolzss_factorize_fasta_per_sequence(const char *fasta_path, int with_rc, int sanitize_mode,
+                                        int want_factors, const char *out_dir, int device,
+                                        nolzss_fasta_per_sequence_result *out);
+void nolzss_free_fasta_per_sequence_result(nolzss_fasta_per_sequence_result *r);
+
 /* ---- per-sequence batch (the FASTA shard unit) ------------------------------------------- */
 /* reference: the per-sequence factorize() loop of genomics.read_nucleotide_fasta,
  *            src/noLZSS/genomics/fasta.py:110-122 (C++ analogue:

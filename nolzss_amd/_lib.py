@@ -21,6 +21,12 @@ class FastaResult(C.Structure):
                 ("num_sequences", C.c_size_t)]
 
 
+class FastaPerSequenceResult(C.Structure):
+    """Mirror of nolzss_fasta_per_sequence_result (include/nolzss_hip.h)."""
+    _fields_ = [("factors", C.POINTER(C.c_void_p)), ("counts", C.POINTER(C.c_size_t)),
+                ("sequence_ids", C.c_void_p), ("sequence_ids_bytes", C.c_size_t), ("num_sequences", C.c_size_t)]
+
+
 class Factor(C.Structure):
     """Mirror of nolzss_factor / the reference's struct Factor (factorizer.hpp:147-151)."""
     _fields_ = [("start", C.c_uint64), ("length", C.c_uint64), ("ref", C.c_uint64)]
@@ -67,6 +73,14 @@ def _load():
     lib.nolzss_free_fasta_result.restype = None
     lib.nolzss_write_factors_binary_file_fasta_multiple_dna.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int,
                                                                         C.c_int, szp]
+    lib.nolzss_factorize_dna_rc_w_ref_fasta_files.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int,
+                                                              C.POINTER(FastaResult)]
+    lib.nolzss_write_factors_dna_w_reference_fasta_files_to_binary.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p,
+                                                                               C.c_int, C.c_int, szp]
+    lib.nolzss_factorize_fasta_per_sequence.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int,
+                                                        C.POINTER(FastaPerSequenceResult)]
+    lib.nolzss_free_fasta_per_sequence_result.argtypes = [C.POINTER(FastaPerSequenceResult)]
+    lib.nolzss_free_fasta_per_sequence_result.restype = None
     lib.nolzss_factorize_batch.argtypes = [
         C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), sz, C.POINTER(C.c_int), sz,
         C.POINTER(C.POINTER(C.c_void_p)), C.POINTER(C.POINTER(C.c_size_t))]
@@ -95,6 +109,8 @@ EXPORTED_SYMBOLS = [
     "nolzss_factorize_w_reference_file", "nolzss_factorize_dna_w_reference_seq_file",
     "nolzss_write_factor_file", "nolzss_prepare_multiple_dna_no_rc", "nolzss_factorize_fasta_multiple_dna",
     "nolzss_free_fasta_result", "nolzss_write_factors_binary_file_fasta_multiple_dna",
+    "nolzss_factorize_fasta_per_sequence", "nolzss_free_fasta_per_sequence_result",
+    "nolzss_factorize_dna_rc_w_ref_fasta_files", "nolzss_write_factors_dna_w_reference_fasta_files_to_binary",
     "nolzss_free_batch", "nolzss_profile_enable", "nolzss_profile_reset", "nolzss_profile_report",
     "nolzss_debug_arrays", "nolzss_debug_sort_pairs", "nolzss_debug_scan", "nolzss_debug_arena",
 ]

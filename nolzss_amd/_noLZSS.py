@@ -1,11 +1,10 @@
 """Python-visible surface of the reference's compiled module `noLZSS._noLZSS`
 (reference: src/cpp/bindings.cpp), bound to libnolzss_hip.so through ctypes.
 
-Same names, argument meaning, return shapes and error behaviour as the pybind11 module for the
-factorize path; ctypes releases the GIL around every native call just as the reference does
-with gil_scoped_release (bindings.cpp:70).  Functions of `_noLZSS` that are outside the hot
-path exist (so `from ._noLZSS import ...` keeps working for code written against the
-reference) and raise NotImplementedError when called.
+Same names, argument meaning, return shapes and error behaviour as the pybind11 module; ctypes
+releases the GIL around every native call just as the reference does with gil_scoped_release
+(bindings.cpp:70).  All 42 functions of the reference module are present; every one of them
+computes on the GPU through the C ABI (there is no CPU path).
 """
 import ctypes as C
 import os
@@ -34,11 +33,38 @@ def get_device() -> int:
 
 
 class Factor:
-    """reference: py::class_<Factor>, bindings.cpp:44-48"""
-    __slots__ = ("start", "length", "ref")
+    """reference: py::class_<Factor>, bindings.cpp:44-48 (ref is reported with RC_MASK stripped)"""
+    __slots__ = ("start", "length", "_raw_ref")
 
     def __init__(self, start=0, length=0, ref=0):
-        self.start, self.length, self.ref = start, length, ref
+        self.start, self.length, self._raw_ref = start, length, ref
+
+    @property
+    def ref(self):
+        return self._raw_ref & (RC_MASK - 1)
+
+    @property
+    def is_rc(self):
+        return bool(self._raw_ref & RC_MASK)
+
+
+class FastaFactorizationResult:
+    """reference: py::class_<FastaFactorizationResult>, bindings.cpp:51-53"""
+    __slots__ = ("factors", "sentinel_factor_indices", "sequence_ids")
+
+    def __init__(self, factors=(), sentinel_factor_indices=(), sequence_ids=()):
+        self.factors = list(factors)
+        self.sentinel_factor_indices = list(sentinel_factor_indices)
+        self.sequence_ids = list(sequence_ids)
+
+
+class FastaPerSequenceFactorizationResult:
+    """reference: py::class_<FastaPerSequenceFactorizationResult>, bindings.cpp:1208-1213"""
+    __slots__ = ("per_sequence_factors", "sequence_ids")
+
+    def __init__(self, per_sequence_factors=(), sequence_ids=()):
+        self.per_sequence_factors = list(per_sequence_factors)
+        self.sequence_ids = list(sequence_ids)
 
 
 def _as_buffer(data):
@@ -323,10 +349,7 @@ def prepare_multiple_dna_sequences_no_rc(sequences):
     return data.decode("utf-8"), orig, sent
 
 
-def _fasta_multiple(fasta_path, sanitize_mode, with_rc):
-    res = _lib.FastaResult()
-    check(lib.nolzss_factorize_fasta_multiple_dna(_str_arg(fasta_path, "fasta_path"), 1 if with_rc else 0,
-                                                  _sanitize_mode(sanitize_mode), _default_device, C.byref(res)))
+def _unpack_fasta_result(res):
     try:
         z = res.num_factors
         if z:
@@ -343,6 +366,80 @@ def _fasta_multiple(fasta_path, sanitize_mode, with_rc):
     finally:
         lib.nolzss_free_fasta_result(C.byref(res))
     return factors, sent, ids
+
+
+def _fasta_multiple(fasta_path, sanitize_mode, with_rc):
+    res = _lib.FastaResult()
+    check(lib.nolzss_factorize_fasta_multiple_dna(_str_arg(fasta_path, "fasta_path"), 1 if with_rc else 0,
+                                                  _sanitize_mode(sanitize_mode), _default_device, C.byref(res)))
+    return _unpack_fasta_result(res)
+
+
+def factorize_dna_rc_w_ref_fasta_files(reference_fasta_path, target_fasta_path,
+                                       sanitize_mode: str = "remove_ambiguous"):
+    """reference: bindings.cpp:563-585 -> (factors, sentinel factor indices, sequence ids); the
+    factors cover the target records only and may point into the reference records."""
+    res = _lib.FastaResult()
+    check(lib.nolzss_factorize_dna_rc_w_ref_fasta_files(
+        _str_arg(reference_fasta_path, "reference_fasta_path"), _str_arg(target_fasta_path, "target_fasta_path"),
+        _sanitize_mode(sanitize_mode), _default_device, C.byref(res)))
+    return _unpack_fasta_result(res)
+
+
+def write_factors_dna_w_reference_fasta_files_to_binary(reference_fasta_path, target_fasta_path, out_path,
+                                                        sanitize_mode: str = "remove_ambiguous") -> int:
+    """reference: fasta_processor.cpp:381-390"""
+    z = C.c_size_t()
+    check(lib.nolzss_write_factors_dna_w_reference_fasta_files_to_binary(
+        _str_arg(reference_fasta_path, "reference_fasta_path"), _str_arg(target_fasta_path, "target_fasta_path"),
+        _str_arg(out_path, "out_path"), _sanitize_mode(sanitize_mode), _default_device, C.byref(z)))
+    return z.value
+
+
+def parallel_write_factors_dna_w_reference_fasta_files_to_binary(reference_fasta_path, target_fasta_path, out_path,
+                                                                 num_threads: int = 0,
+                                                                 sanitize_mode: str = "remove_ambiguous") -> int:
+    return write_factors_dna_w_reference_fasta_files_to_binary(reference_fasta_path, target_fasta_path, out_path,
+                                                               sanitize_mode)
+
+
+def _read_input_file(path):
+    path = os.fsdecode(_str_arg(path, "path"))
+    try:
+        with open(path, "rb") as fh:
+            return fh.read()
+    except OSError:
+        raise RuntimeError(f"Cannot open input file: {path}")   # factorizer.cpp:498-500
+
+
+def factorize_file_dna_w_rc(path, reserve_hint: int = 0):
+    """reference: noLZSS::factorize_file_dna_w_rc, factorizer.cpp:525-545"""
+    return factorize_dna_w_rc(_read_input_file(path))
+
+
+def count_factors_file_dna_w_rc(path) -> int:
+    """reference: factorizer.cpp:575-577"""
+    return count_factors_dna_w_rc(_read_input_file(path))
+
+
+def factorize_file_multiple_dna_w_rc(path, reserve_hint: int = 0):
+    """reference: factorizer.cpp:658-686 (the file holds an already prepared string)"""
+    return factorize_multiple_dna_w_rc(_read_input_file(path))
+
+
+def count_factors_file_multiple_dna_w_rc(path) -> int:
+    """reference: factorizer.cpp:707-732"""
+    return count_factors_multiple_dna_w_rc(_read_input_file(path))
+
+
+def write_factors_binary_file_multiple_dna_w_rc(in_path, out_path) -> int:
+    """reference: factorizer.cpp:751-790: no names, no sentinels, total_length = file size"""
+    data = _read_input_file(in_path)
+    f = factorize_multiple_dna_w_rc_array(data)
+    f = np.ascontiguousarray(f)
+    check(lib.nolzss_write_factor_file(_str_arg(out_path, "out_path"), f.ctypes.data if len(f) else None, len(f), 0, 0,
+                                       len(data), None, 0))
+    return len(f)
 
 
 def factorize_fasta_multiple_dna_w_rc(fasta_path, sanitize_mode: str = "remove_ambiguous"):
@@ -372,6 +469,77 @@ def write_factors_binary_file_fasta_multiple_dna_w_rc(fasta_path, out_path, sani
 def write_factors_binary_file_fasta_multiple_dna_no_rc(fasta_path, out_path, sanitize_mode: str = "remove_ambiguous"):
     """reference: fasta_processor.cpp:353-359"""
     return _write_fasta_multiple(fasta_path, out_path, sanitize_mode, False)
+
+
+def _fasta_per_sequence(fasta_path, sanitize_mode, with_rc, want_factors, out_dir=None):
+    res = _lib.FastaPerSequenceResult()
+    check(lib.nolzss_factorize_fasta_per_sequence(
+        _str_arg(fasta_path, "fasta_path"), 1 if with_rc else 0, _sanitize_mode(sanitize_mode),
+        1 if want_factors else 0, _str_arg(out_dir, "out_dir") if out_dir is not None else None,
+        _default_device, C.byref(res)))
+    try:
+        m = res.num_sequences
+        counts = [res.counts[j] for j in range(m)]
+        per_seq = None
+        if want_factors:
+            per_seq = []
+            for j in range(m):
+                if counts[j] == 0 or not res.factors[j]:
+                    per_seq.append([])
+                else:
+                    raw = np.ctypeslib.as_array(C.cast(res.factors[j], C.POINTER(C.c_uint64)),
+                                                shape=(counts[j] * 3,)).copy()
+                    per_seq.append(_tuples4(raw.view(FACTOR_DTYPE)))
+        blob = C.string_at(res.sequence_ids, res.sequence_ids_bytes) if res.sequence_ids_bytes else b""
+        ids = [x.decode("utf-8") for x in blob.split(b"\x00")[:m]]
+    finally:
+        lib.nolzss_free_fasta_per_sequence_result(C.byref(res))
+    return per_seq, counts, ids
+
+
+def factorize_fasta_dna_w_rc_per_sequence(fasta_path, sanitize_mode: str = "remove_ambiguous"):
+    """reference: bindings.cpp:1215-1237 -> (per-sequence factor lists, sequence ids)"""
+    per_seq, _, ids = _fasta_per_sequence(fasta_path, sanitize_mode, True, True)
+    return per_seq, ids
+
+
+def factorize_fasta_dna_no_rc_per_sequence(fasta_path, sanitize_mode: str = "remove_ambiguous"):
+    """reference: bindings.cpp (no-rc twin); the last base of every record is dropped as in
+    fasta_processor.cpp:469-471"""
+    per_seq, _, ids = _fasta_per_sequence(fasta_path, sanitize_mode, False, True)
+    return per_seq, ids
+
+
+def count_factors_fasta_dna_w_rc_per_sequence(fasta_path, sanitize_mode: str = "remove_ambiguous"):
+    """reference: bindings.cpp:1372-1389 -> (counts, sequence ids, total)"""
+    _, counts, ids = _fasta_per_sequence(fasta_path, sanitize_mode, True, False)
+    return counts, ids, sum(counts)
+
+
+def count_factors_fasta_dna_no_rc_per_sequence(fasta_path, sanitize_mode: str = "remove_ambiguous"):
+    _, counts, ids = _fasta_per_sequence(fasta_path, sanitize_mode, False, False)
+    return counts, ids, sum(counts)
+
+
+def write_factors_binary_file_fasta_dna_w_rc_per_sequence(fasta_path, out_dir, sanitize_mode: str = "remove_ambiguous"):
+    """reference: bindings.cpp:1312-1319 -> total number of factors; one <id>.bin per record"""
+    _, counts, _ = _fasta_per_sequence(fasta_path, sanitize_mode, True, False, out_dir)
+    return sum(counts)
+
+
+def write_factors_binary_file_fasta_dna_no_rc_per_sequence(fasta_path, out_dir, sanitize_mode: str = "remove_ambiguous"):
+    _, counts, _ = _fasta_per_sequence(fasta_path, sanitize_mode, False, False, out_dir)
+    return sum(counts)
+
+
+def parallel_write_factors_binary_file_fasta_dna_w_rc_per_sequence(fasta_path, out_dir, num_threads: int = 0,
+                                                                   sanitize_mode: str = "remove_ambiguous"):
+    return write_factors_binary_file_fasta_dna_w_rc_per_sequence(fasta_path, out_dir, sanitize_mode)
+
+
+def parallel_write_factors_binary_file_fasta_dna_no_rc_per_sequence(fasta_path, out_dir, num_threads: int = 0,
+                                                                    sanitize_mode: str = "remove_ambiguous"):
+    return write_factors_binary_file_fasta_dna_no_rc_per_sequence(fasta_path, out_dir, sanitize_mode)
 
 
 # ---- thread-parallel API (SURVEY.md 8f.4): same results, num_threads is irrelevant on the GPU ---
@@ -487,29 +655,3 @@ def debug_scan(data, mode: int):
     data = np.ascontiguousarray(data, dtype=np.uint32).copy()
     check(lib.nolzss_debug_scan(data.ctypes.data, data.size, mode, _default_device))
     return data
-
-
-# ---- names of the reference module that are outside the hot path -----------------------------
-def _not_on_path(name):
-    def f(*args, **kwargs):
-        raise NotImplementedError(
-            f"_noLZSS.{name} is outside the MI355X hot path of this build (SURVEY.md section 8); "
-            "only the factorize / count_factors / *_dna_w_rc / prepare_* entry points are provided")
-    f.__name__ = name
-    return f
-
-
-for _n in [
-    "factorize_file_dna_w_rc", "count_factors_file_dna_w_rc", "factorize_file_multiple_dna_w_rc",
-    "count_factors_file_multiple_dna_w_rc", "write_factors_binary_file_multiple_dna_w_rc",
-    "factorize_dna_rc_w_ref_fasta_files", "write_factors_dna_w_reference_fasta_files_to_binary",
-    "parallel_write_factors_dna_w_reference_fasta_files_to_binary",
-    "factorize_fasta_dna_w_rc_per_sequence", "factorize_fasta_dna_no_rc_per_sequence",
-    "write_factors_binary_file_fasta_dna_w_rc_per_sequence",
-    "write_factors_binary_file_fasta_dna_no_rc_per_sequence",
-    "count_factors_fasta_dna_w_rc_per_sequence", "count_factors_fasta_dna_no_rc_per_sequence",
-    "parallel_write_factors_binary_file_fasta_dna_w_rc_per_sequence",
-    "parallel_write_factors_binary_file_fasta_dna_no_rc_per_sequence",
-]:
-    globals()[_n] = _not_on_path(_n)
-del _n

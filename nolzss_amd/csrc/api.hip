@@ -5,6 +5,8 @@
 #include <algorithm>
 #include <atomic>
 #include <cctype>
+#include <cerrno>
+#include <sys/stat.h>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -813,10 +815,97 @@ void factorize_fasta(const char *path, bool with_rc, bool strict, int device, Fa
     out.sentinel_idx = sentinel_factors(out.factors, out.z, sent);  // :314 / :337
 }
 
+// factorize_dna_rc_w_ref_fasta_files, fasta_processor.cpp:240-287, 362-378
+void factorize_ref_target_fasta(const char *ref_path, const char *tgt_path, bool strict, int device,
+                                FastaFactors &out) {
+    FastaParse ref = parse_fasta(ref_path, strict);
+    FastaParse tgt = parse_fasta(tgt_path, strict);
+    size_t target_start = 0;
+    for (const auto &q : ref.sequences) target_start += q.size() + 1;  // +1 for each sentinel (:249-252)
+    out.parse.sequences = ref.sequences;
+    out.parse.ids = ref.ids;
+    out.parse.sequences.insert(out.parse.sequences.end(), tgt.sequences.begin(), tgt.sequences.end());
+    out.parse.ids.insert(out.parse.ids.end(), tgt.ids.begin(), tgt.ids.end());
+    std::vector<const char *> ptrs;
+    std::vector<size_t> lens;
+    for (const auto &q : out.parse.sequences) {
+        ptrs.push_back(q.data());
+        lens.push_back(q.size());
+    }
+    std::vector<uint8_t> S;
+    std::vector<uint64_t> sent;
+    size_t orig = 0;
+    prepare_w_rc(ptrs.data(), lens.data(), ptrs.size(), S, orig, sent);
+    if (rc_guards(S.size(), target_start)) {
+        Session ses(device, nullptr);
+        out.z = run_rc_host(ses.ctx(), S.data(), S.size(), target_start, &out.factors);
+    }
+    out.sentinel_idx = sentinel_factors(out.factors, out.z, sent);
+}
+
+void fill_fasta_result(FastaFactors &ff, nolzss_fasta_result *out) {
+    std::string blob;
+    for (const auto &id : ff.parse.ids) blob.append(id).push_back('\0');
+    uint64_t *sidx = static_cast<uint64_t *>(std::malloc(ff.sentinel_idx.size() * sizeof(uint64_t) + 8));
+    char *ids = static_cast<char *>(std::malloc(blob.size() + 1));
+    if (!sidx || !ids) {
+        std::free(sidx);
+        std::free(ids);
+        throw std::bad_alloc();
+    }
+    if (!ff.sentinel_idx.empty())
+        std::memcpy(sidx, ff.sentinel_idx.data(), ff.sentinel_idx.size() * sizeof(uint64_t));
+    std::memcpy(ids, blob.data(), blob.size());
+    out->factors = ff.factors;
+    ff.factors = nullptr;  // ownership moves to the caller
+    out->num_factors = ff.z;
+    out->sentinel_factor_indices = sidx;
+    out->num_sentinels = ff.sentinel_idx.size();
+    out->sequence_ids = ids;
+    out->sequence_ids_bytes = blob.size();
+    out->num_sequences = ff.parse.ids.size();
+}
+
+// write_fasta_metadata, parallel_fasta_processor.cpp:29-62: names, sentinel indices, footer
+void write_fasta_file(const char *out_path, const FastaFactors &ff) {
+    std::string extra;
+    for (const auto &id : ff.parse.ids) extra.append(id).push_back('\0');
+    extra.append(reinterpret_cast<const char *>(ff.sentinel_idx.data()), ff.sentinel_idx.size() * sizeof(uint64_t));
+    uint64_t total = 0;
+    for (size_t i = 0; i < ff.z; ++i) total += ff.factors[i].length;
+    write_v2_file(out_path, ff.factors, ff.z, ff.parse.ids.size(), ff.sentinel_idx.size(), total, extra);
+}
+
 }  // namespace
 }  // namespace nolzss
 
 extern "C" {
+
+int nolzss_factorize_dna_rc_w_ref_fasta_files(const char *reference_fasta_path, const char *target_fasta_path,
+                                              int sanitize_mode, int device, nolzss_fasta_result *out) {
+    return guarded([&] {
+        if (!out) throw std::invalid_argument("output pointer is null");
+        std::memset(out, 0, sizeof *out);
+        if (sanitize_mode != 0 && sanitize_mode != 1) throw std::invalid_argument("sanitize_mode must be 0 or 1");
+        FastaFactors ff;
+        factorize_ref_target_fasta(reference_fasta_path, target_fasta_path, sanitize_mode == 1, device, ff);
+        fill_fasta_result(ff, out);
+    });
+}
+
+int nolzss_write_factors_dna_w_reference_fasta_files_to_binary(const char *reference_fasta_path,
+                                                               const char *target_fasta_path, const char *out_path,
+                                                               int sanitize_mode, int device, size_t *z) {
+    return guarded([&] {
+        if (!z) throw std::invalid_argument("output pointer is null");
+        *z = 0;
+        if (sanitize_mode != 0 && sanitize_mode != 1) throw std::invalid_argument("sanitize_mode must be 0 or 1");
+        FastaFactors ff;
+        factorize_ref_target_fasta(reference_fasta_path, target_fasta_path, sanitize_mode == 1, device, ff);
+        write_fasta_file(out_path, ff);
+        *z = ff.z;
+    });
+}
 
 int nolzss_write_factor_file(const char *out_path, const nolzss_factor *factors, size_t z, uint64_t num_sequences,
                              uint64_t num_sentinels, uint64_t total_length, const void *extra, size_t extra_len) {
@@ -866,26 +955,7 @@ int nolzss_factorize_fasta_multiple_dna(const char *fasta_path, int with_rc, int
         if (sanitize_mode != 0 && sanitize_mode != 1) throw std::invalid_argument("sanitize_mode must be 0 or 1");
         FastaFactors ff;
         factorize_fasta(fasta_path, with_rc != 0, sanitize_mode == 1, device, ff);
-        std::string blob;
-        for (const auto &id : ff.parse.ids) blob.append(id).push_back('\0');
-        uint64_t *sidx = static_cast<uint64_t *>(std::malloc(ff.sentinel_idx.size() * sizeof(uint64_t) + 8));
-        char *ids = static_cast<char *>(std::malloc(blob.size() + 1));
-        if (!sidx || !ids) {
-            std::free(sidx);
-            std::free(ids);
-            throw std::bad_alloc();
-        }
-        if (!ff.sentinel_idx.empty())
-            std::memcpy(sidx, ff.sentinel_idx.data(), ff.sentinel_idx.size() * sizeof(uint64_t));
-        std::memcpy(ids, blob.data(), blob.size());
-        out->factors = ff.factors;
-        ff.factors = nullptr;  // ownership moves to the caller
-        out->num_factors = ff.z;
-        out->sentinel_factor_indices = sidx;
-        out->num_sentinels = ff.sentinel_idx.size();
-        out->sequence_ids = ids;
-        out->sequence_ids_bytes = blob.size();
-        out->num_sequences = ff.parse.ids.size();
+        fill_fasta_result(ff, out);
     });
 }
 
@@ -905,14 +975,91 @@ int nolzss_write_factors_binary_file_fasta_multiple_dna(const char *fasta_path, 
         if (sanitize_mode != 0 && sanitize_mode != 1) throw std::invalid_argument("sanitize_mode must be 0 or 1");
         FastaFactors ff;
         factorize_fasta(fasta_path, with_rc != 0, sanitize_mode == 1, device, ff);
-        // write_fasta_metadata, parallel_fasta_processor.cpp:29-62: names, sentinel indices, footer
-        std::string extra;
-        for (const auto &id : ff.parse.ids) extra.append(id).push_back('\0');
-        extra.append(reinterpret_cast<const char *>(ff.sentinel_idx.data()), ff.sentinel_idx.size() * sizeof(uint64_t));
-        uint64_t total = 0;
-        for (size_t i = 0; i < ff.z; ++i) total += ff.factors[i].length;
-        write_v2_file(out_path, ff.factors, ff.z, ff.parse.ids.size(), ff.sentinel_idx.size(), total, extra);
+        write_fasta_file(out_path, ff);
         *z = ff.z;
+    });
+}
+
+void nolzss_free_fasta_per_sequence_result(nolzss_fasta_per_sequence_result *r) {
+    if (!r) return;
+    if (r->factors)
+        for (size_t j = 0; j < r->num_sequences; ++j) std::free(r->factors[j]);
+    std::free(r->factors);
+    std::free(r->counts);
+    std::free(r->sequence_ids);
+    std::memset(r, 0, sizeof *r);
+}
+
+int nolzss_factorize_fasta_per_sequence(const char *fasta_path, int with_rc, int sanitize_mode, int want_factors,
+                                        const char *out_dir, int device, nolzss_fasta_per_sequence_result *out) {
+    return guarded([&] {
+        if (!out) throw std::invalid_argument("output pointer is null");
+        std::memset(out, 0, sizeof *out);
+        if (sanitize_mode != 0 && sanitize_mode != 1) throw std::invalid_argument("sanitize_mode must be 0 or 1");
+        FastaParse parse = parse_fasta(fasta_path, sanitize_mode == 1);
+        const size_t m = parse.sequences.size();
+        if (out_dir) {  // fs::create_directories(out_dir), parallel_fasta_processor.cpp:343
+            std::string cmd_path(out_dir);
+            for (size_t pos = 1; pos <= cmd_path.size(); ++pos)
+                if (pos == cmd_path.size() || cmd_path[pos] == '/') {
+                    const std::string part = cmd_path.substr(0, pos);
+                    if (!part.empty() && ::mkdir(part.c_str(), 0777) != 0 && errno != EEXIST)
+                        throw std::runtime_error("Cannot create output directory: " + part);
+                }
+        }
+        nolzss_fasta_per_sequence_result res;
+        std::memset(&res, 0, sizeof res);
+        res.num_sequences = m;
+        res.counts = static_cast<size_t *>(std::calloc(m ? m : 1, sizeof(size_t)));
+        const bool keep = want_factors != 0;
+        res.factors = keep ? static_cast<nolzss_factor **>(std::calloc(m ? m : 1, sizeof(nolzss_factor *))) : nullptr;
+        std::string blob;
+        for (const auto &id : parse.ids) blob.append(id).push_back('\0');
+        res.sequence_ids = static_cast<char *>(std::malloc(blob.size() + 1));
+        if (!res.counts || (keep && !res.factors) || !res.sequence_ids) {
+            nolzss_free_fasta_per_sequence_result(&res);
+            throw std::bad_alloc();
+        }
+        std::memcpy(res.sequence_ids, blob.data(), blob.size());
+        res.sequence_ids_bytes = blob.size();
+        try {
+            for (size_t j = 0; j < m; ++j) {
+                const std::string &seq = parse.sequences[j];
+                nolzss_factor *f = nullptr;
+                size_t z = 0;
+                const bool need_f = keep || out_dir;
+                if (with_rc) {  // prepare({seq}) + factorize_multiple_dna_w_rc, fasta_processor.cpp:446-451
+                    dna_w_rc_common(reinterpret_cast<const uint8_t *>(seq.data()), seq.size(), device,
+                                    need_f ? &f : nullptr, &z);
+                } else {  // the reference strips the last base here (:469-471)
+                    const size_t len = seq.size() - 1;
+                    if (len > 0) {
+                        check_text_args(seq.data(), len, 0);
+                        Session ses(device, nullptr);
+                        z = run_plain_host(ses.ctx(), reinterpret_cast<const uint8_t *>(seq.data()), len, 0,
+                                           need_f ? &f : nullptr, nullptr);
+                    }
+                }
+                std::unique_ptr<nolzss_factor, decltype(&std::free)> hold(f, &std::free);
+                res.counts[j] = z;
+                if (out_dir) {  // write_single_sequence_factors, parallel_fasta_processor.cpp:262-290
+                    std::string safe = parse.ids[j];
+                    for (char &c : safe)
+                        if (c == '/' || c == '\\' || c == ':' || c == '*' || c == '?' || c == '"' || c == '<' ||
+                            c == '>' || c == '|' || c == ' ')
+                            c = '_';
+                    uint64_t total = 0;
+                    for (size_t i = 0; i < z; ++i) total += f[i].length;
+                    write_v2_file((std::string(out_dir) + "/" + safe + ".bin").c_str(), f, z, 1, 0, total,
+                                  parse.ids[j] + std::string(1, '\0'));
+                }
+                if (keep) res.factors[j] = hold.release();
+            }
+        } catch (...) {
+            nolzss_free_fasta_per_sequence_result(&res);
+            throw;
+        }
+        *out = res;
     });
 }
 

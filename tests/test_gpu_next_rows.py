@@ -204,3 +204,62 @@ def test_fasta_binary_files_and_parallel_aliases(pkg, tmp_path):
     rc_mask = 1 << 63
     got_rc = [(s, l, r & (rc_mask - 1), bool(r & rc_mask)) for s, l, r in pkg.read_factors_binary_file(dout)]
     assert zr == len(got_rc) and got_rc == oracle.factorize_dna_w_rc(text[:50_000])
+
+
+def test_per_sequence_fasta_and_ref_target_fasta(pkg, tmp_path):
+    """fasta_processor.cpp:430-561 (per record; the no-rc variants drop the last base, kept) and
+    :240-287, 362-378 (reference FASTA + target FASTA)"""
+    from nolzss_amd import _noLZSS
+    recs = [(f"id{k}/x extra words", gen.random_dna(1200 + 97 * k, 800 + k).tobytes().decode()) for k in range(4)]
+    path = tmp_path / "ps.fa"
+    with open(path, "w") as f:
+        for rid, seq in recs:
+            f.write(f">{rid}\n{seq}\n")
+    ids_expected = [rid.split()[0] for rid, _ in recs]
+    per_seq, ids = _noLZSS.factorize_fasta_dna_w_rc_per_sequence(str(path))
+    assert ids == ids_expected
+    for (_, seq), got in zip(recs, per_seq):
+        assert got == oracle.factorize_dna_w_rc(seq.encode())
+    per_seq2, ids2 = _noLZSS.factorize_fasta_dna_no_rc_per_sequence(str(path))
+    for (_, seq), got in zip(recs, per_seq2):
+        assert [(s, l, r) for s, l, r, _ in got] == oracle.factorize(seq[:-1].encode())   # last base dropped
+    counts, ids3, total = _noLZSS.count_factors_fasta_dna_w_rc_per_sequence(str(path))
+    assert counts == [len(x) for x in per_seq] and total == sum(counts) and ids3 == ids_expected
+    counts2, _, total2 = _noLZSS.count_factors_fasta_dna_no_rc_per_sequence(str(path))
+    assert counts2 == [len(x) for x in per_seq2] and total2 == sum(counts2)
+    out_dir = tmp_path / "per" / "seq"
+    assert _noLZSS.write_factors_binary_file_fasta_dna_w_rc_per_sequence(str(path), str(out_dir)) == total
+    for rid, got in zip(ids_expected, per_seq):
+        meta = pkg.read_factors_binary_file_with_metadata(out_dir / (rid.replace("/", "_") + ".bin"))
+        assert meta["factors"] == got and meta["sequence_names"] == [rid] and meta["num_sentinels"] == 0
+
+    ref_fa, tgt_fa = tmp_path / "ref.fa", tmp_path / "tgt.fa"
+    ref_seqs = [gen.random_dna(2000, 901).tobytes().decode(), gen.random_dna(1500, 902).tobytes().decode()]
+    tgt_seqs = [ref_seqs[0][100:900] + gen.random_dna(300, 903).tobytes().decode()]
+    ref_fa.write_text("".join(f">r{k}\n{s}\n" for k, s in enumerate(ref_seqs)))
+    tgt_fa.write_text("".join(f">t{k}\n{s}\n" for k, s in enumerate(tgt_seqs)))
+    factors, sentinels, ids4 = _noLZSS.factorize_dna_rc_w_ref_fasta_files(str(ref_fa), str(tgt_fa))
+    S, _, sent_pos = oracle.prepare_multiple_dna_w_rc(ref_seqs + tgt_seqs)
+    start = sum(len(s) + 1 for s in ref_seqs)
+    assert factors == oracle.factorize_multiple_dna_w_rc(S, start_pos=start)
+    assert ids4 == ["r0", "r1", "t0"] and factors[0][0] == start and factors[0][1] >= 800
+    out = tmp_path / "rt.bin"
+    assert _noLZSS.write_factors_dna_w_reference_fasta_files_to_binary(str(ref_fa), str(tgt_fa), str(out)) == len(factors)
+    meta = pkg.read_factors_binary_file_with_metadata(out)
+    assert meta["factors"] == factors and meta["sequence_names"] == ids4
+
+    # file variants of the RC entry points (factorizer.cpp:525-545, 575-577, 658-732, 751-790)
+    dna = tmp_path / "dna.txt"
+    dna.write_bytes(recs[0][1].encode())
+    assert _noLZSS.factorize_file_dna_w_rc(str(dna)) == per_seq[0]
+    assert _noLZSS.count_factors_file_dna_w_rc(str(dna)) == len(per_seq[0])
+    prepared = tmp_path / "prepared.bin"
+    prepared.write_bytes(S)
+    assert _noLZSS.factorize_file_multiple_dna_w_rc(str(prepared)) == oracle.factorize_multiple_dna_w_rc(S)
+    assert _noLZSS.count_factors_file_multiple_dna_w_rc(str(prepared)) == oracle.count_factors_multiple_dna_w_rc(S)
+    pout = tmp_path / "prepared_out.bin"
+    z = _noLZSS.write_factors_binary_file_multiple_dna_w_rc(str(prepared), str(pout))
+    raw = pout.read_bytes()
+    assert struct.unpack("<8sQQQQQ", raw[-48:]) == (b"noLZSSv2", z, 0, 0, 48, len(S))
+    with pytest.raises(RuntimeError, match="Cannot open input file"):
+        _noLZSS.factorize_file_dna_w_rc(str(tmp_path / "nope"))
