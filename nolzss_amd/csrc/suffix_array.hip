@@ -17,6 +17,7 @@
 #include "scan.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace nolzss {
 
@@ -366,165 +367,216 @@ __global__ __launch_bounds__(kThreads) void group_size_kernel(const uint32_t *__
 }
 
 // One workgroup refines all groups that START inside its kRefineTile list positions; every member
-// is a thread, all state lives in LDS.  Per round each still-tied member fetches the next 128 bits
-// of its own suffix (one random line per member per round -- never a pairwise re-read), the
-// members of a group compare their windows through LDS, tie classes split, and the loop ends when
-// the workgroup has no tie left or the cap is reached.  cls = number of strictly smaller members.
+// is a thread, all state lives in LDS.
+//   * Per round each still-tied member fetches the next kRefineWords * 64 bits of its own suffix
+//     (one random window per member per round -- never a pairwise re-read; an MI355X sustains
+//     ~40 G such windows/s, tools/gatherbench.hip) and parks it in LDS.
+//   * The comparisons are organised by PAIR, not by member: the unordered pairs of every group are
+//     listed in LDS once, each wavefront owns a stretch of that list, compares the two windows of
+//     64 pairs at a time and credits the loser (one more smaller member; the longest common prefix
+//     with a smaller member) with LDS atomics.  A decided pair never comes back; tied pairs are
+//     compacted to the front of the stretch for the next round.  Lanes therefore stay busy whatever
+//     the group sizes are -- a member-per-lane loop runs every wavefront as long as its largest
+//     group (group sizes on repeat-rich DNA: mean 3, size-weighted mean 6, tail to the cap), and
+//     the kernel is bound by instruction issue, not by the fetches (rocprofv3 SQ_INSTS_*).
+//   * cls = number of strictly smaller members; members still tied at the end keep list order.
+// A group whose pairs do not fit the list any more is left as it is (out_lo = 0): the doubling
+// rounds handle it like any other unfinished group.
 constexpr int kRefineTile = 256;
-constexpr int kRefineSpan = kRefineTile + (int)kSmallGroup;
+constexpr int kRefineThreads = kRefineTile + (int)kSmallGroup;  // one thread per possible member
+constexpr int kRefineWaves = kRefineThreads / 64;
+constexpr int kRefineWords = 8;
+constexpr int kPairCap = 3072;  // pairs per workgroup (256 members in groups of up to ~24 fit)
 
 template <int BITS>
-__global__ __launch_bounds__(kThreads) void group_refine_kernel(
+__global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(4, 6))) void group_refine_kernel(
     const uint32_t *__restrict__ act_slot, const uint32_t *__restrict__ act_grp, const uint32_t *__restrict__ gsize,
     const uint32_t *__restrict__ sa, const uint64_t *__restrict__ words, TermTable terms, uint32_t m, uint32_t h0,
     uint32_t cap, uint32_t *__restrict__ out_lo, uint32_t *__restrict__ out_vals,
     uint32_t *__restrict__ lcp_list) {
-    constexpr uint32_t kPerWord = 64 / BITS;
-    constexpr int kPerThread = (kRefineSpan + kThreads - 1) / kThreads;
-    __shared__ uint64_t s_w0[kRefineSpan], s_w1[kRefineSpan];
-    __shared__ uint32_t s_lim[kRefineSpan];   // symbols before the member's next terminator
-    __shared__ uint16_t s_term[kRefineSpan];  // index of that terminator
-    __shared__ uint16_t s_cls[kRefineSpan];   // strictly smaller members so far
-    __shared__ uint8_t s_act[kRefineSpan];    // still tied with somebody
+    constexpr int kW32 = 2 * kRefineWords;  // window in 32-bit words, text order
+    constexpr int kChunks = kW32 / 4;
+    constexpr uint32_t kPer32 = 32 / BITS;
+    constexpr uint32_t kPerRound = kW32 * kPer32;
+    __shared__ uint4 s_w[kChunks][kRefineThreads];  // chunk-major: a wave reads whole 16-byte rows
+    __shared__ uint32_t s_pair[kPairCap];           // (higher member) | (lower member) << 16
+    __shared__ uint32_t s_lim[kRefineThreads];      // symbols before the member's next terminator
+    __shared__ uint32_t s_cls[kRefineThreads];      // strictly smaller members found so far
+    __shared__ uint32_t s_best[kRefineThreads];     // longest common prefix with a smaller member
+    __shared__ uint32_t s_goff[kRefineThreads];     // [first member of a group] first pair of the group
+    __shared__ uint16_t s_term[kRefineThreads];     // index of the member's next terminator
+    __shared__ uint8_t s_tied[2][kRefineThreads];   // member takes part in a tied pair (ping-pong)
+    __shared__ uint32_t s_wtot[kRefineWaves];
+    __shared__ uint32_t s_npairs;
     const size_t a0 = (size_t)blockIdx.x * kRefineTile;
     const size_t a1 = (a0 + kRefineTile < m) ? a0 + kRefineTile : m;
+    const int t = threadIdx.x;
+    const int lane = lane_id();
+    const int w = t >> 6;
+    const size_t a = a0 + t;
 
-    uint32_t my_pos[kPerThread], my_lcp[kPerThread], my_lim[kPerThread];
-    uint16_t my_gl[kPerThread];  // local index of the group's first member
-    uint8_t my_gs[kPerThread];   // group size (0: not handled here)
-#pragma unroll
-    for (int j = 0; j < kPerThread; ++j) {
-        const int t = j * kThreads + threadIdx.x;
-        const size_t a = a0 + t;
-        my_gs[j] = 0;
-        my_gl[j] = 0;
-        my_pos[j] = 0;
-        my_lcp[j] = 0;
-        my_lim[j] = 0;
-        uint32_t my_term = 0;
-        bool mine = false;
-        if (t < kRefineSpan && a < m) {
-            const uint32_t g = act_grp[a];
-            const uint32_t slot = act_slot[a];
-            const size_t g0 = a - (slot - g);
-            const uint32_t sz = gsize[g0];
-            if (a < a1 && sz > kSmallGroup) {  // too large for this round: stays one group, in place
-                out_lo[a] = 0;
-                out_vals[a] = sa[slot];
-            }
-            mine = g0 >= a0 && g0 < a1 && sz <= kSmallGroup;
-            if (mine) {
-                my_gs[j] = (uint8_t)sz;
-                my_gl[j] = (uint16_t)(g0 - a0);
-                my_pos[j] = sa[slot];
-                my_term = term_lower_bound(terms, my_pos[j]);
-                my_lim[j] = terms.pos[my_term] - my_pos[j];
-            }
+    // ---- who is here: members of groups that start in this tile -------------------------------
+    uint32_t my_pos = 0, my_lim = 0, my_term = 0;
+    int my_gl = 0, my_gs = 0, my_j = 0;  // first member (local), group size (0: not mine), my index
+    if (a < m) {
+        const uint32_t g = act_grp[a];
+        const uint32_t slot = act_slot[a];
+        const size_t g0 = a - (slot - g);
+        const uint32_t sz = gsize[g0];
+        if (a < a1 && sz > kSmallGroup) {  // too large for this round: stays one group, in place
+            out_lo[a] = 0;
+            out_vals[a] = sa[slot];
         }
-        if (t < kRefineSpan) {
-            s_lim[t] = my_lim[j];
-            s_term[t] = (uint16_t)my_term;
-            s_cls[t] = 0;
-            s_act[t] = mine ? 1 : 0;
+        if (g0 >= a0 && g0 < a1 && sz <= kSmallGroup) {
+            my_gs = (int)sz;
+            my_gl = (int)(g0 - a0);
+            my_j = t - my_gl;
+            my_pos = sa[slot];
+            my_term = term_lower_bound(terms, my_pos);
+            my_lim = terms.pos[my_term] - my_pos;
         }
     }
+    // member j of a group lists its pairs with members 0 .. j-1: the list position is an exclusive
+    // scan of j over the tile
+    uint32_t inc = wave_scan_inclusive_dpp((uint32_t)my_j, 0u, OpAdd<uint32_t>());
+    if (lane == 63) s_wtot[w] = inc;
+    if (t == 0) s_npairs = 0;
+    s_lim[t] = my_lim;
+    s_term[t] = (uint16_t)my_term;
+    s_cls[t] = 0;
+    s_best[t] = 0;
     __syncthreads();
-
-    for (uint32_t h = h0; h < cap; h += 2 * kPerWord) {
-        int any = 0;
+    uint32_t my_off = inc - (uint32_t)my_j;
 #pragma unroll
-        for (int j = 0; j < kPerThread; ++j) {
-            const int t = j * kThreads + threadIdx.x;
-            if (t < kRefineSpan && s_act[t]) {
-                s_w0[t] = sym_word<BITS>(words, (uint64_t)my_pos[j] + h);
-                s_w1[t] = sym_word<BITS>(words, (uint64_t)my_pos[j] + h + kPerWord);
-                any = 1;
-            }
+    for (int k = 0; k < kRefineWaves; ++k)
+        if (k < w) my_off += s_wtot[k];
+    if (my_gs && my_j == 0) s_goff[t] = my_off;
+    __syncthreads();
+    bool handled = false;
+    if (my_gs) {
+        const uint32_t gend = s_goff[my_gl] + (uint32_t)(my_gs * (my_gs - 1) / 2);
+        handled = gend <= (uint32_t)kPairCap;  // the handled groups are a prefix of the tile's groups
+        if (handled) {
+            for (int y = 0; y < my_j; ++y) s_pair[my_off + y] = (uint32_t)t | ((uint32_t)(my_gl + y) << 16);
+            if (my_j == my_gs - 1) atomicMax(&s_npairs, gend);
+        } else {  // no room for its pairs: the group stays as it is
+            out_lo[a] = 0;
+            out_vals[a] = my_pos;
         }
-        if (!__syncthreads_or(any)) break;
-        uint16_t add[kPerThread];
-        uint8_t still[kPerThread];
+    }
+    s_tied[0][t] = handled ? 1 : 0;
+    __syncthreads();
+    // each wavefront owns a stretch of the pair list
+    const uint32_t npairs = s_npairs;
+    const uint32_t seg = ((npairs + kRefineWaves - 1) / kRefineWaves + 63u) & ~63u;
+    const uint32_t seg0 = (uint32_t)w * seg;
+    uint32_t cnt = seg0 < npairs ? (npairs - seg0 < seg ? npairs - seg0 : seg) : 0u;
+    const uint64_t lt = lanemask_lt();
+
+    int cur = 0;
+    if (npairs > 0) {
+        for (uint32_t h = h0; h < cap; h += kPerRound) {
+            if (s_tied[cur][t]) {  // the next kRefineWords words of my suffix, from symbol h
+                const uint64_t bit = ((uint64_t)my_pos + h) * BITS;
+                const uint64_t *src = words + (bit >> 6);
+                uint32_t r[kW32 + 2];  // text order: high half of each 64-bit word first
 #pragma unroll
-        for (int j = 0; j < kPerThread; ++j) {
-            const int t = j * kThreads + threadIdx.x;
-            add[j] = 0;
-            still[j] = 0;
-            if (t < kRefineSpan && s_act[t]) {
-                const uint64_t x0 = s_w0[t], x1 = s_w1[t];
-                const uint32_t cls = s_cls[t];
-                const uint32_t rem_t = my_lim[j] - h;  // symbols left before my terminator
-                uint32_t best = 0;
-                for (int e = 0; e < my_gs[j]; ++e) {
-                    const int u = my_gl[j] + e;
-                    if (u == t || !s_act[u] || s_cls[u] != cls) continue;
-                    const uint64_t y0 = s_w0[u], y1 = s_w1[u];
-                    const uint32_t rem_u = s_lim[u] - h;
-                    uint32_t valid = rem_t < rem_u ? rem_t : rem_u;
-                    valid = valid < 2 * kPerWord ? valid : 2 * kPerWord;
-                    uint32_t d;
-                    bool u_smaller;
-                    if (x0 != y0) {
-                        d = (uint32_t)__clzll((long long)(x0 ^ y0)) / BITS;
-                        u_smaller = y0 < x0;
-                    } else if (x1 != y1) {
-                        d = kPerWord + (uint32_t)__clzll((long long)(x1 ^ y1)) / BITS;
-                        u_smaller = y1 < x1;
-                    } else {
-                        d = 2 * kPerWord;
-                        u_smaller = false;
+                for (int k = 0; k <= kRefineWords; ++k) {
+                    const uint64_t v = src[k];
+                    r[2 * k] = (uint32_t)(v >> 32);
+                    r[2 * k + 1] = (uint32_t)v;
+                }
+                // bit-select instead of ?: -- the compiler turns the conditional form into a
+                // scratch array with a dynamic offset
+                const uint32_t skip = (bit & 32) ? 0xffffffffu : 0u;
+                const uint32_t o = (uint32_t)bit & 31;
+                uint32_t q[kW32 + 1], win[kW32];
+#pragma unroll
+                for (int k = 0; k <= kW32; ++k) q[k] = (r[k + 1] & skip) | (r[k] & ~skip);
+#pragma unroll
+                for (int k = 0; k < kW32; ++k) win[k] = o ? __builtin_amdgcn_alignbit(q[k], q[k + 1], 32 - o) : q[k];
+#pragma unroll
+                for (int c = 0; c < kChunks; ++c)
+                    s_w[c][t] = make_uint4(win[4 * c], win[4 * c + 1], win[4 * c + 2], win[4 * c + 3]);
+            }
+            s_tied[cur ^ 1][t] = 0;
+            __syncthreads();
+
+            uint32_t kept = 0;
+            bool any_tie = false;
+            for (uint32_t c0 = 0; c0 < cnt; c0 += 64) {
+                const bool have = c0 + lane < cnt;
+                const uint32_t item = have ? s_pair[seg0 + c0 + lane] : 0u;
+                const int x = (int)(item & 0xffffu), u = (int)(item >> 16);  // x > u in list order
+                bool tie = false;
+                if (have) {
+                    const uint32_t rem_x = s_lim[x] - h, rem_u = s_lim[u] - h;  // symbols before the terminators
+                    uint32_t valid = rem_x < rem_u ? rem_x : rem_u;
+                    valid = valid < kPerRound ? valid : kPerRound;
+                    uint32_t d = kPerRound;
+                    bool u_smaller = false, found = false;
+#pragma unroll
+                    for (int c = 0; c < kChunks; ++c) {
+                        if (!found) {
+                            const uint4 p = s_w[c][x], y = s_w[c][u];
+                            if (((p.x ^ y.x) | (p.y ^ y.y) | (p.z ^ y.z) | (p.w ^ y.w)) != 0) {
+                                found = true;
+                                uint32_t xd = p.w, yd = y.w, i = 3;
+                                if (p.z != y.z) { xd = p.z; yd = y.z; i = 2; }
+                                if (p.y != y.y) { xd = p.y; yd = y.y; i = 1; }
+                                if (p.x != y.x) { xd = p.x; yd = y.x; i = 0; }
+                                d = ((uint32_t)(4 * c) + i) * kPer32 + (uint32_t)__clz((int)(xd ^ yd)) / BITS;
+                                u_smaller = yd < xd;
+                            }
+                        }
                     }
                     if (d >= valid) {
-                        if (valid == 2 * kPerWord) {  // equal window, both suffixes go on: tie
-                            still[j] = 1;
-                            continue;
+                        if (valid == kPerRound) {  // equal windows, both suffixes go on
+                            tie = true;
+                        } else {  // a terminator is reached: nearer one first, then lower index
+                            d = valid;
+                            u_smaller = rem_u != rem_x ? rem_u < rem_x : s_term[u] < s_term[x];
                         }
-                        d = valid;  // a terminator is reached: nearer one first, then lower index
-                        u_smaller = rem_u != rem_t ? rem_u < rem_t : s_term[u] < s_term[t];
                     }
-                    if (u_smaller) {
-                        ++add[j];
-                        best = (h + d) > best ? (h + d) : best;
+                    if (!tie) {
+                        const int loser = u_smaller ? x : u;  // the greater suffix
+                        atomicAdd(&s_cls[loser], 1u);
+                        atomicMax(&s_best[loser], h + d);  // deeper rounds only find longer prefixes
+                    } else {
+                        s_tied[cur ^ 1][x] = 1;
+                        s_tied[cur ^ 1][u] = 1;
                     }
                 }
-                if (add[j]) my_lcp[j] = best;  // deeper rounds only ever find longer prefixes
+                const uint64_t bal = __ballot(tie);  // tied pairs move to the front of the stretch
+                if (tie) s_pair[seg0 + kept + (uint32_t)__popcll(bal & lt)] = item;
+                kept += (uint32_t)__popcll(bal);
+                any_tie |= tie;
             }
+            cnt = kept;
+            cur ^= 1;
+            // A workgroup that is still mostly tied after two windows sits on a long exact repeat:
+            // comparing on to the cap would cost a window fetch per member per round for nothing.
+            // Leave those ties to the doubling rounds, which need only log2(LCP) steps.
+            const int busy = __syncthreads_count(any_tie);
+            if (busy == 0 || (h >= h0 + kPerRound && busy > kRefineThreads / 4)) break;
         }
-        __syncthreads();
-        int tied = 0;
-#pragma unroll
-        for (int j = 0; j < kPerThread; ++j) {
-            const int t = j * kThreads + threadIdx.x;
-            if (t < kRefineSpan && s_act[t]) {
-                s_cls[t] = (uint16_t)(s_cls[t] + add[j]);
-                s_act[t] = still[j];
-                tied |= still[j];
-            }
-        }
-        // A workgroup that is still mostly tied after 256 symbols sits on a long exact repeat:
-        // comparing on to the cap would cost a line fetch per member per round for nothing.
-        // Leave those ties to the doubling rounds, which need only log2(LCP) steps.
-        const int busy = __syncthreads_count(tied);
-        if (h >= h0 + 3 * 2 * kPerWord && busy > kThreads / 4) break;
     }
 
-#pragma unroll
-    for (int j = 0; j < kPerThread; ++j) {
-        const int t = j * kThreads + threadIdx.x;
-        if (t < kRefineSpan && my_gs[j]) {
-            uint32_t ties_before = 0;
-            if (s_act[t]) {  // still tied at the cap: keep list order inside the class
-                for (int e = 0; e < my_gs[j]; ++e) {
-                    const int u = my_gl[j] + e;
-                    if (u < t && s_act[u] && s_cls[u] == s_cls[t]) ++ties_before;
-                }
-            }
-            const size_t pos = a0 + my_gl[j] + s_cls[t] + ties_before;
-            out_lo[pos] = s_cls[t];
-            out_vals[pos] = my_pos[j];
-            // LCP to the predecessor in the new order: the closest smaller member shares the
-            // longest prefix; a tied predecessor (then this is not a new head) stays pending
-            lcp_list[pos] = ties_before ? kLcpPending : my_lcp[j];
-        }
+    // ---- members still tied keep their list order: count the tied partners in front of me --------
+    // (s_goff is free now)
+    s_goff[t] = 0;
+    __syncthreads();
+    for (uint32_t c0 = 0; c0 < cnt; c0 += 64)
+        if (c0 + lane < cnt) atomicAdd(&s_goff[s_pair[seg0 + c0 + lane] & 0xffffu], 1u);
+    __syncthreads();
+    if (handled) {
+        const uint32_t cls = s_cls[t], ties_before = s_goff[t];
+        const size_t pos = a0 + my_gl + cls + ties_before;
+        out_lo[pos] = cls;
+        out_vals[pos] = my_pos;
+        // LCP to the predecessor in the new order: the closest smaller member shares the
+        // longest prefix; a tied predecessor (then this is not a new head) stays pending
+        lcp_list[pos] = ties_before ? kLcpPending : s_best[t];
     }
 }
 
@@ -695,7 +747,7 @@ PackedText pack_text(Context &ctx, const uint8_t *d_text, size_t n) {
     t.terms.pos = d_terms;
     t.terms.count = (uint32_t)table.size();
 
-    const size_t nwords = div_up(n * (size_t)t.bits, 64) + 4;  // zero pad: windows read past the end
+    const size_t nwords = div_up(n * (size_t)t.bits, 64) + kRefineWords + 4;  // zero pad: windows read past the end
     uint64_t *words = ctx.arena.alloc<uint64_t>(nwords);
     {
         ProfScope ps(ctx.profiler(), "text_pack", s);
@@ -801,6 +853,8 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
 
     int rounds = 0, a_cur = 0;
     uint64_t h = (uint64_t)k_syms;
+    static const bool trace = getenv("NOLZSS_TRACE") != nullptr;  // active-list sizes to stderr
+    if (trace) fprintf(stderr, "[nolzss] n=%u: %u suffixes tied after the %d-symbol key sort\n", n, m, k_syms);
 
     // one pass writes rank[] for everybody: rank[sa[slot]] = rank_by_slot[slot]
     auto write_all_ranks = [&] {
@@ -816,8 +870,9 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     if (m > 0 && h < n) {
         const uint32_t *slot = act_slot[a_cur], *grp = act_grp[a_cur];
         uint32_t *lcp_list = arena.alloc<uint32_t>(m);
-        // at most 64 words (2048 bases) deep; longer ties are cheaper in the doubling rounds
-        const uint32_t cap = (uint32_t)k_syms + 64u * (64u / (uint32_t)text.bits);
+        // at most 32 words (1024 bases of DNA) deep; longer ties are cheaper in the doubling rounds
+        static const uint32_t cap_words = getenv("NOLZSS_REFINE_WORDS") ? (uint32_t)atoi(getenv("NOLZSS_REFINE_WORDS")) : 32u;
+        const uint32_t cap = (uint32_t)k_syms + cap_words * (64u / (uint32_t)text.bits);
         uint32_t *gsize = arena.alloc<uint32_t>(m);
         {
             ProfScope ps(ctx.profiler(), "sa_direct_sort", s);
@@ -826,15 +881,15 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
             const unsigned g = (unsigned)div_up(m, kRefineTile);
             switch (text.bits) {
             case 2:
-                group_refine_kernel<2><<<g, kThreads, 0, s>>>(slot, grp, gsize, sa, text.words, text.terms, m, (uint32_t)h, cap,
+                group_refine_kernel<2><<<g, kRefineThreads, 0, s>>>(slot, grp, gsize, sa, text.words, text.terms, m, (uint32_t)h, cap,
                                                               out_lo, out_vals, lcp_list);
                 break;
             case 4:
-                group_refine_kernel<4><<<g, kThreads, 0, s>>>(slot, grp, gsize, sa, text.words, text.terms, m, (uint32_t)h, cap,
+                group_refine_kernel<4><<<g, kRefineThreads, 0, s>>>(slot, grp, gsize, sa, text.words, text.terms, m, (uint32_t)h, cap,
                                                               out_lo, out_vals, lcp_list);
                 break;
             default:
-                group_refine_kernel<8><<<g, kThreads, 0, s>>>(slot, grp, gsize, sa, text.words, text.terms, m, (uint32_t)h, cap,
+                group_refine_kernel<8><<<g, kRefineThreads, 0, s>>>(slot, grp, gsize, sa, text.words, text.terms, m, (uint32_t)h, cap,
                                                               out_lo, out_vals, lcp_list);
                 break;
             }
@@ -844,6 +899,7 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
                            act_grp[a_cur ^ 1], tmp_a, tmp_b, tmp_c, scratch_idx, scratch_val, rank_val, d_total, lcp,
                            0, 0, 0, lcp_list, 0, (uint32_t)h, rank_by_slot);
         a_cur ^= 1;
+        if (trace) fprintf(stderr, "[nolzss]   direct round (cap %u symbols): %u still tied\n", cap, m);
         // h stays K: the large groups are only K-sorted
     }
     write_all_ranks();
@@ -884,6 +940,9 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
                            act_grp[a_cur ^ 1], tmp_a, tmp_b, tmp_c, scratch_idx, scratch_val, rank_val, d_total, lcp,
                            0, 0, 0, nullptr, 0, (uint32_t)h);
         a_cur ^= 1;
+        if (trace)
+            fprintf(stderr, "[nolzss]   doubling round h=%llu: %u in large groups, %u still tied\n",
+                    (unsigned long long)h, n_large, m);
         h *= 2;
         ++rounds;
     }

@@ -35,7 +35,7 @@ __device__ __forceinline__ uint32_t term_lower_bound(const TermTable &t, uint32_
 }
 
 struct PackedText {
-    const uint64_t *words = nullptr;  // ceil(n*bits/64) + 4 zero pad words
+    const uint64_t *words = nullptr;  // ceil(n*bits/64) + 12 zero pad words
     uint32_t n = 0;
     int bits = 0;    // 2, 4 or 8
     int sigma = 0;   // distinct byte values present

@@ -1,0 +1,39 @@
+#!/bin/bash
+# tools/pmc_kernel.sh <kernel-regex> <out-name> <probe args...>
+# Collects hardware counters for one kernel of the pipeline (rocprofv3 --pmc, one pass per counter
+# group, kernel trace only) while tools/probe.py factorizes a text.  Run on the GPU box.
+set -e
+KREGEX="$1"; OUT="$2"; shift 2
+ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+mkdir -p "$ROOT/gpurun_out/$OUT"
+cd /tmp && export TMPDIR=/tmp
+i=0
+for group in \
+  "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY" \
+  "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS" \
+  "TA_BUSY_avr TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum" \
+  "TCP_TOTAL_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum" \
+  "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_REQ_sum" \
+  "GRBM_GUI_ACTIVE FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $group --kernel-include-regex "$KREGEX" --output-format csv \
+     -d "$ROOT/gpurun_out/$OUT/p$i" -o pmc -- python3 "$ROOT/tools/probe.py" "$@" > "$ROOT/gpurun_out/$OUT/p$i.log" 2>&1 || echo "pass $i failed"
+  echo "pass $i done"
+done
+python3 - "$ROOT/gpurun_out/$OUT" <<'PY'
+import csv, glob, sys, collections
+root = sys.argv[1]
+acc = collections.defaultdict(lambda: collections.defaultdict(float)); calls = collections.Counter()
+for f in glob.glob(root + "/p*/**/*counter_collection.csv", recursive=True):
+    seen = set()
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0][-60:]
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        seen.add((k, r["Dispatch_Id"]))
+    for k, _ in seen: calls[(k, f)] += 1
+with open(root + "/summary.txt", "w") as out:
+    for k, d in acc.items():
+        out.write(k + "\n")
+        for c, v in sorted(d.items()): out.write(f"  {c:40s} {v:.6g}\n")
+print(open(root + "/summary.txt").read())
+PY
