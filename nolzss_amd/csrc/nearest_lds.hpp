@@ -25,6 +25,7 @@ constexpr int kLdsPerWave = kLdsTile / kLdsWaves;   // 256 ranks per wavefront
 constexpr int kLdsReach = 256;                      // steps each way that stay inside LDS
 constexpr int kLdsSpan = kLdsTile + 2 * kLdsReach;
 constexpr int kLdsStep = 8;                         // steps per round
+constexpr int kLdsStep0 = 4;                        // steps of the first round (4/5 of the searches end there)
 constexpr uint32_t kFarLen = 0xffffffffu;           // res_len marker: search left the reach
 constexpr uint32_t kLdsSparse = 24;                 // work-list length below which the wave gangs up
 
@@ -50,12 +51,13 @@ __device__ __forceinline__ void stage_tile(const uint32_t *__restrict__ sa, cons
 // Returns 0 = finished without a match (len 0), 1 = match (m = its LCP, pos = its suffix start),
 // 2 = still searching.  No bounds logic is needed: LCP[0] = LCP[n] = 0 (and 0 is staged outside
 // the array), so the running minimum dies exactly when a search would leave the array.
+template <int kSteps>
 __device__ __forceinline__ int lds_scan_round(const uint32_t *s_sa, const uint32_t *s_lcp, int li, int s0,
                                               bool greater, bool up, uint32_t x, uint32_t &m, uint32_t &pos) {
-    uint32_t c[kLdsStep], v[kLdsStep];
+    uint32_t c[kSteps], v[kSteps];
     const int dir = up ? -1 : 1;
 #pragma unroll
-    for (int k = 0; k < kLdsStep; ++k) {
+    for (int k = 0; k < kSteps; ++k) {
         const int q = li + dir * (s0 + k + 1);
         c[k] = s_lcp[q + (up ? 1 : 0)];
         v[k] = s_sa[q];
@@ -64,14 +66,14 @@ __device__ __forceinline__ int lds_scan_round(const uint32_t *s_sa, const uint32
     const uint32_t flip = greater ? 0xffffffffu : 0u;
     const uint32_t xf = x ^ flip;
 #pragma unroll
-    for (int k = 0; k < kLdsStep; ++k) {  // running minima
+    for (int k = 0; k < kSteps; ++k) {  // running minima
         m = c[k] < m ? c[k] : m;
         c[k] = m;
     }
     int status = 2;
     uint32_t len = m;
 #pragma unroll
-    for (int k = kLdsStep - 1; k >= 0; --k) {  // the earliest stopping step wins
+    for (int k = kSteps - 1; k >= 0; --k) {  // the earliest stopping step wins
         const bool dead = c[k] == 0;
         const bool stop = dead || (v[k] ^ flip) < xf;
         status = stop ? (dead ? 0 : 1) : status;
@@ -112,11 +114,12 @@ __device__ __forceinline__ void lds_search_wave(const uint32_t *s_sa, const uint
             const bool greater = k >= 2, up = (k & 1) == 0;
             uint32_t m = 0xffffffffu, pos = kNoPos;
             int st = 0;
-            if (valid) st = lds_scan_round(s_sa, s_lcp, li, 0, greater, up, greater ? thr_gt(i) : i, m, pos);
+            if (valid) st = lds_scan_round<kLdsStep0>(s_sa, s_lcp, li, 0, greater, up, greater ? thr_gt(i) : i, m, pos);
             res_len[k * kLdsTile + t] = (st == 0) ? 0u : m;
             if (k < NP) res_pos[k * kLdsTile + t] = (st == 1) ? pos : kNoPos;
             const bool pending = st == 2;
             const uint64_t bal = __ballot(pending);
+            // item = rank in the wave | search << 8 | (steps taken / kLdsStep0) << 10
             if (pending) lists[0][cnt + (uint32_t)__popcll(bal & lt)] = (uint16_t)(tl | (k << 8) | (1 << 10));
             cnt += (uint32_t)__popcll(bal);
         }
@@ -132,7 +135,7 @@ __device__ __forceinline__ void lds_search_wave(const uint32_t *s_sa, const uint
         for (uint32_t c0 = 0; c0 < cnt; c0 += 64) {
             const bool have = c0 + lane < cnt;
             const uint32_t item = have ? lists[cur][c0 + lane] : 0u;
-            const int tl = item & 255, k = (item >> 8) & 3, chunk = (int)(item >> 10);
+            const int tl = item & 255, k = (item >> 8) & 3, done = (int)(item >> 10) * kLdsStep0;
             const int t = w * kLdsPerWave + tl;
             const int li = t + kLdsReach;
             const bool greater = k >= 2, up = (k & 1) == 0;
@@ -140,16 +143,17 @@ __device__ __forceinline__ void lds_search_wave(const uint32_t *s_sa, const uint
             if (have) {
                 const uint32_t i = s_sa[li];
                 uint32_t m = res_len[k * kLdsTile + t], pos = kNoPos;
-                const int st = lds_scan_round(s_sa, s_lcp, li, chunk * kLdsStep, greater, up,
-                                              greater ? thr_gt(i) : i, m, pos);
-                const bool at_reach = (chunk + 1) * kLdsStep >= kLdsReach;
+                const int st = lds_scan_round<kLdsStep>(s_sa, s_lcp, li, done, greater, up,
+                                                        greater ? thr_gt(i) : i, m, pos);
+                const bool at_reach = done + 2 * kLdsStep > kLdsReach;  // the next round would leave the halo
                 pending = st == 2 && !at_reach;
                 res_len[k * kLdsTile + t] = (st == 0) ? 0u : ((st == 2 && at_reach) ? kFarLen : m);
                 if (k < NP) res_pos[k * kLdsTile + t] = (st == 1) ? pos : kNoPos;
             }
             const uint64_t bal = __ballot(pending);
             if (pending)
-                lists[cur ^ 1][next_cnt + (uint32_t)__popcll(bal & lt)] = (uint16_t)(tl | (k << 8) | ((chunk + 1) << 10));
+                lists[cur ^ 1][next_cnt + (uint32_t)__popcll(bal & lt)] =
+                    (uint16_t)(tl | (k << 8) | ((done + kLdsStep) / kLdsStep0 << 10));
             next_cnt += (uint32_t)__popcll(bal);
         }
         cur ^= 1;
@@ -164,7 +168,7 @@ __device__ __forceinline__ void lds_search_wave(const uint32_t *s_sa, const uint
     for (uint32_t e = 0; e < cnt; ++e) {
         const uint32_t item = lists[cur][e];  // same address in every lane: broadcast
         const int tl = item & 255, k = (item >> 8) & 3;
-        int s0 = (int)(item >> 10) * kLdsStep;
+        int s0 = (int)(item >> 10) * kLdsStep0;
         const int t = w * kLdsPerWave + tl;
         const int li = t + kLdsReach;
         const bool greater = k >= 2, up = (k & 1) == 0;

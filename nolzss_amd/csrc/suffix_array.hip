@@ -194,102 +194,236 @@ __device__ __forceinline__ bool is_head(const uint64_t *__restrict__ keys, const
     return grp[a] != grp[a - 1] || lo[a] != lo[a - 1];
 }
 
-// headpos[a] = slot(a) if sorted element a starts a new group else 0 (max-scanned afterwards)
-template <bool kRound0>
-__global__ __launch_bounds__(kThreads) void mark_heads_kernel(const uint64_t *__restrict__ keys,
-                                                              const uint32_t *__restrict__ grp,
-                                                              const uint32_t *__restrict__ lo,
-                                                              const uint32_t *__restrict__ act_slot, uint32_t m,
-                                                              uint32_t *__restrict__ headpos) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x; a < m; a += stride) {
-        const uint32_t slot = kRound0 ? (uint32_t)a : act_slot[a];
-        headpos[a] = is_head<kRound0>(keys, grp, lo, a) ? slot : 0u;
-    }
-}
-
 // LCP code while the suffix array is being built: the boundary has not appeared yet (values
 // >= kLcpPendingMin act as +infinity in range minima).
 constexpr uint32_t kLcpPending = 0xffffffffu;
 constexpr uint32_t kLcpPendingMin = kLcpPending - 64u;
 
-// writes the new order and ranks; keep[a] = 1 while a's group still has more than one member
+// ---- single-pass regroup --------------------------------------------------------------------
+// One kernel does what used to be five passes (mark heads, max-scan, commit, add-scan, compact):
+// every workgroup takes the next tile of the sorted view (ticket order), finds the group heads,
+// and obtains the two running values it needs from the tiles in front of it -- the slot of the
+// last group head (a max-scan) and the number of elements that stay active (an add-scan) -- by
+// decoupled look-back over per-tile descriptors in HBM: [status : value] in one 64-bit word,
+// status 1 = the tile's own aggregate, 2 = inclusive prefix.  Tickets are handed out in start
+// order, so a workgroup only ever waits for workgroups that are already running.
+// It then writes the new order (sa), the rank of every element (slot of its group head + 1), the
+// LCP of every boundary that became known, and the compacted active list for the next round.
+// HBM traffic at round 0: 12 B read + 12 B written per suffix plus 8 B per surviving element,
+// where the five passes moved ~88 B.
+constexpr int kFuseItems = 16;
+constexpr int kFuseTile = kThreads * kFuseItems;
+constexpr uint32_t kSpinLimit = 1u << 24;  // look-back polls before the kernel gives up (sets err)
+
+__device__ __forceinline__ uint64_t desc_load(const uint64_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void desc_store(uint64_t *p, uint64_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Run by the first wavefront of a workgroup: publishes the tile's aggregate, combines the
+// descriptors of the tiles in front (64 per step, nearest first) up to the first inclusive one,
+// publishes the tile's inclusive prefix and returns its exclusive prefix.
+template <typename Op>
+__device__ __forceinline__ uint32_t lookback_exclusive(uint64_t *desc, uint32_t tile, uint32_t aggregate, Op op,
+                                                       uint32_t *err) {
+    const int lane = lane_id();
+    if (tile == 0) {
+        if (lane == 0) desc_store(desc, (2ull << 32) | aggregate);
+        return Op::identity();
+    }
+    if (lane == 0) desc_store(desc + tile, (1ull << 32) | aggregate);
+    uint32_t excl = Op::identity();
+    int64_t look = (int64_t)tile - 1;
+    for (;;) {
+        const int64_t idx = look - lane;
+        uint64_t d, need, inc;
+        uint32_t spins = 0;
+        for (;;) {
+            d = idx >= 0 ? desc_load(desc + idx) : (2ull << 32);  // in front of tile 0: inclusive identity
+            const uint32_t st = (uint32_t)(d >> 32);
+            inc = __ballot(st == 2);
+            // every lane up to and including the first inclusive one must have been published
+            need = inc ? (((inc & (~inc + 1ull)) << 1) - 1ull) : ~0ull;
+            const uint64_t missing = __ballot(st == 0) & need;
+            if (!missing) break;
+            if (++spins > kSpinLimit) {  // cannot happen with ticket order; never hang the GPU
+                if (lane == 0) atomicExch(err, 1u);
+                return excl;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        const uint32_t v = ((need >> lane) & 1ull) ? (uint32_t)d : Op::identity();
+        excl = op(excl, wave_reduce(v, op));
+        if (inc) break;  // an inclusive prefix was reached
+        look -= 64;
+    }
+    if (lane == 0) desc_store(desc + tile, (2ull << 32) | op(excl, aggregate));
+    return excl;
+}
+
+struct RegroupArgs {
+    const uint64_t *keys;     // round 0: sorted keys
+    const uint32_t *grp;      // later rounds: (group head slot, secondary key) per list element
+    const uint32_t *lo;
+    const uint32_t *vals;     // suffix start per element
+    const uint32_t *act_slot; // later rounds: slot per list element
+    uint32_t m;
+    uint32_t *sa;
+    uint32_t *rank_val;       // rank per list element (when rank_by_slot == nullptr)
+    uint32_t *rank_by_slot;   // rank per slot
+    uint32_t *lcp;
+    int sym_bits, tag_bits, bits, low_bits;  // round 0 key layout
+    const uint32_t *lcp_list; // later rounds: LCP decided by the direct comparison round
+    uint32_t dbl_h;
+    Pyramid Plcp;
+    uint32_t *new_slot, *new_grp;  // compacted active list of the next round
+    uint64_t *desc_max, *desc_sum;
+    uint32_t *ticket;         // [0] tile tickets, [1] error flag
+    uint32_t *d_total;        // number of elements that stay active
+};
+
+// value of the previous / next lane of the wavefront (lane 0 / lane 63 keep `edge`)
+__device__ __forceinline__ uint32_t lane_prev(uint32_t v, uint32_t edge) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x138, 0xf, 0xf, false);  // wave_shr:1
+}
+__device__ __forceinline__ uint32_t lane_next(uint32_t v, uint32_t edge) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x130, 0xf, 0xf, false);  // wave_shl:1
+}
+
 template <bool kRound0>
-__global__ __launch_bounds__(kThreads) void commit_kernel(const uint64_t *__restrict__ keys,
-                                                          const uint32_t *__restrict__ grp,
-                                                          const uint32_t *__restrict__ lo,
-                                                          const uint32_t *__restrict__ vals,
-                                                          const uint32_t *__restrict__ act_slot,
-                                                          const uint32_t *__restrict__ head_of, uint32_t m,
-                                                          uint32_t *__restrict__ sa,
-                                                          uint32_t *__restrict__ rank_val,
-                                                          uint32_t *__restrict__ keep,
-                                                          uint32_t *__restrict__ lcp, int sym_bits, int tag_bits,
-                                                          int bits, const uint32_t *__restrict__ lcp_list,
-                                                          int low_bits, uint32_t dbl_h, Pyramid Plcp,
-                                                          uint32_t *__restrict__ rank_by_slot) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x; a < m; a += stride) {
-        const bool head = is_head<kRound0>(keys, grp, lo, a);
-        const bool next_head = (a + 1 == m) || is_head<kRound0>(keys, grp, lo, a + 1);
-        const uint32_t slot = kRound0 ? (uint32_t)a : act_slot[a];
-        const uint32_t i = vals[a];
-        sa[slot] = i;
-        if (rank_by_slot)
-            rank_by_slot[slot] = head_of[a] + 1u;  // rank[] itself is written later, in one pass
-        else
-            rank_val[a] = head_of[a] + 1u;  // goes to rank[i] through bucketed_scatter
-        keep[a] = (head && next_head) ? 0u : 1u;
-        if (!kRound0) {
+__global__ __launch_bounds__(kThreads) void regroup_kernel(RegroupArgs A) {
+    constexpr int kWaves = kThreads / 64;
+    constexpr int kSegs = kFuseItems * kWaves;  // 64-element segments of the tile, in element order
+    __shared__ uint32_t s_tile;
+    __shared__ uint32_t s_seg_max[kSegs], s_seg_sum[kSegs];  // per segment: last head slot, kept; then prefixes
+    __shared__ uint32_t s_excl[2];
+    if (threadIdx.x == 0) s_tile = atomicAdd(A.ticket, 1u);
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const uint32_t m = A.m;
+    const size_t tile_base = (size_t)tile * kFuseTile;
+    const int lane = lane_id();
+    const int w = threadIdx.x >> 6;
+    const uint64_t lt = lanemask_lt();
+
+    auto load_view = [&](size_t a) -> uint64_t {
+        if (kRound0) return A.keys[a];
+        return ((uint64_t)A.grp[a] << 32) | A.lo[a];
+    };
+    // striped: item k of thread t is element tile_base + k * kThreads + t (coalesced rows)
+    uint32_t slot[kFuseItems];
+    uint64_t hmask[kFuseItems], kmask[kFuseItems];  // wave-uniform: heads / kept elements of my segment
+#pragma unroll
+    for (int k = 0; k < kFuseItems; ++k) {
+        const size_t a = tile_base + (size_t)k * kThreads + threadIdx.x;
+        const bool in = a < m;
+        const uint64_t v = in ? load_view(a) : 0ull;
+        // the element in front: the previous lane's, except for lane 0
+        uint64_t edge = 0;
+        if (lane == 0 && in && a > 0) edge = load_view(a - 1);
+        const uint64_t pv = ((uint64_t)lane_prev((uint32_t)(v >> 32), (uint32_t)(edge >> 32)) << 32) |
+                            lane_prev((uint32_t)v, (uint32_t)edge);
+        slot[k] = kRound0 ? (uint32_t)a : (in ? A.act_slot[a] : 0u);
+        const bool head = !in || a == 0 || v != pv;  // "past the end" counts as a head
+        // is the element behind me a head?
+        uint32_t edge_next = 1;
+        if (lane == 63 && in && a + 1 < m) edge_next = load_view(a + 1) != v ? 1u : 0u;
+        const bool next_head = lane_next(head ? 1u : 0u, edge_next) != 0;
+        const bool keep = in && !(head && next_head);
+        hmask[k] = __ballot(in && head);
+        kmask[k] = __ballot(keep);
+        // the LCP of a boundary that has just appeared needs nothing from the other tiles
+        if (in && !kRound0) {
             // a new boundary inside an old group
-            if (head && a > 0 && grp[a] == grp[a - 1]) {
-                uint32_t v = lcp_list ? lcp_list[a] : kLcpPending;
-                if (v >= kLcpPendingMin) {
+            if (head && a > 0 && (uint32_t)(v >> 32) == (uint32_t)(pv >> 32)) {
+                uint32_t l = A.lcp_list ? A.lcp_list[a] : kLcpPending;
+                if (l >= kLcpPendingMin) {
                     // created by a doubling step with offset h: the two suffixes agree on h symbols
                     // and continue with suffixes of DIFFERENT h-groups, whose LCP is the minimum of
                     // the boundaries already decided between those groups (undecided entries hold
                     // pending codes, i.e. +infinity):  lcp = h + min LCP(head1 .. head2]
-                    const uint32_t p = lo[a - 1], q = lo[a];  // rank codes: group head slot + 1
-                    v = dbl_h;
-                    if (p != 0) v += pyr_range<false>(Plcp, p, q - 1);
+                    const uint32_t p = (uint32_t)pv, q = (uint32_t)v;  // rank codes: head slot + 1
+                    l = A.dbl_h;
+                    if (p != 0) l += pyr_range<false>(A.Plcp, p, q - 1);
                 }
-                lcp[slot] = v;
+                A.lcp[slot[k]] = l;
             }
-        }
-        if (kRound0) {
+        } else if (in) {
             // LCP of neighbours that round 0 already separates can be read off the two keys
             // (symbol prefix, capped by both length tags); the rest is marked pending.
             uint32_t l = kLcpPending;
             if (a == 0) {
                 l = 0;
             } else if (head) {
-                const uint64_t ka = keys[a] >> low_bits, kb = keys[a - 1] >> low_bits;
-                const uint64_t tmask = (1ull << tag_bits) - 1ull;
+                const uint64_t ka = v >> A.low_bits, kb = pv >> A.low_bits;
+                const uint64_t tmask = (1ull << A.tag_bits) - 1ull;
                 const uint32_t ta = (uint32_t)(ka & tmask), tb = (uint32_t)(kb & tmask);
-                const uint64_t x = (ka ^ kb) >> tag_bits << (64 - sym_bits);  // symbols, left-aligned
-                uint32_t ls = x ? (uint32_t)__clzll((long long)x) / (uint32_t)bits : 0xffffffffu;
+                const uint64_t x = (ka ^ kb) >> A.tag_bits << (64 - A.sym_bits);  // symbols, left-aligned
+                uint32_t ls = x ? (uint32_t)__clzll((long long)x) / (uint32_t)A.bits : 0xffffffffu;
                 ls = ls < ta ? ls : ta;
                 l = ls < tb ? ls : tb;
             }
-            lcp[a] = l;
+            A.lcp[a] = l;
+        }
+        // segment aggregate: slot of its last head (slots grow along the list), elements kept
+        uint32_t last = 0;
+        if (hmask[k]) last = (uint32_t)__builtin_amdgcn_readlane((int)slot[k], 63 - __builtin_clzll(hmask[k]));
+        if (lane == 0) {
+            s_seg_max[k * kWaves + w] = last;
+            s_seg_sum[k * kWaves + w] = (uint32_t)__popcll(kmask[k]);
         }
     }
-}
-
-// surviving elements keep their slot and learn the slot of their (new) group head
-__global__ __launch_bounds__(kThreads) void compact_kernel(const uint32_t *__restrict__ keep,
-                                                           const uint32_t *__restrict__ idx,
-                                                           const uint32_t *__restrict__ act_slot,
-                                                           const uint32_t *__restrict__ head_of, uint32_t m,
-                                                           uint32_t *__restrict__ new_slot,
-                                                           uint32_t *__restrict__ new_grp) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x; a < m; a += stride)
-        if (keep[a]) {
-            const uint32_t k = idx[a];
-            new_slot[k] = act_slot ? act_slot[a] : (uint32_t)a;
-            new_grp[k] = head_of[a];
+    __syncthreads();
+    if (w == 0) {  // prefixes over the segments, then over the tiles in front
+        static_assert(kSegs <= 64, "one lane per segment");
+        const uint32_t vmax = lane < kSegs ? s_seg_max[lane] : 0u;
+        const uint32_t vsum = lane < kSegs ? s_seg_sum[lane] : 0u;
+        const uint32_t imax = wave_scan_inclusive_dpp(vmax, 0u, OpMax<uint32_t>());
+        const uint32_t isum = wave_scan_inclusive_dpp(vsum, 0u, OpAdd<uint32_t>());
+        const uint32_t agg_max = (uint32_t)__builtin_amdgcn_readlane((int)imax, 63);
+        const uint32_t agg_sum = (uint32_t)__builtin_amdgcn_readlane((int)isum, 63);
+        const uint32_t emax = lane_prev(imax, 0u);
+        if (lane < kSegs) {
+            s_seg_max[lane] = emax;
+            s_seg_sum[lane] = isum - vsum;
         }
+        const uint32_t xm = lookback_exclusive(A.desc_max, tile, agg_max, OpMax<uint32_t>(), A.ticket + 1);
+        const uint32_t xs = lookback_exclusive(A.desc_sum, tile, agg_sum, OpAdd<uint32_t>(), A.ticket + 1);
+        if (lane == 0) {
+            s_excl[0] = xm;
+            s_excl[1] = xs;
+            if (tile_base + kFuseTile >= m) *A.d_total = xs + agg_sum;  // the last tile
+        }
+    }
+    __syncthreads();
+    const uint32_t xmax = s_excl[0], xsum = s_excl[1];
+
+#pragma unroll
+    for (int k = 0; k < kFuseItems; ++k) {
+        const size_t a = tile_base + (size_t)k * kThreads + threadIdx.x;
+        const bool in = a < m;
+        // slot of my group head: the last head at or in front of me
+        const uint64_t mine = hmask[k] & ((2ull << lane) - 1ull);
+        const int hl = mine ? 63 - __builtin_clzll(mine) : lane;
+        uint32_t head_of = kRound0 ? (uint32_t)(a - (size_t)(lane - hl)) : (uint32_t)__shfl((int)slot[k], hl, 64);
+        if (!mine) {
+            const uint32_t pm = s_seg_max[k * kWaves + w];
+            head_of = pm > xmax ? pm : xmax;
+        }
+        if (!in) continue;
+        if (!kRound0) A.sa[slot[k]] = A.vals[a];  // round 0: the key sort left the suffixes in sa itself
+        if (A.rank_by_slot)
+            A.rank_by_slot[slot[k]] = head_of + 1u;  // rank[] itself is written later, in one pass
+        else
+            A.rank_val[a] = head_of + 1u;  // goes to rank[i] through bucketed_scatter
+        if ((kmask[k] >> lane) & 1ull) {  // surviving elements keep their slot, learn their group head
+            const uint32_t kk = xsum + s_seg_sum[k * kWaves + w] + (uint32_t)__popcll(kmask[k] & lt);
+            A.new_slot[kk] = slot[k];
+            A.new_grp[kk] = head_of;
+        }
+    }
 }
 
 // secondary key of a doubling round: rank of the suffix h symbols further on (0 past the end)
@@ -631,10 +765,10 @@ void launch_initial_keys(Context &ctx, const PackedText &t, uint64_t *keys, uint
 template <bool kRound0>
 uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *grp, const uint32_t *lo, uint32_t *vals,
                  const uint32_t *act_slot, uint32_t m, uint32_t n, uint32_t *sa, uint32_t *rank, uint32_t *new_slot,
-                 uint32_t *new_grp, uint32_t *tmp_a, uint32_t *tmp_b, uint32_t *tmp_c, uint32_t *scratch_idx,
-                 uint32_t *scratch_val, uint32_t *rank_val, uint32_t *d_total, uint32_t *lcp = nullptr,
-                 int sym_bits = 0, int tag_bits = 0, int bits = 0, const uint32_t *lcp_list = nullptr,
-                 int low_bits = 0, uint32_t dbl_h = 0, uint32_t *rank_by_slot = nullptr) {
+                 uint32_t *new_grp, uint32_t *scratch_idx, uint32_t *scratch_val, uint32_t *rank_val,
+                 uint32_t *d_total, uint32_t *lcp = nullptr, int sym_bits = 0, int tag_bits = 0, int bits = 0,
+                 const uint32_t *lcp_list = nullptr, int low_bits = 0, uint32_t dbl_h = 0,
+                 uint32_t *rank_by_slot = nullptr) {
     hipStream_t s = ctx.stream;
     const size_t pmark = ctx.arena.mark();
     Pyramid Plcp{};
@@ -642,22 +776,26 @@ uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *grp, const 
         ProfScope ps(ctx.profiler(), "sa_lcp_pyramid", s);
         Plcp = build_pyramid(lcp, n + 1, false, ctx.arena, s);
     }
+    const size_t tiles = div_up(m, kFuseTile);
+    uint32_t total[2] = {0, 0};
     {
-        ProfScope ps(ctx.profiler(), "sa_mark_heads", s);
-        mark_heads_kernel<kRound0><<<grid_for(m, kThreads), kThreads, 0, s>>>(keys, grp, lo, act_slot, m, tmp_a);
+        const double bytes = kRound0 ? 20.0 * m : 28.0 * m;  // view (+ vals) in, (sa +) rank + lcp out (+ survivors)
+        ProfScope ps(ctx.profiler(), "sa_regroup", s, bytes);
+        // descriptors of both scans, then [ticket, error flag]
+        uint64_t *desc = ctx.arena.alloc<uint64_t>(2 * tiles + 1);
+        HIP_CHECK(hipMemsetAsync(desc, 0, (2 * tiles + 1) * sizeof(uint64_t), s));
+        RegroupArgs A{};
+        A.keys = keys; A.grp = grp; A.lo = lo; A.vals = vals; A.act_slot = act_slot; A.m = m;
+        A.sa = sa; A.rank_val = rank_val; A.rank_by_slot = rank_by_slot; A.lcp = lcp;
+        A.sym_bits = sym_bits; A.tag_bits = tag_bits; A.bits = bits; A.low_bits = low_bits;
+        A.lcp_list = lcp_list; A.dbl_h = dbl_h; A.Plcp = Plcp;
+        A.new_slot = new_slot; A.new_grp = new_grp;
+        A.desc_max = desc; A.desc_sum = desc + tiles;
+        A.ticket = reinterpret_cast<uint32_t *>(desc + 2 * tiles);
+        A.d_total = d_total;
+        regroup_kernel<kRound0><<<(unsigned)tiles, kThreads, 0, s>>>(A);
         KERNEL_CHECK();
-    }
-    {
-        ProfScope ps(ctx.profiler(), "sa_scan", s);
-        scan_inclusive_max_u32(tmp_a, tmp_a, m, ctx.arena, s);
-    }
-    {
-        ProfScope ps(ctx.profiler(), "sa_commit", s);
-        commit_kernel<kRound0><<<grid_for(m, kThreads), kThreads, 0, s>>>(keys, grp, lo, vals, act_slot, tmp_a, m,
-                                                                          sa, rank_val, tmp_b, lcp, sym_bits,
-                                                                          tag_bits, bits, lcp_list, low_bits, dbl_h,
-                                                                          Plcp, rank_by_slot);
-        KERNEL_CHECK();
+        HIP_CHECK(hipMemcpyAsync(d_total + 1, A.ticket + 1, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
     }
     ctx.arena.rewind(pmark);
     if (!rank_by_slot) {
@@ -667,19 +805,9 @@ uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *grp, const 
         uint32_t *val[2] = {rank_val, scratch_val};
         bucketed_scatter(idx, val, m, rank, n, ctx.arena, s, ctx.profiler(), false);
     }
-    {
-        ProfScope ps(ctx.profiler(), "sa_scan", s);
-        scan_exclusive_add_u32(tmp_b, tmp_c, m, d_total, ctx.arena, s);
-    }
-    {
-        ProfScope ps(ctx.profiler(), "sa_compact", s);
-        compact_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(tmp_b, tmp_c, kRound0 ? nullptr : act_slot, tmp_a,
-                                                                  m, new_slot, new_grp);
-        KERNEL_CHECK();
-    }
-    uint32_t total = 0;
-    ctx.read_back(d_total, &total, 1);
-    return total;
+    ctx.read_back(d_total, total, 2);
+    if (total[1]) throw HipError("suffix array: look-back scan timed out");
+    return total[0];
 }
 
 }  // namespace
@@ -788,7 +916,19 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     const size_t mark = arena.mark();
 
     uint64_t *keys[2] = {arena.alloc<uint64_t>(n), arena.alloc<uint64_t>(n)};
-    uint32_t *vals[2] = {arena.alloc<uint32_t>(n), arena.alloc<uint32_t>(n)};
+    // The value buffers of the key sort: the one the last pass lands in IS sa (no copy afterwards).
+    int key_passes = 0;
+    {
+        int kb = text.segmented ? kSegSyms * 2 + kSegTagBits + kSegTermBits
+                 : text.bits == 2 ? KeyLayout<2>::kSyms * 2 + KeyLayout<2>::kTagBits
+                 : text.bits == 4 ? KeyLayout<4>::kSyms * 4 + KeyLayout<4>::kTagBits
+                                  : KeyLayout<8>::kSyms * 8 + KeyLayout<8>::kTagBits;
+        key_passes = (kb + kRadixBits - 1) / kRadixBits;
+        if (key_passes > 8) key_passes = 8;
+    }
+    uint32_t *vals_other = arena.alloc<uint32_t>(n);
+    uint32_t *vals[2] = {vals_other, vals_other};
+    vals[key_passes & 1] = sa;
     uint32_t *act_slot[2] = {arena.alloc<uint32_t>(n), arena.alloc<uint32_t>(n)};
     uint32_t *act_grp[2] = {arena.alloc<uint32_t>(n), arena.alloc<uint32_t>(n)};
     uint32_t *tmp_a = arena.alloc<uint32_t>(n);
@@ -822,6 +962,7 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         for (int b = 0; b < key_bits && np0 < 8; b += kRadixBits) shifts0[np0++] = b;
         ProfScope ps(ctx.profiler(), "sa_sort_initial", s);
         cur = radix_sort_pairs(keys, vals, n, shifts0, np0, arena, s, ctx.profiler());
+        if (np0 != key_passes || vals[cur] != sa) throw HipError("suffix array: key sort did not end in sa");
     }
     int tag_bits = 0, low_bits = 0;
     switch (text.bits) {
@@ -835,15 +976,15 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         low_bits = kSegTermBits;
     }
     uint32_t m = regroup<true>(ctx, keys[cur], nullptr, nullptr, vals[cur], nullptr, n, n, sa, rank, act_slot[0],
-                               act_grp[0], tmp_a, tmp_b, tmp_c, scratch_idx, scratch_val, rank_val, d_total, lcp,
+                               act_grp[0], scratch_idx, scratch_val, rank_val, d_total, lcp,
                                k_syms * text.bits, tag_bits, text.bits, nullptr, low_bits, 0, rank_by_slot);
 
     // ---- doubling rounds ------------------------------------------------------------------
     // in the rounds the 8n-byte key buffers are reused as four u32 arrays
     uint32_t *lo = reinterpret_cast<uint32_t *>(keys[0]);
     uint32_t *out_lo = lo + n;
-    uint32_t *rvals = vals[0];
-    uint32_t *out_vals = vals[1];
+    uint32_t *rvals = rank_by_slot;  // free once rank[] has been written (before the doubling rounds)
+    uint32_t *out_vals = vals_other;
     int nbits = 1;
     while (nbits < 32 && (1ull << nbits) <= (uint64_t)n) ++nbits;  // ranks and slots are <= n
     const int half_passes = (nbits + kRadixBits - 1) / kRadixBits;
@@ -896,7 +1037,7 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
             KERNEL_CHECK();
         }
         m = regroup<false>(ctx, nullptr, grp, out_lo, out_vals, slot, m, n, sa, rank, act_slot[a_cur ^ 1],
-                           act_grp[a_cur ^ 1], tmp_a, tmp_b, tmp_c, scratch_idx, scratch_val, rank_val, d_total, lcp,
+                           act_grp[a_cur ^ 1], scratch_idx, scratch_val, rank_val, d_total, lcp,
                            0, 0, 0, lcp_list, 0, (uint32_t)h, rank_by_slot);
         a_cur ^= 1;
         if (trace) fprintf(stderr, "[nolzss]   direct round (cap %u symbols): %u still tied\n", cap, m);
@@ -937,7 +1078,7 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
             arena.rewind(lmark);
         }
         m = regroup<false>(ctx, nullptr, grp, out_lo, out_vals, slot, m, n, sa, rank, act_slot[a_cur ^ 1],
-                           act_grp[a_cur ^ 1], tmp_a, tmp_b, tmp_c, scratch_idx, scratch_val, rank_val, d_total, lcp,
+                           act_grp[a_cur ^ 1], scratch_idx, scratch_val, rank_val, d_total, lcp,
                            0, 0, 0, nullptr, 0, (uint32_t)h);
         a_cur ^= 1;
         if (trace)

@@ -11,12 +11,12 @@ i=0
 for group in \
   "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY" \
   "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS" \
-  "TA_BUSY_avr TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum" \
-  "TCP_TOTAL_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum" \
+  "SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_WAIT_ANY SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_VALU" \
   "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_REQ_sum" \
-  "GRBM_GUI_ACTIVE FETCH_SIZE" "WRITE_SIZE"; do
+  "FETCH_SIZE" "WRITE_SIZE"; do
+  # (a pass with TA_* counters aborted rocprofv3 on this pool and hung the run: left out)
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $group --kernel-include-regex "$KREGEX" --output-format csv \
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $group --kernel-include-regex "$KREGEX" --output-format csv \
      -d "$ROOT/gpurun_out/$OUT/p$i" -o pmc -- python3 "$ROOT/tools/probe.py" "$@" > "$ROOT/gpurun_out/$OUT/p$i.log" 2>&1 || echo "pass $i failed"
   echo "pass $i done"
 done
