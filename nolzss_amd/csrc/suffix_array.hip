@@ -486,20 +486,6 @@ __global__ __launch_bounds__(kThreads) void small_sort_kernel(const uint32_t *__
 // smaller members is equal for them) and go on to the doubling rounds; groups larger than
 // kSmallGroup are flagged for the radix path (one ordinary doubling step).
 
-// gsize[first list index of a group] = number of members
-__global__ __launch_bounds__(kThreads) void group_size_kernel(const uint32_t *__restrict__ act_slot,
-                                                              const uint32_t *__restrict__ act_grp, uint32_t m,
-                                                              uint32_t *__restrict__ gsize) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x; a < m; a += stride) {
-        const uint32_t g = act_grp[a];
-        if (a + 1 == m || act_grp[a + 1] != g) {  // last member
-            const size_t g0 = a - (act_slot[a] - g);
-            gsize[g0] = (uint32_t)(a - g0 + 1);
-        }
-    }
-}
-
 // One workgroup refines all groups that START inside its kRefineTile list positions; every member
 // is a thread, all state lives in LDS.
 //   * Per round each still-tied member fetches the next kRefineWords * 64 bits of its own suffix
@@ -524,10 +510,9 @@ constexpr int kPairCap = 3072;  // pairs per workgroup (256 members in groups of
 
 template <int BITS>
 __global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(4, 6))) void group_refine_kernel(
-    const uint32_t *__restrict__ act_slot, const uint32_t *__restrict__ act_grp, const uint32_t *__restrict__ gsize,
-    const uint32_t *__restrict__ sa, const uint64_t *__restrict__ words, TermTable terms, uint32_t m, uint32_t h0,
-    uint32_t cap, uint32_t *__restrict__ out_lo, uint32_t *__restrict__ out_vals,
-    uint32_t *__restrict__ lcp_list) {
+    const uint32_t *__restrict__ act_slot, const uint32_t *__restrict__ act_grp, const uint32_t *__restrict__ sa,
+    const uint64_t *__restrict__ words, TermTable terms, uint32_t m, uint32_t h0, uint32_t cap,
+    uint32_t *__restrict__ out_lo, uint32_t *__restrict__ out_vals, uint32_t *__restrict__ lcp_list) {
     constexpr int kW32 = 2 * kRefineWords;  // window in 32-bit words, text order
     constexpr int kChunks = kW32 / 4;
     constexpr uint32_t kPer32 = 32 / BITS;
@@ -550,26 +535,44 @@ __global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(
     const size_t a = a0 + t;
 
     // ---- who is here: members of groups that start in this tile -------------------------------
+    // The size of a group is found in LDS: its last member (the next list element belongs to another
+    // group) sits inside the span whenever the group has at most kSmallGroup members.
     uint32_t my_pos = 0, my_lim = 0, my_term = 0;
     int my_gl = 0, my_gs = 0, my_j = 0;  // first member (local), group size (0: not mine), my index
+    bool starts_here = false;
+    uint32_t j = 0;
+    bool last = false;
+    s_goff[t] = 0;  // doubles as the group size table until the pair offsets are written
     if (a < m) {
         const uint32_t g = act_grp[a];
         const uint32_t slot = act_slot[a];
-        const size_t g0 = a - (slot - g);
-        const uint32_t sz = gsize[g0];
-        if (a < a1 && sz > kSmallGroup) {  // too large for this round: stays one group, in place
+        last = a + 1 == m || act_grp[a + 1] != g;
+        my_pos = sa[slot];
+        j = slot - g;  // my index inside the group
+        const size_t g0 = a - j;
+        starts_here = g0 >= a0 && g0 < a1;
+        my_gl = starts_here ? (int)(g0 - a0) : 0;
+    }
+    __syncthreads();
+    if (starts_here && last) s_goff[my_gl] = j + 1;
+    __syncthreads();
+    if (a < m) {
+        const uint32_t sz = starts_here ? s_goff[my_gl] : 0u;  // 0: the group ends beyond the span
+        const bool large = starts_here ? (sz == 0 || sz > kSmallGroup) : false;
+        // too large for this round: stays one group, in place.  Its first kSmallGroup members are
+        // written by the tile it starts in, the others by the tile that owns their list position.
+        if ((large && j < kSmallGroup) || (a < a1 && j >= kSmallGroup)) {
             out_lo[a] = 0;
-            out_vals[a] = sa[slot];
+            out_vals[a] = my_pos;
         }
-        if (g0 >= a0 && g0 < a1 && sz <= kSmallGroup) {
+        if (starts_here && !large) {
             my_gs = (int)sz;
-            my_gl = (int)(g0 - a0);
-            my_j = t - my_gl;
-            my_pos = sa[slot];
+            my_j = (int)j;
             my_term = term_lower_bound(terms, my_pos);
             my_lim = terms.pos[my_term] - my_pos;
         }
     }
+    __syncthreads();  // everybody has read the sizes
     // member j of a group lists its pairs with members 0 .. j-1: the list position is an exclusive
     // scan of j over the tile
     uint32_t inc = wave_scan_inclusive_dpp((uint32_t)my_j, 0u, OpAdd<uint32_t>());
@@ -1014,23 +1017,20 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         // at most 32 words (1024 bases of DNA) deep; longer ties are cheaper in the doubling rounds
         static const uint32_t cap_words = getenv("NOLZSS_REFINE_WORDS") ? (uint32_t)atoi(getenv("NOLZSS_REFINE_WORDS")) : 32u;
         const uint32_t cap = (uint32_t)k_syms + cap_words * (64u / (uint32_t)text.bits);
-        uint32_t *gsize = arena.alloc<uint32_t>(m);
         {
             ProfScope ps(ctx.profiler(), "sa_direct_sort", s);
-            group_size_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(slot, grp, m, gsize);
-            KERNEL_CHECK();
             const unsigned g = (unsigned)div_up(m, kRefineTile);
             switch (text.bits) {
             case 2:
-                group_refine_kernel<2><<<g, kRefineThreads, 0, s>>>(slot, grp, gsize, sa, text.words, text.terms, m, (uint32_t)h, cap,
+                group_refine_kernel<2><<<g, kRefineThreads, 0, s>>>(slot, grp, sa, text.words, text.terms, m, (uint32_t)h, cap,
                                                               out_lo, out_vals, lcp_list);
                 break;
             case 4:
-                group_refine_kernel<4><<<g, kRefineThreads, 0, s>>>(slot, grp, gsize, sa, text.words, text.terms, m, (uint32_t)h, cap,
+                group_refine_kernel<4><<<g, kRefineThreads, 0, s>>>(slot, grp, sa, text.words, text.terms, m, (uint32_t)h, cap,
                                                               out_lo, out_vals, lcp_list);
                 break;
             default:
-                group_refine_kernel<8><<<g, kRefineThreads, 0, s>>>(slot, grp, gsize, sa, text.words, text.terms, m, (uint32_t)h, cap,
+                group_refine_kernel<8><<<g, kRefineThreads, 0, s>>>(slot, grp, sa, text.words, text.terms, m, (uint32_t)h, cap,
                                                               out_lo, out_vals, lcp_list);
                 break;
             }

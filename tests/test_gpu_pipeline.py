@@ -51,6 +51,28 @@ def _cases():
         "all256": bytes(range(256)) * 40,
         "fib": None,
     }
+    # families of 40 and of 64 near-identical copies: every group of the key sort has 33..64
+    # members, so the pair list of the direct comparison round overflows (groups left to the
+    # doubling rounds) and the ones that fit run many pairs per member
+    blk = gen.random_dna(6000, 11)
+    fam = []
+    for c in range(40):
+        b = blk.copy()
+        b[(c * 131) % 6000::997] = ord("ACGT"[c % 4])
+        fam.append(b.tobytes())
+    cases["family_of_40_with_edits"] = b"".join(fam)
+    cases["family_of_64_exact"] = gen.random_dna(3000, 12).tobytes() * 64
+    cases["family_of_65_exact"] = gen.random_dna(2000, 13).tobytes() * 65
+    # mixture: group sizes 2..20 side by side with singletons (balanced pair list, several rounds)
+    parts = []
+    r2 = random.Random(5)
+    base = [gen.random_dna(700, 20 + k).tobytes() for k in range(30)]
+    for k in range(400):
+        b = bytearray(base[r2.randrange(30)] if r2.random() < 0.7 else gen.random_dna(700, 1000 + k).tobytes())
+        if r2.random() < 0.5:
+            b[r2.randrange(700)] = ord("ACGT"[r2.randrange(4)])
+        parts.append(bytes(b))
+    cases["mixed_families_280k"] = b"".join(parts)
     a, b = b"a", b"ab"
     while len(b) < 40_000:
         a, b = b, b + a
