@@ -131,6 +131,34 @@ def _fib(n):
     return b[:n]
 
 
+@pytest.mark.timeout(1200)
+def test_beyond_2Gi_positions(native):
+    """Maximum sizes: 2^31 + 2^21 bases, so starts, references and ranks exceed 2^31 (32-bit index
+    arithmetic must be unsigned everywhere).  The last 2^20 bases copy a block that straddles
+    position 2^31: the parse must end with that factor.  Plus tiling, sampled true-match
+    checks and the exact prefix of the parse."""
+    n = (1 << 31) + (1 << 21)
+    text = gen.random_dna(n, seed=77)
+    src = (1 << 31) - (1 << 19)
+    text[n - (1 << 20):] = text[src:src + (1 << 20)]
+    f = native.factorize_array(text)
+    _check_tiling(f, n)
+    # (the factor in front may run a few bases into the copy by chance)
+    k = int(f["start"][-1]) - (n - (1 << 20))
+    assert 0 <= k < 64
+    assert (int(f["length"][-1]), int(f["ref"][-1])) == ((1 << 20) - k, src + k)
+    _check_matches(text, f, 20_000, np.random.default_rng(3))
+    tail = np.flatnonzero(f["start"] > np.uint64(1 << 31))
+    _check_matches(text, f[tail[0]:], 20_000, np.random.default_rng(4))
+    P = 1 << 23
+    exp = oracle.factors_array(text[:P])
+    cut = int(np.searchsorted(f["start"] + f["length"], P, side="right"))
+    assert cut > 100_000 and cut <= len(exp)
+    for k in ("start", "length", "ref"):
+        assert np.array_equal(f[k][:cut], exp[k][:cut]), k
+    assert native.count_factors(text) == len(f)
+
+
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("name", ["allA_8M", "period3_4M", "fib_4M", "abracadabra_x400k", "two_long_copies_8M",
                                   "long_copy_with_edits_6M"])
