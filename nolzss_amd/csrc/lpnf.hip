@@ -64,15 +64,20 @@ __global__ __launch_bounds__(kLdsThreads) void lpf_tile_kernel(const uint32_t *_
     stage_tile(sa, lcp, n, base, s_sa, s_lcp);
     __syncthreads();
     const int w = threadIdx.x >> 6;
+    const uint32_t far_bit = n <= 0x80000000u ? 0x80000000u : 0u;
     lds_search_wave<NS, NS>(s_sa, s_lcp, n, base, s_len, s_pos, s_list[w][0], s_list[w][1],
-                        [](uint32_t) { return true; }, [](uint32_t) { return 0u; });
+                            [](uint32_t) { return true; }, [](uint32_t) { return 0u; }, far_bit);
     // ranks with a search beyond the reach go to the far queue: one atomic per wavefront
     uint64_t far_mask[kLdsPerWave / 64];
     uint32_t far_total = 0;
 #pragma unroll
     for (int row = 0; row < kLdsPerWave / 64; ++row) {
         const int t = w * kLdsPerWave + row * 64 + lane_id();
-        const bool far = (uint64_t)base + t < n && (s_len[t] == kFarLen || s_len[kLdsTile + t] == kFarLen);
+        // a search that left the reach matters only if its bound can beat the other direction
+        uint32_t up = s_len[t], down = s_len[kLdsTile + t];
+        const bool far = far_resolve(up, down, far_bit, 0u) && (uint64_t)base + t < n;
+        s_len[t] = up;
+        s_len[kLdsTile + t] = down;
         far_mask[row] = __ballot(far);
         far_total += (uint32_t)__popcll(far_mask[row]);
     }

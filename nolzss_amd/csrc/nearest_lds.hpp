@@ -27,6 +27,34 @@ constexpr int kLdsSpan = kLdsTile + 2 * kLdsReach;
 constexpr int kLdsStep = 8;                         // steps per round
 constexpr int kLdsStep0 = 4;                        // steps of the first round (4/5 of the searches end there)
 constexpr uint32_t kFarLen = 0xffffffffu;           // res_len marker: search left the reach
+// A search that leaves the reach still knows the running LCP minimum m it got to, and whatever it
+// would find further out cannot be longer than m.  With far_bit = 0x80000000 (texts of at most 2^31
+// symbols, where every length fits 31 bits) the marker is far_bit | m, and the caller sends a rank
+// to the far queue only if that bound can still beat what the other direction found -- after 250
+// ranks the bound is tiny, so 9 of 10 "far" searches need no second look.  far_bit = 0: plain marker.
+__device__ __forceinline__ uint32_t far_mark(uint32_t m, uint32_t far_bit) {
+    return far_bit ? (far_bit | (m & ~far_bit)) : kFarLen;
+}
+__device__ __forceinline__ bool far_is(uint32_t v, uint32_t far_bit) {
+    return far_bit ? (v & far_bit) != 0 : v == kFarLen;
+}
+__device__ __forceinline__ uint32_t far_bound(uint32_t v, uint32_t far_bit) {
+    return far_bit ? (v & ~far_bit) : 0xffffffffu;
+}
+// Combine the two directions of one kind of search: true if the rank must go to the far queue;
+// otherwise a far side (which cannot win) is replaced by "nothing found".
+__device__ __forceinline__ bool far_resolve(uint32_t &up, uint32_t &down, uint32_t far_bit, uint32_t floor_len) {
+    const bool fu = far_is(up, far_bit), fd = far_is(down, far_bit);
+    if (!fu && !fd) return false;
+    const uint32_t bu = fu ? far_bound(up, far_bit) : 0u, bd = fd ? far_bound(down, far_bit) : 0u;
+    uint32_t known = floor_len;  // lengths up to floor_len can never matter to the caller
+    if (!fu) known = up > known ? up : known;
+    if (!fd) known = down > known ? down : known;
+    if ((fu && bu > known) || (fd && bd > known)) return true;
+    if (fu) up = 0;
+    if (fd) down = 0;
+    return false;
+}
 constexpr uint32_t kLdsSparse = 24;                 // work-list length below which the wave gangs up
 
 struct OpMinU32 {
@@ -87,13 +115,14 @@ __device__ __forceinline__ int lds_scan_round(const uint32_t *s_sa, const uint32
 // Runs NS searches for each of the wavefront's kLdsPerWave ranks.  Search k is "up" for even k,
 // "down" for odd k; searches 0/1 look for smaller values (threshold = own suffix start i),
 // searches 2/3 (NS == 4) for values greater than thr_gt(i).  A rank takes part iff active(i).
-// Results: res_len[k * kLdsTile + t] (0: none, kFarLen: left the reach) and, for the first NP
+// Results: res_len[k * kLdsTile + t] (0: none, far_mark(): left the reach) and, for the first NP
 // searches only, res_pos[k * kLdsTile + t] (suffix start of the match).
 // list0/list1: this wave's two work lists (NS * kLdsPerWave items each).
 template <int NS, int NP, typename Active, typename ThrGt>
 __device__ __forceinline__ void lds_search_wave(const uint32_t *s_sa, const uint32_t *s_lcp, uint32_t n,
                                                 uint32_t base, uint32_t *res_len, uint32_t *res_pos,
-                                                uint16_t *list0, uint16_t *list1, Active active, ThrGt thr_gt) {
+                                                uint16_t *list0, uint16_t *list1, Active active, ThrGt thr_gt,
+                                                uint32_t far_bit) {
     const int lane = lane_id();
     const int w = threadIdx.x >> 6;
     const uint64_t lt = lanemask_lt();
@@ -147,7 +176,7 @@ __device__ __forceinline__ void lds_search_wave(const uint32_t *s_sa, const uint
                                                         greater ? thr_gt(i) : i, m, pos);
                 const bool at_reach = done + 2 * kLdsStep > kLdsReach;  // the next round would leave the halo
                 pending = st == 2 && !at_reach;
-                res_len[k * kLdsTile + t] = (st == 0) ? 0u : ((st == 2 && at_reach) ? kFarLen : m);
+                res_len[k * kLdsTile + t] = (st == 0) ? 0u : ((st == 2 && at_reach) ? far_mark(m, far_bit) : m);
                 if (k < NP) res_pos[k * kLdsTile + t] = (st == 1) ? pos : kNoPos;
             }
             const uint64_t bal = __ballot(pending);
@@ -176,6 +205,7 @@ __device__ __forceinline__ void lds_search_wave(const uint32_t *s_sa, const uint
         const uint32_t x = greater ? thr_gt(i) : i;
         uint32_t m = res_len[k * kLdsTile + t];
         uint32_t out_len = kFarLen, out_pos = kNoPos;
+        bool stopped = false;
         while (s0 < kLdsReach) {
             const int step = s0 + lane + 1;
             const bool inside = step <= kLdsReach;
@@ -197,12 +227,16 @@ __device__ __forceinline__ void lds_search_wave(const uint32_t *s_sa, const uint
                     out_pos = f_pos;
                 } else if ((deadmask >> first) & 1) {
                     out_len = 0;
-                }  // else: first stop is the end of the reach -> kFarLen
+                } else {  // first stop is the end of the reach
+                    out_len = far_mark(f_len, far_bit);
+                }
+                stopped = true;
                 break;
             }
             m = (uint32_t)__builtin_amdgcn_readlane((int)mk, 63);
             s0 += 64;
         }
+        if (!stopped) out_len = far_mark(m, far_bit);
         if (lane == 0) {
             res_len[k * kLdsTile + t] = out_len;
             if (k < NP) res_pos[k * kLdsTile + t] = out_pos;

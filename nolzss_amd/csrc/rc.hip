@@ -72,8 +72,9 @@ __global__ __launch_bounds__(kLdsThreads) void rc_tile_kernel(const uint32_t *__
     stage_tile(sa, lcp, m, base, s_sa, s_lcp);
     __syncthreads();
     const int w = threadIdx.x >> 6;
+    const uint32_t far_bit = m <= 0x80000000u ? 0x80000000u : 0u;
     lds_search_wave<NS, NP>(s_sa, s_lcp, m, base, s_len, s_pos, s_list[w][0], s_list[w][1],
-                            [N](uint32_t i) { return i < N; }, [N](uint32_t i) { return 2u * N - i; });
+                            [N](uint32_t i) { return i < N; }, [N](uint32_t i) { return 2u * N - i; }, far_bit);
 #pragma unroll 1
     for (int row = 0; row < kLdsPerWave / 64; ++row) {
         const int t = w * kLdsPerWave + row * 64 + lane_id();
@@ -84,9 +85,13 @@ __global__ __launch_bounds__(kLdsThreads) void rc_tile_kernel(const uint32_t *__
             code_by_rank[rr] = 0;
             continue;
         }
-        const uint32_t lp = s_len[t], ls = s_len[kLdsTile + t];
-        const uint32_t ru = s_len[2 * kLdsTile + t], rd = s_len[3 * kLdsTile + t];
-        if (lp == kFarLen || ls == kFarLen || ru == kFarLen || rd == kFarLen) {
+        uint32_t lp = s_len[t], ls = s_len[kLdsTile + t];
+        uint32_t ru = s_len[2 * kLdsTile + t], rd = s_len[3 * kLdsTile + t];
+        // a search that left the reach matters only if its bound can beat the other direction
+        // (reverse-complement lengths <= 1 can never be chosen)
+        const bool far_f = far_resolve(lp, ls, far_bit, 0u);
+        const bool far_r = far_resolve(ru, rd, far_bit, 1u);
+        if (far_f || far_r) {
             far_queue[atomicAdd(far_count, 1u)] = (uint32_t)rr;  // finish from global memory
             code_by_rank[rr] = 0;
             continue;

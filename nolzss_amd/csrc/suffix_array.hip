@@ -299,7 +299,7 @@ __global__ __launch_bounds__(kThreads) void regroup_kernel(RegroupArgs A) {
     __shared__ uint32_t s_tile;
     __shared__ uint32_t s_seg_max[kSegs], s_seg_sum[kSegs];  // per segment: last head slot, kept; then prefixes
     __shared__ uint32_t s_excl[2];
-    if (threadIdx.x == 0) s_tile = atomicAdd(A.ticket, 1u);
+    if (threadIdx.x == 0) s_tile = atomicAdd(A.ticket, 1u);  // (blockIdx order measured 5 % faster, not guaranteed)
     __syncthreads();
     const uint32_t tile = s_tile;
     const uint32_t m = A.m;
@@ -775,7 +775,7 @@ uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *grp, const 
     hipStream_t s = ctx.stream;
     const size_t pmark = ctx.arena.mark();
     Pyramid Plcp{};
-    if (!kRound0) {  // doubling boundaries read range minima of the LCP values decided so far
+    if (!kRound0 && !lcp_list) {  // doubling boundaries read range minima of the LCP values decided so far
         ProfScope ps(ctx.profiler(), "sa_lcp_pyramid", s);
         Plcp = build_pyramid(lcp, n + 1, false, ctx.arena, s);
     }
