@@ -16,6 +16,8 @@
 //      and lpnf_fallback_kernel finds max d by galloping + binary search on the monotone
 //      predicate, using the LCP pyramid for I(d) and the SA pyramid for the range minimum.
 #include "pipeline.hpp"
+
+#include <cstdlib>
 #include "nearest_lds.hpp"
 #include "radix_sort.hpp"
 
@@ -163,6 +165,8 @@ uint32_t build_lstar(Context &ctx, uint32_t n, const uint32_t *sa, const uint32_
     }
     uint32_t h[2] = {0, 0};
     ctx.read_back(counts, h, 2);
+    static const bool trace = getenv("NOLZSS_TRACE") != nullptr;
+    if (trace) fprintf(stderr, "[nolzss] lpf: %u ranks to the far queue, %u positions to the exact search so far\n", h[1], h[0]);
     if (h[1] > 0) {
         ProfScope ps(ctx.profiler(), "lpf_far", s);
         size_t g = div_up(h[1], kThreads);

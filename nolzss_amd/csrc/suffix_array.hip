@@ -583,28 +583,36 @@ __global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(
     s_cls[t] = 0;
     s_best[t] = 0;
     __syncthreads();
-    uint32_t my_off = inc - (uint32_t)my_j;
+    uint32_t my_off = inc - (uint32_t)my_j, all_pairs = 0;
 #pragma unroll
-    for (int k = 0; k < kRefineWaves; ++k)
+    for (int k = 0; k < kRefineWaves; ++k) {
         if (k < w) my_off += s_wtot[k];
-    if (my_gs && my_j == 0) s_goff[t] = my_off;
-    __syncthreads();
-    bool handled = false;
-    if (my_gs) {
-        const uint32_t gend = s_goff[my_gl] + (uint32_t)(my_gs * (my_gs - 1) / 2);
-        handled = gend <= (uint32_t)kPairCap;  // the handled groups are a prefix of the tile's groups
-        if (handled) {
-            for (int y = 0; y < my_j; ++y) s_pair[my_off + y] = (uint32_t)t | ((uint32_t)(my_gl + y) << 16);
-            if (my_j == my_gs - 1) atomicMax(&s_npairs, gend);
-        } else {  // no room for its pairs: the group stays as it is
-            out_lo[a] = 0;
-            out_vals[a] = my_pos;
-        }
+        all_pairs += s_wtot[k];
     }
+    bool handled = my_gs != 0;
+    uint32_t npairs = all_pairs;
+    if (all_pairs > (uint32_t)kPairCap) {  // (rare, workgroup-uniform) not every group fits the list:
+        // the handled groups are a prefix of the tile's groups
+        if (my_gs && my_j == 0) s_goff[t] = my_off;
+        __syncthreads();
+        uint32_t gend = 0;
+        if (my_gs) {
+            gend = s_goff[my_gl] + (uint32_t)(my_gs * (my_gs - 1) / 2);
+            handled = gend <= (uint32_t)kPairCap;
+            if (handled && my_j == my_gs - 1) atomicMax(&s_npairs, gend);
+            if (!handled) {  // no room for its pairs: the group stays as it is
+                out_lo[a] = 0;
+                out_vals[a] = my_pos;
+            }
+        }
+        __syncthreads();
+        npairs = s_npairs;
+    }
+    if (handled)
+        for (int y = 0; y < my_j; ++y) s_pair[my_off + y] = (uint32_t)t | ((uint32_t)(my_gl + y) << 16);
     s_tied[0][t] = handled ? 1 : 0;
     __syncthreads();
     // each wavefront owns a stretch of the pair list
-    const uint32_t npairs = s_npairs;
     const uint32_t seg = ((npairs + kRefineWaves - 1) / kRefineWaves + 63u) & ~63u;
     const uint32_t seg0 = (uint32_t)w * seg;
     uint32_t cnt = seg0 < npairs ? (npairs - seg0 < seg ? npairs - seg0 : seg) : 0u;
@@ -650,23 +658,28 @@ __global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(
                     const uint32_t rem_x = s_lim[x] - h, rem_u = s_lim[u] - h;  // symbols before the terminators
                     uint32_t valid = rem_x < rem_u ? rem_x : rem_u;
                     valid = valid < kPerRound ? valid : kPerRound;
-                    uint32_t d = kPerRound;
-                    bool u_smaller = false, found = false;
+                    // both windows in one go: the compare is bound by LDS round trips, not LDS bytes
+                    uint4 p[kChunks], y[kChunks];
 #pragma unroll
                     for (int c = 0; c < kChunks; ++c) {
-                        if (!found) {
-                            const uint4 p = s_w[c][x], y = s_w[c][u];
-                            if (((p.x ^ y.x) | (p.y ^ y.y) | (p.z ^ y.z) | (p.w ^ y.w)) != 0) {
-                                found = true;
-                                uint32_t xd = p.w, yd = y.w, i = 3;
-                                if (p.z != y.z) { xd = p.z; yd = y.z; i = 2; }
-                                if (p.y != y.y) { xd = p.y; yd = y.y; i = 1; }
-                                if (p.x != y.x) { xd = p.x; yd = y.x; i = 0; }
-                                d = ((uint32_t)(4 * c) + i) * kPer32 + (uint32_t)__clz((int)(xd ^ yd)) / BITS;
-                                u_smaller = yd < xd;
-                            }
+                        p[c] = s_w[c][x];
+                        y[c] = s_w[c][u];
+                    }
+                    uint32_t xd = 0, yd = 0, wi = (uint32_t)kW32;  // the first differing word and its index
+#pragma unroll
+                    for (int c = kChunks - 1; c >= 0; --c) {
+                        const uint32_t px[4] = {p[c].x, p[c].y, p[c].z, p[c].w};
+                        const uint32_t yx[4] = {y[c].x, y[c].y, y[c].z, y[c].w};
+#pragma unroll
+                        for (int i = 3; i >= 0; --i) {
+                            const bool diff = px[i] != yx[i];
+                            xd = diff ? px[i] : xd;
+                            yd = diff ? yx[i] : yd;
+                            wi = diff ? (uint32_t)(4 * c + i) : wi;
                         }
                     }
+                    uint32_t d = wi == (uint32_t)kW32 ? kPerRound : wi * kPer32 + (uint32_t)__clz((int)(xd ^ yd)) / BITS;
+                    bool u_smaller = yd < xd;
                     if (d >= valid) {
                         if (valid == kPerRound) {  // equal windows, both suffixes go on
                             tie = true;
