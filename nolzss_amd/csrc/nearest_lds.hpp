@@ -191,55 +191,83 @@ __device__ __forceinline__ void lds_search_wave(const uint32_t *s_sa, const uint
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
-    // ---- the long tail: few searches left, each possibly far from done.  The whole wavefront
-    // now works on ONE search at a time: lane l inspects step s0 + l + 1, a wave-wide prefix
-    // minimum gives every lane its running LCP, and a ballot finds the first lane that stops.
-    for (uint32_t e = 0; e < cnt; ++e) {
-        const uint32_t item = lists[cur][e];  // same address in every lane: broadcast
-        const int tl = item & 255, k = (item >> 8) & 3;
-        int s0 = (int)(item >> 10) * kLdsStep0;
-        const int t = w * kLdsPerWave + tl;
-        const int li = t + kLdsReach;
-        const bool greater = k >= 2, up = (k & 1) == 0;
-        const uint32_t i = s_sa[li];
-        const uint32_t x = greater ? thr_gt(i) : i;
-        uint32_t m = res_len[k * kLdsTile + t];
-        uint32_t out_len = kFarLen, out_pos = kNoPos;
-        bool stopped = false;
-        while (s0 < kLdsReach) {
-            const int step = s0 + lane + 1;
+    // ---- the long tail: few searches left, each possibly far from done (a search that has taken
+    // s steps needs about s more).  Rounds of 8 steps would finish almost nothing per round, and
+    // one search at a time leaves the wavefront waiting on a chain of dependent LDS reads and DPP
+    // steps, so the wavefront splits into its four 16-lane rows: every row works on its own
+    // search, lane l of the row inspects step s0 + l + 1, a row-wide prefix minimum (4 DPP steps)
+    // gives every lane its running LCP, the first lane that stops writes the result, and a row
+    // that is done takes the next search from the list.
+    {
+        const int row = lane >> 4, rl = lane & 15;
+        uint32_t next = 0;   // next list entry to hand out (wave-uniform)
+        bool busy = false;   // my row has a search (row-uniform)
+        int t = 0, k = 0, li = kLdsReach, s0 = 0;
+        bool greater = false, up = false;
+        uint32_t x = 0, m = 0;
+        for (;;) {
+            // idle rows take the next entries of the list, lowest row first
+            const uint64_t idle = __ballot(!busy);
+            const uint32_t idle_rows = (uint32_t)((idle & 1ull) | ((idle >> 15) & 2ull) | ((idle >> 30) & 4ull) |
+                                                  ((idle >> 45) & 8ull));
+            if (!busy) {
+                const uint32_t e = next + (uint32_t)__popc(idle_rows & ((1u << row) - 1u));
+                if (e < cnt) {
+                    const uint32_t item = lists[cur][e];
+                    k = (int)((item >> 8) & 3u);
+                    t = w * kLdsPerWave + (int)(item & 255u);
+                    s0 = (int)(item >> 10) * kLdsStep0;
+                    li = t + kLdsReach;
+                    greater = k >= 2;
+                    up = (k & 1) == 0;
+                    const uint32_t i = s_sa[li];
+                    x = greater ? thr_gt(i) : i;
+                    m = res_len[k * kLdsTile + t];
+                    busy = true;
+                }
+            }
+            next += (uint32_t)__popc(idle_rows);
+            if (!__ballot(busy)) break;
+            const int step = s0 + rl + 1;
             const bool inside = step <= kLdsReach;
             const int q = inside ? (up ? li - step : li + step) : li;
-            const uint32_t c = inside ? s_lcp[q + (up ? 1 : 0)] : 0xffffffffu;
+            const uint32_t c = (busy && inside) ? s_lcp[q + (up ? 1 : 0)] : 0xffffffffu;
             const uint32_t v = s_sa[q];
-            uint32_t mk = wave_scan_inclusive_dpp(c, 0xffffffffu, OpMinU32());
+            // prefix minimum over the lanes of my row
+            uint32_t mk = c;
+            mk = OpMinU32()(mk, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)mk, 0x111, 0xf, 0xf, false));  // row_shr:1
+            mk = OpMinU32()(mk, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)mk, 0x112, 0xf, 0xf, false));  // row_shr:2
+            mk = OpMinU32()(mk, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)mk, 0x114, 0xf, 0xf, false));  // row_shr:4
+            mk = OpMinU32()(mk, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)mk, 0x118, 0xf, 0xf, false));  // row_shr:8
             mk = mk < m ? mk : m;
             const bool dead = inside && mk == 0;  // LCP[0] = LCP[n] = 0 end every search in range
             const bool hit = inside && !dead && (greater ? (v > x) : (v < x));
-            const uint64_t stop = __ballot(dead || hit || !inside);
-            if (stop) {
-                const int first = __ffsll((long long)stop) - 1;  // wave-uniform
-                const uint32_t f_len = (uint32_t)__builtin_amdgcn_readlane((int)mk, first);
-                const uint32_t f_pos = (uint32_t)__builtin_amdgcn_readlane((int)v, first);
-                const uint64_t hitmask = __ballot(hit), deadmask = __ballot(dead);
-                if ((hitmask >> first) & 1) {
-                    out_len = f_len;
-                    out_pos = f_pos;
-                } else if ((deadmask >> first) & 1) {
-                    out_len = 0;
-                } else {  // first stop is the end of the reach
-                    out_len = far_mark(f_len, far_bit);
+            const uint64_t stop = __ballot(busy && (dead || hit || !inside));
+            const uint32_t mine = (uint32_t)(stop >> (row * 16)) & 0xffffu;
+            // running minimum at the end of each row, for the rows that go on
+            const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)mk, 15);
+            const uint32_t e1 = (uint32_t)__builtin_amdgcn_readlane((int)mk, 31);
+            const uint32_t e2 = (uint32_t)__builtin_amdgcn_readlane((int)mk, 47);
+            const uint32_t e3 = (uint32_t)__builtin_amdgcn_readlane((int)mk, 63);
+            if (mine) {
+                if (rl == __ffs((int)mine) - 1) {  // the first lane that stops decides
+                    uint32_t out_len, out_pos = kNoPos;
+                    if (hit) {
+                        out_len = mk;
+                        out_pos = v;
+                    } else if (dead) {
+                        out_len = 0;
+                    } else {  // the end of the reach
+                        out_len = far_mark(mk, far_bit);
+                    }
+                    res_len[k * kLdsTile + t] = out_len;
+                    if (k < NP) res_pos[k * kLdsTile + t] = out_pos;
                 }
-                stopped = true;
-                break;
+                busy = false;
+            } else if (busy) {
+                m = row == 0 ? e0 : (row == 1 ? e1 : (row == 2 ? e2 : e3));
+                s0 += 16;
             }
-            m = (uint32_t)__builtin_amdgcn_readlane((int)mk, 63);
-            s0 += 64;
-        }
-        if (!stopped) out_len = far_mark(m, far_bit);
-        if (lane == 0) {
-            res_len[k * kLdsTile + t] = out_len;
-            if (k < NP) res_pos[k * kLdsTile + t] = out_pos;
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
