@@ -34,6 +34,15 @@ constexpr int kWaveSpan = 64 * kKeysPerThread;  // 1024 keys per wavefront, 16 r
 
 static_assert(kBins == kThreads, "one thread per bin in the offset phase");
 
+// 8-bit digit of a key at a bit offset that is a multiple of 8: the digit never straddles the two
+// halves of a 64-bit key, so one v_bfe_u32 on the right half does it (a variable 64-bit shift costs
+// several instructions, three times per key)
+__device__ __forceinline__ uint32_t digit_of(uint64_t k, int shift) {
+    const uint32_t half = shift >= 32 ? (uint32_t)(k >> 32) : (uint32_t)k;
+    return (half >> (shift & 31)) & (uint32_t)(kBins - 1);
+}
+__device__ __forceinline__ uint32_t digit_of(uint32_t k, int shift) { return (k >> shift) & (uint32_t)(kBins - 1); }
+
 // block -> tile, XCD x owning a contiguous range of tiles (one extra tile for x < rem)
 __device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t num_tiles) {
     const uint32_t per = num_tiles / 8, rem = num_tiles % 8;
@@ -54,7 +63,7 @@ __global__ __launch_bounds__(kThreads) void rs_hist_kernel(const KeyT *__restric
 #pragma unroll
     for (int j = 0; j < kKeysPerThread; ++j) {
         size_t idx = base + (size_t)j * kThreads + threadIdx.x;
-        if (idx < n) atomicAdd(&hist[(uint32_t)(keys[idx] >> shift) & (kBins - 1)], 1u);
+        if (idx < n) atomicAdd(&hist[digit_of(keys[idx], shift)], 1u);
     }
     __syncthreads();
     tile_hist[(size_t)threadIdx.x * num_tiles + blockIdx.x] = hist[threadIdx.x];
@@ -95,7 +104,7 @@ __global__ __launch_bounds__(kThreads) void rs_scatter_kernel(
         const bool valid = idx < n;
         key[row] = valid ? keys_in[idx] : KeyT(0);
         val[row] = valid ? vals_in[idx] : 0;
-        const uint32_t d = (uint32_t)(key[row] >> shift) & (kBins - 1);
+        const uint32_t d = digit_of(key[row], shift);
         uint64_t peers = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < kRadixBits; ++b) {
@@ -136,7 +145,7 @@ __global__ __launch_bounds__(kThreads) void rs_scatter_kernel(
     // tile-local sorted position of every element (reuses lrank)
 #pragma unroll
     for (int row = 0; row < kKeysPerThread; ++row) {
-        const uint32_t d = (uint32_t)(key[row] >> shift) & (kBins - 1);
+        const uint32_t d = digit_of(key[row], shift);
         lrank[row] += s_whist[w * kBins + d];
     }
 #pragma unroll
@@ -153,7 +162,7 @@ __global__ __launch_bounds__(kThreads) void rs_scatter_kernel(
         const uint32_t p = (uint32_t)j * kThreads + tid;
         if (p < count) {
             const KeyT k = s_keys[p];
-            const uint32_t d = (uint32_t)(k >> shift) & (kBins - 1);
+            const uint32_t d = digit_of(k, shift);
             gpos[j] = s_glob[d] + p;
             keys_out[gpos[j]] = k;
         }
@@ -176,6 +185,9 @@ template <typename KeyT>
 int radix_sort_impl(KeyT *keys[2], uint32_t *vals[2], size_t n, const int *shifts, int npasses, Arena &arena,
                     hipStream_t stream, Profiler *prof) {
     if (n == 0 || npasses == 0) return 0;
+    if (sizeof(KeyT) == 8)
+        for (int p = 0; p < npasses; ++p)
+            if ((shifts[p] & 31) + kRadixBits > 32) throw HipError("radix sort: a digit may not straddle the key halves");
     const size_t m = arena.mark();
     const uint32_t num_tiles = (uint32_t)div_up(n, kTile);
     uint32_t *hist = arena.alloc<uint32_t>((size_t)kBins * num_tiles);

@@ -1,5 +1,7 @@
-"""Radix-sort micro-benchmark: python tools/sortbench.py [log2n] -- device sort of random
-(u64, u32) pairs through nolzss_debug_sort_pairs with the stage profiler on."""
+"""Radix-sort micro-benchmark: python tools/sortbench.py [log2n] [random|sorted|onebin] -- device
+sort of (u64, u32) pairs through nolzss_debug_sort_pairs with the stage profiler on.
+"sorted" input makes every pass a near-identity permutation (long runs per bin: the streaming
+ceiling of the scatter kernel), "onebin" puts all keys into one bin per pass."""
 import sys
 import time
 from pathlib import Path
@@ -13,7 +15,12 @@ from nolzss_amd import _noLZSS as native  # noqa: E402
 log2n = int(sys.argv[1]) if len(sys.argv) > 1 else 27
 n = 1 << log2n
 rng = np.random.default_rng(1)
+mode = sys.argv[2] if len(sys.argv) > 2 else "random"
 keys = rng.integers(0, 1 << 63, size=n, dtype=np.uint64)
+if mode == "sorted":
+    keys = np.arange(n, dtype=np.uint64) << np.uint64(64 - log2n - 1)
+elif mode == "onebin":
+    keys = np.zeros(n, dtype=np.uint64) + np.uint64(0x0101010101010101)
 vals = np.arange(n, dtype=np.uint32)
 native.debug_sort_pairs(keys[:1 << 20], vals[:1 << 20])
 native.profile_enable(True)
