@@ -105,13 +105,18 @@ __global__ __launch_bounds__(kThreads) void rs_scatter_kernel(
         key[row] = valid ? keys_in[idx] : KeyT(0);
         val[row] = valid ? vals_in[idx] : 0;
         const uint32_t d = digit_of(key[row], shift);
-        uint64_t peers = __ballot(valid);
+        // lanes with the same digit: the complement of the lanes that differ in some bit.  Per bit,
+        // m = 0 / ~0 (bit clear / set, one v_bfe_i32), and (ballot ^ m) is the set of lanes whose bit
+        // differs from mine -- six VALU instructions per bit instead of nine for the select form.
+        uint32_t diff_lo = 0, diff_hi = 0;
 #pragma unroll
         for (int b = 0; b < kRadixBits; ++b) {
-            const bool bit = (d >> b) & 1;
-            const uint64_t bal = __ballot(bit);
-            peers &= bit ? bal : ~bal;
+            const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)d, (unsigned)b, 1u);
+            const uint64_t bal = __ballot(m != 0);
+            diff_lo |= (uint32_t)bal ^ m;
+            diff_hi |= (uint32_t)(bal >> 32) ^ m;
         }
+        const uint64_t peers = ~(((uint64_t)diff_hi << 32) | diff_lo) & __ballot(valid);
         if (valid) {
             const uint64_t below = peers & lanemask_lt();
             const uint32_t old = whist[d];
