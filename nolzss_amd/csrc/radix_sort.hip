@@ -97,13 +97,21 @@ __global__ __launch_bounds__(kThreads) void rs_scatter_kernel(
     uint32_t val[kKeysPerThread];
     uint32_t lrank[kKeysPerThread];
 
-    // rank inside the wavefront: rows of 64 keys in input order (keeps the sort stable)
+    // all loads of the tile go out before anything is ranked (the ranking below goes through
+    // volatile LDS counters, which the compiler will not move loads across: interleaved, every row
+    // would wait for its own round trip to HBM)
 #pragma unroll
     for (int row = 0; row < kKeysPerThread; ++row) {
         const size_t idx = base + (size_t)w * kWaveSpan + (size_t)row * 64 + lane;
         const bool valid = idx < n;
         key[row] = valid ? keys_in[idx] : KeyT(0);
         val[row] = valid ? vals_in[idx] : 0;
+    }
+    // rank inside the wavefront: rows of 64 keys in input order (keeps the sort stable)
+#pragma unroll
+    for (int row = 0; row < kKeysPerThread; ++row) {
+        const size_t idx = base + (size_t)w * kWaveSpan + (size_t)row * 64 + lane;
+        const bool valid = idx < n;
         const uint32_t d = digit_of(key[row], shift);
         // lanes with the same digit: the complement of the lanes that differ in some bit.  Per bit,
         // m = 0 / ~0 (bit clear / set, one v_bfe_i32), and (ballot ^ m) is the set of lanes whose bit
