@@ -47,11 +47,17 @@ __global__ __launch_bounds__(kThreads) void chain_exit_kernel(const uint32_t *__
     const uint32_t base = blockIdx.x * (uint32_t)kTile;
     const uint32_t tile_end = (n - base < (uint32_t)kTile) ? n : base + kTile;
     const int tid = threadIdx.x;
+    uint32_t ls[kPerThread];  // all loads of the tile in flight together
+#pragma unroll
+    for (int j = 0; j < kPerThread; ++j) {
+        const uint32_t p = base + j * kThreads + tid;
+        ls[j] = (p < n) ? lstar[p] : 0u;
+    }
 #pragma unroll
     for (int j = 0; j < kPerThread; ++j) {
         const uint32_t lp = j * kThreads + tid;
         const uint32_t p = base + lp;
-        jump[lp] = (p < n) ? next_pos(p, lstar[p], n) : n;
+        jump[lp] = (p < n) ? next_pos(p, ls[j], n) : n;
     }
     __syncthreads();
     for (int round = 0; round < 13; ++round) {
@@ -171,13 +177,19 @@ __global__ __launch_bounds__(kThreads) void chain_mark_kernel(const uint32_t *__
         if (tid == 0) tile_count[blockIdx.x] = 0;
         return;
     }
+    uint32_t ls[kPerThread];  // all loads of the tile in flight together
+#pragma unroll
+    for (int j = 0; j < kPerThread; ++j) {
+        const uint32_t p = base + j * kThreads + tid;
+        ls[j] = (p < n) ? lstar[p] : 0u;
+    }
 #pragma unroll
     for (int j = 0; j < kPerThread; ++j) {
         const uint32_t lp = j * kThreads + tid;
         const uint32_t p = base + lp;
         uint32_t nl = kTile;
         if (p < n) {
-            const uint32_t nx = next_pos(p, lstar[p], n);
+            const uint32_t nx = next_pos(p, ls[j], n);
             if (nx < tile_end) nl = nx - base;
         }
         jmp[0][lp] = (uint16_t)nl;

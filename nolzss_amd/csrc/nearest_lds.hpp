@@ -65,12 +65,24 @@ struct OpMinU32 {
 __device__ __forceinline__ void stage_tile(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ lcp,
                                            uint32_t n, uint32_t base, uint32_t *s_sa, uint32_t *s_lcp) {
     const int64_t first = (int64_t)base - kLdsReach;
-    for (int j = threadIdx.x; j < kLdsSpan + 1; j += blockDim.x) {
+    // every load of the thread goes out before the first LDS store (one round trip to HBM per
+    // workgroup instead of one per row)
+    constexpr int kRows = (kLdsSpan + 1 + kLdsThreads - 1) / kLdsThreads;
+    uint32_t a[kRows], c[kRows];
+#pragma unroll
+    for (int k = 0; k < kRows; ++k) {
+        const int j = k * kLdsThreads + (int)threadIdx.x;
         const int64_t g = first + j;
-        const bool in_sa = g >= 0 && g < (int64_t)n;
-        const bool in_lcp = g >= 0 && g <= (int64_t)n;
-        if (j < kLdsSpan) s_sa[j] = in_sa ? sa[g] : 0u;
-        s_lcp[j] = in_lcp ? lcp[g] : 0u;
+        const bool in_sa = j < kLdsSpan && g >= 0 && g < (int64_t)n;
+        const bool in_lcp = j <= kLdsSpan && g >= 0 && g <= (int64_t)n;
+        a[k] = in_sa ? sa[g] : 0u;
+        c[k] = in_lcp ? lcp[g] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < kRows; ++k) {
+        const int j = k * kLdsThreads + (int)threadIdx.x;
+        if (j < kLdsSpan) s_sa[j] = a[k];
+        if (j <= kLdsSpan) s_lcp[j] = c[k];
     }
 }
 

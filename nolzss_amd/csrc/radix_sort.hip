@@ -60,10 +60,17 @@ __global__ __launch_bounds__(kThreads) void rs_hist_kernel(const KeyT *__restric
     hist[threadIdx.x] = 0;
     __syncthreads();
     const size_t base = (size_t)blockIdx.x * kTile;
+    // all loads first: the compiler does not move loads across the LDS atomics
+    KeyT k[kKeysPerThread];
 #pragma unroll
     for (int j = 0; j < kKeysPerThread; ++j) {
-        size_t idx = base + (size_t)j * kThreads + threadIdx.x;
-        if (idx < n) atomicAdd(&hist[digit_of(keys[idx], shift)], 1u);
+        const size_t idx = base + (size_t)j * kThreads + threadIdx.x;
+        k[j] = idx < n ? keys[idx] : KeyT(0);
+    }
+#pragma unroll
+    for (int j = 0; j < kKeysPerThread; ++j) {
+        const size_t idx = base + (size_t)j * kThreads + threadIdx.x;
+        if (idx < n) atomicAdd(&hist[digit_of(k[j], shift)], 1u);
     }
     __syncthreads();
     tile_hist[(size_t)threadIdx.x * num_tiles + blockIdx.x] = hist[threadIdx.x];
@@ -258,7 +265,22 @@ __global__ __launch_bounds__(kThreads) void window_scatter_kernel(const uint32_t
     const uint32_t W = 1u << window_bits;
     const size_t base = (size_t)blockIdx.x << window_bits;
     const uint32_t len = (uint32_t)((n_out - base < (size_t)W) ? (n_out - base) : (size_t)W);
-    for (uint32_t t = threadIdx.x; t < len; t += kThreads) s_out[idx[base + t] - (uint32_t)base] = val[base + t];
+    // eight (index, value) pairs per thread in flight at a time
+    constexpr int kBatch = 8;
+    for (uint32_t t0 = 0; t0 < len; t0 += kBatch * kThreads) {
+        uint32_t ii[kBatch], vv[kBatch];
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            const uint32_t t = t0 + (uint32_t)j * kThreads + threadIdx.x;
+            ii[j] = t < len ? idx[base + t] : 0u;
+            vv[j] = t < len ? val[base + t] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            const uint32_t t = t0 + (uint32_t)j * kThreads + threadIdx.x;
+            if (t < len) s_out[ii[j] - (uint32_t)base] = vv[j];
+        }
+    }
     __syncthreads();
     for (uint32_t t = threadIdx.x; t < len; t += kThreads) out[base + t] = s_out[t];
 }

@@ -312,24 +312,35 @@ __global__ __launch_bounds__(kThreads) void regroup_kernel(RegroupArgs A) {
         if (kRound0) return A.keys[a];
         return ((uint64_t)A.grp[a] << 32) | A.lo[a];
     };
-    // striped: item k of thread t is element tile_base + k * kThreads + t (coalesced rows)
+    // striped: item k of thread t is element tile_base + k * kThreads + t (coalesced rows).
+    // Every load of the tile goes out first (the LCP stores further down may alias the inputs as
+    // far as the compiler knows; interleaved, each of the 16 rows would wait for its own round
+    // trips to HBM): the view of my elements, their slots, and per row ONE neighbour -- the
+    // element in front of the wavefront for lane 0, the element behind it for lane 63.
     uint32_t slot[kFuseItems];
+    uint64_t view[kFuseItems], edge[kFuseItems];
+#pragma unroll
+    for (int k = 0; k < kFuseItems; ++k) {
+        const size_t a = tile_base + (size_t)k * kThreads + threadIdx.x;
+        const bool in = a < m;
+        view[k] = in ? load_view(a) : 0ull;
+        slot[k] = kRound0 ? (uint32_t)a : (in ? A.act_slot[a] : 0u);
+        edge[k] = 0;
+        if (lane == 0 && in && a > 0) edge[k] = load_view(a - 1);
+        if (lane == 63 && a + 1 < m) edge[k] = load_view(a + 1);
+    }
     uint64_t hmask[kFuseItems], kmask[kFuseItems];  // wave-uniform: heads / kept elements of my segment
 #pragma unroll
     for (int k = 0; k < kFuseItems; ++k) {
         const size_t a = tile_base + (size_t)k * kThreads + threadIdx.x;
         const bool in = a < m;
-        const uint64_t v = in ? load_view(a) : 0ull;
+        const uint64_t v = view[k];
         // the element in front: the previous lane's, except for lane 0
-        uint64_t edge = 0;
-        if (lane == 0 && in && a > 0) edge = load_view(a - 1);
-        const uint64_t pv = ((uint64_t)lane_prev((uint32_t)(v >> 32), (uint32_t)(edge >> 32)) << 32) |
-                            lane_prev((uint32_t)v, (uint32_t)edge);
-        slot[k] = kRound0 ? (uint32_t)a : (in ? A.act_slot[a] : 0u);
+        const uint64_t pv = ((uint64_t)lane_prev((uint32_t)(v >> 32), (uint32_t)(edge[k] >> 32)) << 32) |
+                            lane_prev((uint32_t)v, (uint32_t)edge[k]);
         const bool head = !in || a == 0 || v != pv;  // "past the end" counts as a head
         // is the element behind me a head?
-        uint32_t edge_next = 1;
-        if (lane == 63 && in && a + 1 < m) edge_next = load_view(a + 1) != v ? 1u : 0u;
+        const uint32_t edge_next = (lane == 63 && a + 1 < m) ? (edge[k] != v ? 1u : 0u) : 1u;
         const bool next_head = lane_next(head ? 1u : 0u, edge_next) != 0;
         const bool keep = in && !(head && next_head);
         hmask[k] = __ballot(in && head);
