@@ -263,6 +263,59 @@ __device__ __forceinline__ uint32_t lookback_exclusive(uint64_t *desc, uint32_t 
     return excl;
 }
 
+// Both running values in ONE descriptor, [status:2 | last head slot:31 | kept:31], for lists shorter
+// than 2^31: one walk over the tiles in front instead of two.  (The walk is what a regroup tile
+// waits for -- with ~1800 small tiles in flight, most of them published but not yet finished, it
+// goes back through dozens of 64-descriptor windows, each a device-scope round trip.)
+struct MaxSum {
+    uint32_t mx, sum;
+};
+__device__ __forceinline__ uint64_t pack_desc(uint32_t status, MaxSum v) {
+    return ((uint64_t)status << 62) | ((uint64_t)v.mx << 31) | (uint64_t)v.sum;
+}
+__device__ __forceinline__ MaxSum lookback_exclusive_packed(uint64_t *desc, uint32_t tile, MaxSum aggregate,
+                                                            uint32_t *err) {
+    const int lane = lane_id();
+    MaxSum excl{0u, 0u};
+    if (tile == 0) {
+        if (lane == 0) desc_store(desc, pack_desc(2u, aggregate));
+        return excl;
+    }
+    if (lane == 0) desc_store(desc + tile, pack_desc(1u, aggregate));
+    int64_t look = (int64_t)tile - 1;
+    for (;;) {
+        const int64_t idx = look - lane;
+        uint64_t d, need, inc;
+        uint32_t spins = 0;
+        for (;;) {
+            d = idx >= 0 ? desc_load(desc + idx) : (2ull << 62);  // in front of tile 0: inclusive identity
+            const uint32_t st = (uint32_t)(d >> 62);
+            inc = __ballot(st == 2);
+            need = inc ? (((inc & (~inc + 1ull)) << 1) - 1ull) : ~0ull;
+            const uint64_t missing = __ballot(st == 0) & need;
+            if (!missing) break;
+            if (++spins > kSpinLimit) {  // cannot happen with ticket order; never hang the GPU
+                if (lane == 0) atomicExch(err, 1u);
+                return excl;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        const bool use = (need >> lane) & 1ull;
+        const uint32_t vm = use ? (uint32_t)(d >> 31) & 0x7fffffffu : 0u;
+        const uint32_t vs = use ? (uint32_t)d & 0x7fffffffu : 0u;
+        const uint32_t wm = wave_reduce(vm, OpMax<uint32_t>());
+        excl.mx = wm > excl.mx ? wm : excl.mx;
+        excl.sum += wave_reduce(vs, OpAdd<uint32_t>());
+        if (inc) break;  // an inclusive prefix was reached
+        look -= 64;
+    }
+    if (lane == 0) {
+        MaxSum incl{excl.mx > aggregate.mx ? excl.mx : aggregate.mx, excl.sum + aggregate.sum};
+        desc_store(desc + tile, pack_desc(2u, incl));
+    }
+    return excl;
+}
+
 struct RegroupArgs {
     const uint64_t *keys;     // round 0: sorted keys
     const uint32_t *grp;      // later rounds: (group head slot, secondary key) per list element
@@ -280,6 +333,7 @@ struct RegroupArgs {
     Pyramid Plcp;
     uint32_t *new_slot, *new_grp;  // compacted active list of the next round
     uint64_t *desc_max, *desc_sum;
+    int packed;               // both scans share the descriptors in desc_max (n < 2^31)
     uint32_t *ticket;         // [0] tile tickets, [1] error flag
     uint32_t *d_total;        // number of elements that stay active
 };
@@ -400,8 +454,15 @@ __global__ __launch_bounds__(kThreads) void regroup_kernel(RegroupArgs A) {
             s_seg_max[lane] = emax;
             s_seg_sum[lane] = isum - vsum;
         }
-        const uint32_t xm = lookback_exclusive(A.desc_max, tile, agg_max, OpMax<uint32_t>(), A.ticket + 1);
-        const uint32_t xs = lookback_exclusive(A.desc_sum, tile, agg_sum, OpAdd<uint32_t>(), A.ticket + 1);
+        uint32_t xm, xs;
+        if (A.packed) {  // lists shorter than 2^31: one walk for both values
+            const MaxSum x = lookback_exclusive_packed(A.desc_max, tile, MaxSum{agg_max, agg_sum}, A.ticket + 1);
+            xm = x.mx;
+            xs = x.sum;
+        } else {
+            xm = lookback_exclusive(A.desc_max, tile, agg_max, OpMax<uint32_t>(), A.ticket + 1);
+            xs = lookback_exclusive(A.desc_sum, tile, agg_sum, OpAdd<uint32_t>(), A.ticket + 1);
+        }
         if (lane == 0) {
             s_excl[0] = xm;
             s_excl[1] = xs;
@@ -818,6 +879,7 @@ uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *grp, const 
         A.lcp_list = lcp_list; A.dbl_h = dbl_h; A.Plcp = Plcp;
         A.new_slot = new_slot; A.new_grp = new_grp;
         A.desc_max = desc; A.desc_sum = desc + tiles;
+        A.packed = n < 0x80000000u ? 1 : 0;  // slots and counts fit 31 bits
         A.ticket = reinterpret_cast<uint32_t *>(desc + 2 * tiles);
         A.d_total = d_total;
         regroup_kernel<kRound0><<<(unsigned)tiles, kThreads, 0, s>>>(A);
