@@ -52,8 +52,25 @@ __device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t num_tiles) {
     return k < cnt ? start + k : 0xffffffffu;
 }
 
-template <typename KeyT>
-__global__ __launch_bounds__(kThreads) void rs_hist_kernel(const KeyT *__restrict__ keys, size_t n, int shift,
+// where a pass reads its pairs from: arrays, or (first pass of the suffix sort) the packed text
+template <typename KeyT> struct ArraySrc {
+    const KeyT *__restrict__ keys;
+    const uint32_t *__restrict__ vals;
+    __device__ __forceinline__ KeyT key(size_t idx) const { return keys[idx]; }
+    __device__ __forceinline__ uint32_t val(size_t idx) const { return vals[idx]; }
+};
+template <int BITS> struct TextSrc {
+    const uint64_t *__restrict__ words;
+    TermTable terms;
+    bool segmented;
+    __device__ __forceinline__ uint64_t key(size_t idx) const {
+        return initial_key<BITS>(words, terms, segmented, (uint32_t)idx);
+    }
+    __device__ __forceinline__ uint32_t val(size_t idx) const { return (uint32_t)idx; }
+};
+
+template <typename KeyT, typename Src>
+__global__ __launch_bounds__(kThreads) void rs_hist_kernel(Src src, size_t n, int shift,
                                                            uint32_t *__restrict__ tile_hist,
                                                            uint32_t num_tiles) {
     __shared__ uint32_t hist[kBins];
@@ -65,7 +82,7 @@ __global__ __launch_bounds__(kThreads) void rs_hist_kernel(const KeyT *__restric
 #pragma unroll
     for (int j = 0; j < kKeysPerThread; ++j) {
         const size_t idx = base + (size_t)j * kThreads + threadIdx.x;
-        k[j] = idx < n ? keys[idx] : KeyT(0);
+        k[j] = idx < n ? src.key(idx) : KeyT(0);
     }
 #pragma unroll
     for (int j = 0; j < kKeysPerThread; ++j) {
@@ -76,11 +93,10 @@ __global__ __launch_bounds__(kThreads) void rs_hist_kernel(const KeyT *__restric
     tile_hist[(size_t)threadIdx.x * num_tiles + blockIdx.x] = hist[threadIdx.x];
 }
 
-template <typename KeyT>
+template <typename KeyT, typename Src>
 __global__ __launch_bounds__(kThreads) void rs_scatter_kernel(
-    const KeyT *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, KeyT *__restrict__ keys_out,
-    uint32_t *__restrict__ vals_out, size_t n, int shift, const uint32_t *__restrict__ tile_base,
-    uint32_t num_tiles) {
+    Src src, KeyT *__restrict__ keys_out, uint32_t *__restrict__ vals_out, size_t n, int shift,
+    const uint32_t *__restrict__ tile_base, uint32_t num_tiles) {
     const uint32_t tile = xcd_tile(blockIdx.x, num_tiles);
     if (tile == 0xffffffffu) return;
     __shared__ uint64_t s_stage[kTile];  // keys, then values, take turns here
@@ -111,8 +127,8 @@ __global__ __launch_bounds__(kThreads) void rs_scatter_kernel(
     for (int row = 0; row < kKeysPerThread; ++row) {
         const size_t idx = base + (size_t)w * kWaveSpan + (size_t)row * 64 + lane;
         const bool valid = idx < n;
-        key[row] = valid ? keys_in[idx] : KeyT(0);
-        val[row] = valid ? vals_in[idx] : 0;
+        key[row] = valid ? src.key(idx) : KeyT(0);
+        val[row] = valid ? src.val(idx) : 0;
     }
     // rank inside the wavefront: rows of 64 keys in input order (keeps the sort stable)
 #pragma unroll
@@ -201,9 +217,30 @@ __global__ __launch_bounds__(kThreads) void rs_scatter_kernel(
     }
 }
 
+// one pass: histogram, scan, scatter
+template <typename KeyT, typename Src>
+void radix_pass(Src src, KeyT *keys_out, uint32_t *vals_out, size_t n, int shift, uint32_t *hist, uint32_t num_tiles,
+                double hist_bytes, double scatter_bytes, Arena &arena, hipStream_t stream, Profiler *prof) {
+    {
+        ProfScope ps(prof, "rs_hist", stream, hist_bytes);
+        rs_hist_kernel<KeyT, Src><<<num_tiles, kThreads, 0, stream>>>(src, n, shift, hist, num_tiles);
+        KERNEL_CHECK();
+    }
+    {
+        ProfScope ps(prof, "rs_scan", stream, 8.0 * (double)kBins * num_tiles);
+        scan_exclusive_add_u32(hist, hist, (size_t)kBins * num_tiles, nullptr, arena, stream);
+    }
+    {
+        ProfScope ps(prof, "rs_scatter", stream, scatter_bytes);
+        const uint32_t grid = (uint32_t)div_up(num_tiles, 8) * 8;
+        rs_scatter_kernel<KeyT, Src><<<grid, kThreads, 0, stream>>>(src, keys_out, vals_out, n, shift, hist, num_tiles);
+        KERNEL_CHECK();
+    }
+}
+
 template <typename KeyT>
 int radix_sort_impl(KeyT *keys[2], uint32_t *vals[2], size_t n, const int *shifts, int npasses, Arena &arena,
-                    hipStream_t stream, Profiler *prof) {
+                    hipStream_t stream, Profiler *prof, int first_pass = 0) {
     if (n == 0 || npasses == 0) return 0;
     if (sizeof(KeyT) == 8)
         for (int p = 0; p < npasses; ++p)
@@ -211,26 +248,13 @@ int radix_sort_impl(KeyT *keys[2], uint32_t *vals[2], size_t n, const int *shift
     const size_t m = arena.mark();
     const uint32_t num_tiles = (uint32_t)div_up(n, kTile);
     uint32_t *hist = arena.alloc<uint32_t>((size_t)kBins * num_tiles);
-    int cur = 0;
-    for (int p = 0; p < npasses; ++p) {
-        {
-            ProfScope ps(prof, "rs_hist", stream, (double)sizeof(KeyT) * (double)n);
-            rs_hist_kernel<KeyT><<<num_tiles, kThreads, 0, stream>>>(keys[cur], n, shifts[p], hist, num_tiles);
-            KERNEL_CHECK();
-        }
-        {
-            ProfScope ps(prof, "rs_scan", stream, 8.0 * (double)kBins * num_tiles);
-            scan_exclusive_add_u32(hist, hist, (size_t)kBins * num_tiles, nullptr, arena, stream);
-        }
-        {
-            // algorithmic bytes of one scatter launch: every (key, value) pair read once and
-            // written once = 2 * (sizeof(key) + 4) bytes per pair
-            ProfScope ps(prof, "rs_scatter", stream, 2.0 * (sizeof(KeyT) + 4.0) * (double)n);
-            const uint32_t grid = (uint32_t)div_up(num_tiles, 8) * 8;
-            rs_scatter_kernel<KeyT><<<grid, kThreads, 0, stream>>>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1],
-                                                                   n, shifts[p], hist, num_tiles);
-            KERNEL_CHECK();
-        }
+    int cur = first_pass & 1;
+    for (int p = first_pass; p < npasses; ++p) {
+        // algorithmic bytes of one scatter launch: every (key, value) pair read once and
+        // written once = 2 * (sizeof(key) + 4) bytes per pair
+        radix_pass<KeyT>(ArraySrc<KeyT>{keys[cur], vals[cur]}, keys[cur ^ 1], vals[cur ^ 1], n, shifts[p], hist,
+                         num_tiles, (double)sizeof(KeyT) * (double)n, 2.0 * (sizeof(KeyT) + 4.0) * (double)n, arena,
+                         stream, prof);
         cur ^= 1;
     }
     arena.rewind(m);
@@ -352,6 +376,38 @@ int radix_sort_pairs(uint64_t *keys[2], uint32_t *vals[2], size_t n, const int *
 int radix_sort_pairs(uint32_t *keys[2], uint32_t *vals[2], size_t n, const int *shifts, int npasses,
                      Arena &arena, hipStream_t stream, Profiler *prof) {
     return radix_sort_impl<uint32_t>(keys, vals, n, shifts, npasses, arena, stream, prof);
+}
+
+int radix_sort_initial_keys(const PackedText &text, uint64_t *keys[2], uint32_t *vals[2], const int *shifts,
+                            int npasses, Arena &arena, hipStream_t stream, Profiler *prof) {
+    const size_t n = text.n;
+    if (n == 0 || npasses == 0) return 0;
+    {
+        // first pass: pairs computed from the packed text, written to buffer 1.  Algorithmic bytes:
+        // the text window once per kernel (bits / 8 per symbol) and, for the scatter, the sorted
+        // pairs written once.
+        const size_t m = arena.mark();
+        const uint32_t num_tiles = (uint32_t)div_up(n, kTile);
+        uint32_t *hist = arena.alloc<uint32_t>((size_t)kBins * num_tiles);
+        const double text_bytes = (double)n * text.bits / 8.0;
+        const double out_bytes = text_bytes + 12.0 * (double)n;
+        switch (text.bits) {
+        case 2:
+            radix_pass<uint64_t>(TextSrc<2>{text.words, text.terms, text.segmented}, keys[1], vals[1], n, shifts[0], hist,
+                                 num_tiles, text_bytes, out_bytes, arena, stream, prof);
+            break;
+        case 4:
+            radix_pass<uint64_t>(TextSrc<4>{text.words, text.terms, text.segmented}, keys[1], vals[1], n, shifts[0], hist,
+                                 num_tiles, text_bytes, out_bytes, arena, stream, prof);
+            break;
+        default:
+            radix_pass<uint64_t>(TextSrc<8>{text.words, text.terms, text.segmented}, keys[1], vals[1], n, shifts[0], hist,
+                                 num_tiles, text_bytes, out_bytes, arena, stream, prof);
+            break;
+        }
+        arena.rewind(m);
+    }
+    return radix_sort_impl<uint64_t>(keys, vals, n, shifts, npasses, arena, stream, prof, 1);
 }
 
 }  // namespace nolzss

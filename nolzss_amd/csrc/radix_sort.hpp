@@ -1,6 +1,7 @@
 // radix_sort.hpp -- LSD radix sort of (u64 or u32 key, u32 value) pairs, 8-bit digits.
 #pragma once
 #include "common.hpp"
+#include "text.hpp"
 
 namespace nolzss {
 
@@ -15,6 +16,13 @@ int radix_sort_pairs(uint64_t *keys[2], uint32_t *vals[2], size_t n, const int *
                      int npasses, Arena &arena, hipStream_t stream, Profiler *prof = nullptr);
 int radix_sort_pairs(uint32_t *keys[2], uint32_t *vals[2], size_t n, const int *shifts,
                      int npasses, Arena &arena, hipStream_t stream, Profiler *prof = nullptr);
+
+// The round-0 sort of the suffix array: pairs (initial_key(i), i) for i < text.n, sorted by the given
+// digits.  The first pass computes the keys from the packed text on the fly (histogram and scatter
+// kernels read 2 bits per base instead of 12 bytes per suffix, and no kernel writes the unsorted
+// pairs); keys[0] / vals[0] are only used as ping-pong space from the second pass on.
+int radix_sort_initial_keys(const PackedText &text, uint64_t *keys[2], uint32_t *vals[2], const int *shifts,
+                            int npasses, Arena &arena, hipStream_t stream, Profiler *prof = nullptr);
 
 // out[idx[k]] = val[k] for k < count, idx[k] < n_out (entries with idx >= n_out are dropped).
 // A random 4-byte scatter over an array much larger than the caches costs a read-modify-write

@@ -148,38 +148,6 @@ __global__ __launch_bounds__(kThreads) void pack_kernel(const uint8_t *__restric
 }
 
 // ---------------------------------------------------------------------------------------
-// round 0 keys
-// ---------------------------------------------------------------------------------------
-template <int BITS>
-__global__ __launch_bounds__(kThreads) void initial_keys_kernel(const uint64_t *__restrict__ words,
-                                                                uint32_t n, TermTable terms, bool segmented,
-                                                                uint64_t *__restrict__ keys,
-                                                                uint32_t *__restrict__ vals) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint64_t w = sym_word<BITS>(words, i);
-        const uint32_t k = term_lower_bound(terms, (uint32_t)i);
-        const uint32_t lim = terms.pos[k] - (uint32_t)i;  // symbols before the next terminator
-        if (BITS == 2 && segmented) {
-            // [kSegSyms symbols][5-bit tag][8-bit terminator index]: a suffix that meets a terminator
-            // inside the key window gets a key of its own, so every group left after the sort
-            // consists of suffixes that agree on kSegSyms real nucleotides
-            const uint32_t tag = lim < (uint32_t)kSegSyms ? lim : (uint32_t)kSegSyms;
-            uint64_t sym = w >> (64 - kSegSyms * 2);
-            if (tag < (uint32_t)kSegSyms) sym &= ~((1ull << (2 * (kSegSyms - tag))) - 1ull);
-            keys[i] = (sym << (kSegTagBits + kSegTermBits)) | ((uint64_t)tag << kSegTermBits) |
-                      (tag < (uint32_t)kSegSyms ? (uint64_t)(k & 255u) : 0ull);
-        } else {
-            constexpr int K = KeyLayout<BITS>::kSyms;
-            constexpr int TAG = KeyLayout<BITS>::kTagBits;
-            const uint64_t tag = lim < (uint32_t)K ? lim : (uint32_t)K;
-            keys[i] = ((w >> (64 - K * BITS)) << TAG) | tag;
-        }
-        vals[i] = (uint32_t)i;
-    }
-}
-
-// ---------------------------------------------------------------------------------------
 // regrouping after a sort
 // ---------------------------------------------------------------------------------------
 // The sorted view of the m active elements is either the 64-bit round-0 keys (kRound0) or, in
@@ -841,14 +809,6 @@ __global__ __launch_bounds__(kThreads) void rank_to_isa_kernel(uint32_t *__restr
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) rank[i] -= 1u;
 }
 
-template <int BITS>
-void launch_initial_keys(Context &ctx, const PackedText &t, uint64_t *keys, uint32_t *vals) {
-    ProfScope ps(ctx.profiler(), "sa_initial_keys", ctx.stream);
-    initial_keys_kernel<BITS><<<grid_for(t.n, kThreads), kThreads, 0, ctx.stream>>>(t.words, t.n, t.terms, t.segmented,
-                                                                                keys, vals);
-    KERNEL_CHECK();
-}
-
 // shared tail of every round: sorted view of m active elements -> sa / rank / next active list
 template <bool kRound0>
 uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *grp, const uint32_t *lo, uint32_t *vals,
@@ -1031,11 +991,13 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     uint32_t *rank = isa;
 
     // ---- round 0: order by the first K symbols -------------------------------------------
+    // (the keys are never materialised in text order: the first radix pass computes them from the
+    // packed text, radix_sort_initial_keys)
     int k_syms = 0;
     switch (text.bits) {
-    case 2: launch_initial_keys<2>(ctx, text, keys[0], vals[0]); k_syms = KeyLayout<2>::kSyms; break;
-    case 4: launch_initial_keys<4>(ctx, text, keys[0], vals[0]); k_syms = KeyLayout<4>::kSyms; break;
-    default: launch_initial_keys<8>(ctx, text, keys[0], vals[0]); k_syms = KeyLayout<8>::kSyms; break;
+    case 2: k_syms = KeyLayout<2>::kSyms; break;
+    case 4: k_syms = KeyLayout<4>::kSyms; break;
+    default: k_syms = KeyLayout<8>::kSyms; break;
     }
     int cur;
     {
@@ -1050,7 +1012,7 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         int shifts0[8], np0 = 0;
         for (int b = 0; b < key_bits && np0 < 8; b += kRadixBits) shifts0[np0++] = b;
         ProfScope ps(ctx.profiler(), "sa_sort_initial", s);
-        cur = radix_sort_pairs(keys, vals, n, shifts0, np0, arena, s, ctx.profiler());
+        cur = radix_sort_initial_keys(text, keys, vals, shifts0, np0, arena, s, ctx.profiler());
         if (np0 != key_passes || vals[cur] != sa) throw HipError("suffix array: key sort did not end in sa");
     }
     int tag_bits = 0, low_bits = 0;

@@ -129,4 +129,27 @@ __device__ __forceinline__ int suffix_compare(const uint64_t *__restrict__ w, co
     return 0;
 }
 
+// Round-0 sort key of suffix i: its first K symbols and a length tag (plain texts), or
+// [kSegSyms symbols][5-bit tag][8-bit terminator index] for segmented texts: a suffix that meets a
+// terminator inside the key window gets a key of its own, so every group left after the sort
+// consists of suffixes that agree on kSegSyms real nucleotides.
+template <int BITS>
+__device__ __forceinline__ uint64_t initial_key(const uint64_t *__restrict__ words, const TermTable &terms,
+                                                bool segmented, uint32_t i) {
+    const uint64_t w = sym_word<BITS>(words, i);
+    const uint32_t k = term_lower_bound(terms, i);
+    const uint32_t lim = terms.pos[k] - i;  // symbols before the next terminator
+    if (BITS == 2 && segmented) {
+        const uint32_t tag = lim < (uint32_t)kSegSyms ? lim : (uint32_t)kSegSyms;
+        uint64_t sym = w >> (64 - kSegSyms * 2);
+        if (tag < (uint32_t)kSegSyms) sym &= ~((1ull << (2 * (kSegSyms - tag))) - 1ull);
+        return (sym << (kSegTagBits + kSegTermBits)) | ((uint64_t)tag << kSegTermBits) |
+               (tag < (uint32_t)kSegSyms ? (uint64_t)(k & 255u) : 0ull);
+    }
+    constexpr int K = KeyLayout<BITS>::kSyms;
+    constexpr int TAG = KeyLayout<BITS>::kTagBits;
+    const uint64_t tag = lim < (uint32_t)K ? lim : (uint32_t)K;
+    return ((w >> (64 - K * BITS)) << TAG) | tag;
+}
+
 }  // namespace nolzss
