@@ -27,7 +27,10 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
-constexpr int kKeysPerThread = 16;  // 12 and 8 measured within 3 % of this on MI355X
+#ifndef NOLZSS_KPT
+#define NOLZSS_KPT 16
+#endif
+constexpr int kKeysPerThread = NOLZSS_KPT;  // 12 and 8 measured within 3 % of this on MI355X
 constexpr int kTile = kThreads * kKeysPerThread;  // 4096
 constexpr int kBins = 1 << kRadixBits;
 constexpr int kWaveSpan = 64 * kKeysPerThread;  // 1024 keys per wavefront, 16 rows of 64
@@ -109,7 +112,6 @@ __global__ __launch_bounds__(kThreads) void rs_scatter_kernel(
     const int tid = threadIdx.x;
     const int w = tid >> 6;
     const int lane = tid & 63;
-    volatile uint32_t *whist = s_whist + w * kBins;
 
 #pragma unroll
     for (int k = 0; k < kWaves; ++k) s_whist[k * kBins + tid] = 0;
@@ -130,7 +132,14 @@ __global__ __launch_bounds__(kThreads) void rs_scatter_kernel(
         key[row] = valid ? src.key(idx) : KeyT(0);
         val[row] = valid ? src.val(idx) : 0;
     }
-    // rank inside the wavefront: rows of 64 keys in input order (keeps the sort stable)
+    // rank inside the wavefront: rows of 64 keys in input order (keeps the sort stable).  The lowest
+    // lane of every digit group adds the group's size to the wave's counter with ONE returning LDS
+    // atomic per row; the atomics of all rows are issued back to back (LDS executes a wave's
+    // operations in order, so row r sees rows < r) and the results are handed to the other lanes
+    // of the groups afterwards -- no row waits for the LDS round trip of the row in front.
+    // lrank[row] packs, until the second loop: counter value seen by the group's first lane (11 bits,
+    // <= 1024 keys per wave) | lanes of my group below me << 11 | lane of the first member << 17
+    uint32_t *wcount = s_whist + w * kBins;
 #pragma unroll
     for (int row = 0; row < kKeysPerThread; ++row) {
         const size_t idx = base + (size_t)w * kWaveSpan + (size_t)row * 64 + lane;
@@ -148,12 +157,15 @@ __global__ __launch_bounds__(kThreads) void rs_scatter_kernel(
             diff_hi |= (uint32_t)(bal >> 32) ^ m;
         }
         const uint64_t peers = ~(((uint64_t)diff_hi << 32) | diff_lo) & __ballot(valid);
-        if (valid) {
-            const uint64_t below = peers & lanemask_lt();
-            const uint32_t old = whist[d];
-            lrank[row] = old + (uint32_t)__popcll(below);
-            if (below == 0) whist[d] = old + (uint32_t)__popcll(peers);
-        }
+        const uint64_t below = peers & lanemask_lt();
+        uint32_t seen = 0;
+        if (valid && below == 0) seen = atomicAdd(&wcount[d], (uint32_t)__popcll(peers));
+        lrank[row] = seen | ((uint32_t)__popcll(below) << 11) | ((uint32_t)(peers ? __builtin_ctzll(peers) : 0) << 17);
+    }
+#pragma unroll
+    for (int row = 0; row < kKeysPerThread; ++row) {
+        const uint32_t packed = lrank[row];
+        lrank[row] = ((uint32_t)__shfl((int)packed, (int)(packed >> 17), 64) & 0x7ffu) + ((packed >> 11) & 63u);
     }
     __syncthreads();
 
