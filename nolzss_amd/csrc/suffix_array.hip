@@ -382,6 +382,12 @@ __global__ __launch_bounds__(kThreads) void regroup_kernel(RegroupArgs A) {
                     if (p != 0) l += pyr_range<false>(A.Plcp, p, q - 1);
                 }
                 A.lcp[slot[k]] = l;
+                // the range-minimum pyramid over the LCP array is kept up to date instead of being
+                // rebuilt every round: a decided value only ever replaces a pending code (+infinity)
+                for (int lev = 1; lev < A.Plcp.nlev; ++lev) {
+                    uint32_t *up = const_cast<uint32_t *>(A.Plcp.lvl[lev]) + (slot[k] >> (kPyrShift * lev));
+                    if (atomicMin(up, l) <= l) break;
+                }
             }
         } else if (in) {
             // LCP of neighbours that round 0 already separates can be read off the two keys
@@ -816,14 +822,11 @@ uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *grp, const 
                  uint32_t *new_grp, uint32_t *scratch_idx, uint32_t *scratch_val, uint32_t *rank_val,
                  uint32_t *d_total, uint32_t *lcp = nullptr, int sym_bits = 0, int tag_bits = 0, int bits = 0,
                  const uint32_t *lcp_list = nullptr, int low_bits = 0, uint32_t dbl_h = 0,
-                 uint32_t *rank_by_slot = nullptr) {
+                 uint32_t *rank_by_slot = nullptr, const Pyramid *plcp = nullptr) {
     hipStream_t s = ctx.stream;
     const size_t pmark = ctx.arena.mark();
-    Pyramid Plcp{};
-    if (!kRound0 && !lcp_list) {  // doubling boundaries read range minima of the LCP values decided so far
-        ProfScope ps(ctx.profiler(), "sa_lcp_pyramid", s);
-        Plcp = build_pyramid(lcp, n + 1, false, ctx.arena, s);
-    }
+    // doubling boundaries read range minima of the LCP values decided so far
+    const Pyramid Plcp = plcp ? *plcp : Pyramid{};
     const size_t tiles = div_up(m, kFuseTile);
     uint32_t total[2] = {0, 0};
     {
@@ -1093,6 +1096,13 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     }
     write_all_ranks();
 
+    // one range-minimum pyramid over the LCP values known so far; the regroup kernel keeps it current
+    Pyramid Plcp{};
+    if (m > 0) {
+        ProfScope ps(ctx.profiler(), "sa_lcp_pyramid", s);
+        Plcp = build_pyramid(lcp, n + 1, false, arena, s);
+    }
+
     while (m > 0) {
         if (h >= n || rounds > 40) throw HipError("suffix array: prefix doubling failed to converge");
         const uint32_t *slot = act_slot[a_cur], *grp = act_grp[a_cur];
@@ -1127,7 +1137,7 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         }
         m = regroup<false>(ctx, nullptr, grp, out_lo, out_vals, slot, m, n, sa, rank, act_slot[a_cur ^ 1],
                            act_grp[a_cur ^ 1], scratch_idx, scratch_val, rank_val, d_total, lcp,
-                           0, 0, 0, nullptr, 0, (uint32_t)h);
+                           0, 0, 0, nullptr, 0, (uint32_t)h, nullptr, &Plcp);
         a_cur ^= 1;
         if (trace)
             fprintf(stderr, "[nolzss]   doubling round h=%llu: %u in large groups, %u still tied\n",
