@@ -67,7 +67,7 @@ __global__ __launch_bounds__(kLdsThreads) void lpf_tile_kernel(const uint32_t *_
     __syncthreads();
     const int w = threadIdx.x >> 6;
     const uint32_t far_bit = n <= 0x80000000u ? 0x80000000u : 0u;
-    lds_search_wave<NS, NS>(s_sa, s_lcp, n, base, s_len, s_pos, s_list[w][0], s_list[w][1],
+    lds_search_wave<NS, NS, 1>(s_sa, s_lcp, n, base, s_len, s_pos, s_list[w][0], s_list[w][1],
                             [](uint32_t) { return true; }, [](uint32_t) { return 0u; }, far_bit);
     // ranks with a search beyond the reach go to the far queue: one atomic per wavefront
     uint64_t far_mask[kLdsPerWave / 64];

@@ -130,7 +130,7 @@ __device__ __forceinline__ int lds_scan_round(const uint32_t *s_sa, const uint32
 // Results: res_len[k * kLdsTile + t] (0: none, far_mark(): left the reach) and, for the first NP
 // searches only, res_pos[k * kLdsTile + t] (suffix start of the match).
 // list0/list1: this wave's two work lists (NS * kLdsPerWave items each).
-template <int NS, int NP, typename Active, typename ThrGt>
+template <int NS, int NP, int kPerLane, typename Active, typename ThrGt>
 __device__ __forceinline__ void lds_search_wave(const uint32_t *s_sa, const uint32_t *s_lcp, uint32_t n,
                                                 uint32_t base, uint32_t *res_len, uint32_t *res_pos,
                                                 uint16_t *list0, uint16_t *list1, Active active, ThrGt thr_gt,
@@ -205,11 +205,13 @@ __device__ __forceinline__ void lds_search_wave(const uint32_t *s_sa, const uint
 
     // ---- the long tail: few searches left, each possibly far from done (a search that has taken
     // s steps needs about s more).  Rounds of 8 steps would finish almost nothing per round, and
-    // one search at a time leaves the wavefront waiting on a chain of dependent LDS reads and DPP
-    // steps, so the wavefront splits into its four 16-lane rows: every row works on its own
-    // search, lane l of the row inspects step s0 + l + 1, a row-wide prefix minimum (4 DPP steps)
-    // gives every lane its running LCP, the first lane that stops writes the result, and a row
-    // that is done takes the next search from the list.
+    // the kernel is bound by instruction issue, so the tail is organised for few instructions per
+    // step: the wavefront splits into its four 16-lane rows, every row works on its own search,
+    // each lane inspects kPerLane consecutive steps (1 for the forward-only searches of plain mode,
+    // which mostly end within a few more steps; 4 = 64 steps per row and iteration for the
+    // reverse-complement kernel, whose searches for greater values run longer), a row-wide
+    // prefix minimum over the lanes' own minima (DPP) gives every step its running LCP, the first
+    // lane that stops writes the result, and a row that is done takes the next search.
     {
         const int row = lane >> 4, rl = lane & 15;
         uint32_t next = 0;   // next list entry to hand out (wave-uniform)
@@ -240,37 +242,60 @@ __device__ __forceinline__ void lds_search_wave(const uint32_t *s_sa, const uint
             }
             next += (uint32_t)__popc(idle_rows);
             if (!__ballot(busy)) break;
-            const int step = s0 + rl + 1;
-            const bool inside = step <= kLdsReach;
-            const int q = inside ? (up ? li - step : li + step) : li;
-            const uint32_t c = (busy && inside) ? s_lcp[q + (up ? 1 : 0)] : 0xffffffffu;
-            const uint32_t v = s_sa[q];
-            // prefix minimum over the lanes of my row
-            uint32_t mk = c;
-            mk = OpMinU32()(mk, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)mk, 0x111, 0xf, 0xf, false));  // row_shr:1
-            mk = OpMinU32()(mk, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)mk, 0x112, 0xf, 0xf, false));  // row_shr:2
-            mk = OpMinU32()(mk, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)mk, 0x114, 0xf, 0xf, false));  // row_shr:4
-            mk = OpMinU32()(mk, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)mk, 0x118, 0xf, 0xf, false));  // row_shr:8
-            mk = mk < m ? mk : m;
-            const bool dead = inside && mk == 0;  // LCP[0] = LCP[n] = 0 end every search in range
-            const bool hit = inside && !dead && (greater ? (v > x) : (v < x));
-            const uint64_t stop = __ballot(busy && (dead || hit || !inside));
-            const uint32_t mine = (uint32_t)(stop >> (row * 16)) & 0xffffu;
+            // my four steps: s0 + 4 rl + 1 .. s0 + 4 rl + 4
+            uint32_t c[kPerLane], v[kPerLane];
+            bool in[kPerLane];
+#pragma unroll
+            for (int j = 0; j < kPerLane; ++j) {
+                const int step = s0 + rl * kPerLane + j + 1;
+                in[j] = step <= kLdsReach;
+                const int q = in[j] ? (up ? li - step : li + step) : li;
+                c[j] = (busy && in[j]) ? s_lcp[q + (up ? 1 : 0)] : 0xffffffffu;
+                v[j] = s_sa[q];
+            }
+#pragma unroll
+            for (int j = 1; j < kPerLane; ++j) c[j] = c[j] < c[j - 1] ? c[j] : c[j - 1];  // minima inside the lane
+            // minimum over the lanes in front of me in my row (and over the steps taken before)
+            uint32_t inc = c[kPerLane - 1];
+            inc = OpMinU32()(inc, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)inc, 0x111, 0xf, 0xf, false));  // row_shr:1
+            inc = OpMinU32()(inc, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)inc, 0x112, 0xf, 0xf, false));  // row_shr:2
+            inc = OpMinU32()(inc, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)inc, 0x114, 0xf, 0xf, false));  // row_shr:4
+            inc = OpMinU32()(inc, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)inc, 0x118, 0xf, 0xf, false));  // row_shr:8
+            uint32_t pre = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)inc, 0x111, 0xf, 0xf, false);  // exclusive
+            pre = pre < m ? pre : m;
+            // the first of my steps that stops, if any
+            bool lane_stop = false, f_hit = false, f_dead = false;
+            uint32_t f_len = 0, f_pos = kNoPos;
+#pragma unroll
+            for (int j = kPerLane - 1; j >= 0; --j) {
+                const uint32_t mk = c[j] < pre ? c[j] : pre;
+                const bool dead = in[j] && mk == 0;  // LCP[0] = LCP[n] = 0 end every search in range
+                const bool hit = in[j] && !dead && (greater ? (v[j] > x) : (v[j] < x));
+                const bool stop = dead || hit || !in[j];
+                lane_stop = stop || lane_stop;
+                f_hit = stop ? hit : f_hit;
+                f_dead = stop ? dead : f_dead;
+                f_len = stop ? mk : f_len;
+                f_pos = stop ? v[j] : f_pos;
+            }
+            const uint64_t stopb = __ballot(busy && lane_stop);
+            const uint32_t mine = (uint32_t)(stopb >> (row * 16)) & 0xffffu;
             // running minimum at the end of each row, for the rows that go on
-            const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)mk, 15);
-            const uint32_t e1 = (uint32_t)__builtin_amdgcn_readlane((int)mk, 31);
-            const uint32_t e2 = (uint32_t)__builtin_amdgcn_readlane((int)mk, 47);
-            const uint32_t e3 = (uint32_t)__builtin_amdgcn_readlane((int)mk, 63);
+            const uint32_t incm = inc < m ? inc : m;
+            const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)incm, 15);
+            const uint32_t e1 = (uint32_t)__builtin_amdgcn_readlane((int)incm, 31);
+            const uint32_t e2 = (uint32_t)__builtin_amdgcn_readlane((int)incm, 47);
+            const uint32_t e3 = (uint32_t)__builtin_amdgcn_readlane((int)incm, 63);
             if (mine) {
                 if (rl == __ffs((int)mine) - 1) {  // the first lane that stops decides
                     uint32_t out_len, out_pos = kNoPos;
-                    if (hit) {
-                        out_len = mk;
-                        out_pos = v;
-                    } else if (dead) {
+                    if (f_hit) {
+                        out_len = f_len;
+                        out_pos = f_pos;
+                    } else if (f_dead) {
                         out_len = 0;
                     } else {  // the end of the reach
-                        out_len = far_mark(mk, far_bit);
+                        out_len = far_mark(f_len, far_bit);
                     }
                     res_len[k * kLdsTile + t] = out_len;
                     if (k < NP) res_pos[k * kLdsTile + t] = out_pos;
@@ -278,7 +303,7 @@ __device__ __forceinline__ void lds_search_wave(const uint32_t *s_sa, const uint
                 busy = false;
             } else if (busy) {
                 m = row == 0 ? e0 : (row == 1 ? e1 : (row == 2 ? e2 : e3));
-                s0 += 16;
+                s0 += 16 * kPerLane;
             }
         }
     }
