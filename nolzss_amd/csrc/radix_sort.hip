@@ -32,6 +32,7 @@ constexpr int kWaves = kThreads / 64;
 #endif
 constexpr int kKeysPerThread = NOLZSS_KPT;  // 12 and 8 measured within 3 % of this on MI355X
 constexpr int kTile = kThreads * kKeysPerThread;  // 4096
+static_assert(kTile == kSortTile, "tile size is part of the SegView contract");
 constexpr int kBins = 1 << kRadixBits;
 constexpr int kWaveSpan = 64 * kKeysPerThread;  // 1024 keys per wavefront, 16 rows of 64
 
@@ -75,33 +76,34 @@ template <int BITS> struct TextSrc {
 template <typename KeyT, typename Src>
 __global__ __launch_bounds__(kThreads) void rs_hist_kernel(Src src, size_t n, int shift,
                                                            uint32_t *__restrict__ tile_hist,
-                                                           uint32_t num_tiles) {
+                                                           uint32_t num_tiles, SegView seg) {
     __shared__ uint32_t hist[kBins];
     hist[threadIdx.x] = 0;
     __syncthreads();
-    const size_t base = (size_t)blockIdx.x * kTile;
+    const TileExtent ext = tile_extent(blockIdx.x, n, num_tiles, seg);
     // all loads first: the compiler does not move loads across the LDS atomics
     KeyT k[kKeysPerThread];
 #pragma unroll
     for (int j = 0; j < kKeysPerThread; ++j) {
-        const size_t idx = base + (size_t)j * kThreads + threadIdx.x;
-        k[j] = idx < n ? src.key(idx) : KeyT(0);
+        const uint32_t local = (uint32_t)j * kThreads + threadIdx.x;
+        k[j] = local < ext.count ? src.key(ext.first + local) : KeyT(0);
     }
 #pragma unroll
     for (int j = 0; j < kKeysPerThread; ++j) {
-        const size_t idx = base + (size_t)j * kThreads + threadIdx.x;
-        if (idx < n) atomicAdd(&hist[digit_of(k[j], shift)], 1u);
+        const uint32_t local = (uint32_t)j * kThreads + threadIdx.x;
+        if (local < ext.count) atomicAdd(&hist[digit_of(k[j], shift)], 1u);
     }
     __syncthreads();
-    tile_hist[(size_t)threadIdx.x * num_tiles + blockIdx.x] = hist[threadIdx.x];
+    tile_hist[ext.hist0 + (size_t)threadIdx.x * ext.hstride] = hist[threadIdx.x];
 }
 
-template <typename KeyT, typename Src>
+template <typename KeyT, typename OutT, typename Src>
 __global__ __launch_bounds__(kThreads) void rs_scatter_kernel(
-    Src src, KeyT *__restrict__ keys_out, uint32_t *__restrict__ vals_out, size_t n, int shift,
-    const uint32_t *__restrict__ tile_base, uint32_t num_tiles) {
+    Src src, OutT *__restrict__ keys_out, uint32_t *__restrict__ vals_out, size_t n, int shift,
+    const uint32_t *__restrict__ tile_base, uint32_t num_tiles, SegView seg) {
     const uint32_t tile = xcd_tile(blockIdx.x, num_tiles);
     if (tile == 0xffffffffu) return;
+    const TileExtent ext = tile_extent(tile, n, num_tiles, seg);
     __shared__ uint64_t s_stage[kTile];  // keys, then values, take turns here
     KeyT *s_keys = reinterpret_cast<KeyT *>(s_stage);
     uint32_t *s_vals = reinterpret_cast<uint32_t *>(s_stage);
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(kThreads) void rs_scatter_kernel(
     for (int k = 0; k < kWaves; ++k) s_whist[k * kBins + tid] = 0;
     __syncthreads();
 
-    const size_t base = (size_t)tile * kTile;
+    const size_t base = ext.first;
     KeyT key[kKeysPerThread];
     uint32_t val[kKeysPerThread];
     uint32_t lrank[kKeysPerThread];
@@ -127,10 +129,10 @@ __global__ __launch_bounds__(kThreads) void rs_scatter_kernel(
     // would wait for its own round trip to HBM)
 #pragma unroll
     for (int row = 0; row < kKeysPerThread; ++row) {
-        const size_t idx = base + (size_t)w * kWaveSpan + (size_t)row * 64 + lane;
-        const bool valid = idx < n;
-        key[row] = valid ? src.key(idx) : KeyT(0);
-        val[row] = valid ? src.val(idx) : 0;
+        const uint32_t local = (uint32_t)w * kWaveSpan + (uint32_t)row * 64 + lane;
+        const bool valid = local < ext.count;
+        key[row] = valid ? src.key(base + local) : KeyT(0);
+        val[row] = valid ? src.val(base + local) : 0;
     }
     // rank inside the wavefront: rows of 64 keys in input order (keeps the sort stable).  The lowest
     // lane of every digit group adds the group's size to the wave's counter with ONE returning LDS
@@ -142,8 +144,7 @@ __global__ __launch_bounds__(kThreads) void rs_scatter_kernel(
     uint32_t *wcount = s_whist + w * kBins;
 #pragma unroll
     for (int row = 0; row < kKeysPerThread; ++row) {
-        const size_t idx = base + (size_t)w * kWaveSpan + (size_t)row * 64 + lane;
-        const bool valid = idx < n;
+        const bool valid = (uint32_t)w * kWaveSpan + (uint32_t)row * 64 + lane < ext.count;
         const uint32_t d = digit_of(key[row], shift);
         // lanes with the same digit: the complement of the lanes that differ in some bit.  Per bit,
         // m = 0 / ~0 (bit clear / set, one v_bfe_i32), and (ballot ^ m) is the set of lanes whose bit
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(kThreads) void rs_scatter_kernel(
             s_whist[k * kBins + d] = run;
             run += c[k];
         }
-        s_glob[d] = tile_base[(size_t)d * num_tiles + tile] - bin_start;
+        s_glob[d] = tile_base[ext.hist0 + (size_t)d * ext.hstride] - bin_start;
     }
     __syncthreads();
 
@@ -198,12 +199,11 @@ __global__ __launch_bounds__(kThreads) void rs_scatter_kernel(
     }
 #pragma unroll
     for (int row = 0; row < kKeysPerThread; ++row) {
-        const size_t idx = base + (size_t)w * kWaveSpan + (size_t)row * 64 + lane;
-        if (idx < n) s_keys[lrank[row]] = key[row];
+        if ((uint32_t)w * kWaveSpan + (uint32_t)row * 64 + lane < ext.count) s_keys[lrank[row]] = key[row];
     }
     __syncthreads();
 
-    const uint32_t count = (uint32_t)((n - base < (size_t)kTile) ? (n - base) : (size_t)kTile);
+    const uint32_t count = ext.count;
     uint32_t gpos[kKeysPerThread];
 #pragma unroll
     for (int j = 0; j < kKeysPerThread; ++j) {
@@ -212,14 +212,13 @@ __global__ __launch_bounds__(kThreads) void rs_scatter_kernel(
             const KeyT k = s_keys[p];
             const uint32_t d = digit_of(k, shift);
             gpos[j] = s_glob[d] + p;
-            keys_out[gpos[j]] = k;
+            keys_out[gpos[j]] = (OutT)k;
         }
     }
     __syncthreads();
 #pragma unroll
     for (int row = 0; row < kKeysPerThread; ++row) {
-        const size_t idx = base + (size_t)w * kWaveSpan + (size_t)row * 64 + lane;
-        if (idx < n) s_vals[lrank[row]] = val[row];
+        if ((uint32_t)w * kWaveSpan + (uint32_t)row * 64 + lane < ext.count) s_vals[lrank[row]] = val[row];
     }
     __syncthreads();
 #pragma unroll
@@ -230,12 +229,13 @@ __global__ __launch_bounds__(kThreads) void rs_scatter_kernel(
 }
 
 // one pass: histogram, scan, scatter
-template <typename KeyT, typename Src>
-void radix_pass(Src src, KeyT *keys_out, uint32_t *vals_out, size_t n, int shift, uint32_t *hist, uint32_t num_tiles,
-                double hist_bytes, double scatter_bytes, Arena &arena, hipStream_t stream, Profiler *prof) {
+template <typename KeyT, typename OutT, typename Src>
+void radix_pass(Src src, OutT *keys_out, uint32_t *vals_out, size_t n, int shift, uint32_t *hist, uint32_t num_tiles,
+                double hist_bytes, double scatter_bytes, Arena &arena, hipStream_t stream, Profiler *prof,
+                const SegView &seg = SegView{}) {
     {
         ProfScope ps(prof, "rs_hist", stream, hist_bytes);
-        rs_hist_kernel<KeyT, Src><<<num_tiles, kThreads, 0, stream>>>(src, n, shift, hist, num_tiles);
+        rs_hist_kernel<KeyT, Src><<<num_tiles, kThreads, 0, stream>>>(src, n, shift, hist, num_tiles, seg);
         KERNEL_CHECK();
     }
     {
@@ -245,7 +245,8 @@ void radix_pass(Src src, KeyT *keys_out, uint32_t *vals_out, size_t n, int shift
     {
         ProfScope ps(prof, "rs_scatter", stream, scatter_bytes);
         const uint32_t grid = (uint32_t)div_up(num_tiles, 8) * 8;
-        rs_scatter_kernel<KeyT, Src><<<grid, kThreads, 0, stream>>>(src, keys_out, vals_out, n, shift, hist, num_tiles);
+        rs_scatter_kernel<KeyT, OutT, Src><<<grid, kThreads, 0, stream>>>(src, keys_out, vals_out, n, shift, hist,
+                                                                          num_tiles, seg);
         KERNEL_CHECK();
     }
 }
@@ -264,7 +265,7 @@ int radix_sort_impl(KeyT *keys[2], uint32_t *vals[2], size_t n, const int *shift
     for (int p = first_pass; p < npasses; ++p) {
         // algorithmic bytes of one scatter launch: every (key, value) pair read once and
         // written once = 2 * (sizeof(key) + 4) bytes per pair
-        radix_pass<KeyT>(ArraySrc<KeyT>{keys[cur], vals[cur]}, keys[cur ^ 1], vals[cur ^ 1], n, shifts[p], hist,
+        radix_pass<KeyT, KeyT>(ArraySrc<KeyT>{keys[cur], vals[cur]}, keys[cur ^ 1], vals[cur ^ 1], n, shifts[p], hist,
                          num_tiles, (double)sizeof(KeyT) * (double)n, 2.0 * (sizeof(KeyT) + 4.0) * (double)n, arena,
                          stream, prof);
         cur ^= 1;
@@ -390,6 +391,98 @@ int radix_sort_pairs(uint32_t *keys[2], uint32_t *vals[2], size_t n, const int *
     return radix_sort_impl<uint32_t>(keys, vals, n, shifts, npasses, arena, stream, prof);
 }
 
+namespace {
+// bucket starts of the partition the MSD pass has just made: the scanned table holds, for bin d
+// and tile 0, the first output position of the bin
+__global__ void bucket_starts_kernel(const uint32_t *__restrict__ scanned, uint32_t num_tiles, uint32_t n,
+                                     uint32_t *__restrict__ bstart) {
+    const uint32_t d = threadIdx.x;
+    bstart[d] = scanned[(size_t)d * num_tiles];
+    if (d == 0) bstart[kBins] = n;
+}
+
+// one descriptor per tile of the bucketed view (radix_sort.hpp)
+__global__ __launch_bounds__(kThreads) void seg_desc_kernel(const uint32_t *__restrict__ bstart,
+                                                            const uint32_t *__restrict__ tile0,
+                                                            const uint32_t *__restrict__ prev_ne,
+                                                            const uint32_t *__restrict__ next_ne, uint32_t num_tiles,
+                                                            uint32_t *__restrict__ desc) {
+    const uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tile >= num_tiles) return;
+    uint32_t lo = 0, hi = kBins;  // largest b with tile0[b] <= tile (the non-empty one among equals)
+    while (lo + 1 < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (tile0[mid] <= tile)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    const uint32_t t0 = tile0[lo], local = tile - t0;
+    const uint32_t first = bstart[lo] + local * (uint32_t)kTile, end = bstart[lo + 1];
+    uint32_t *d = desc + (size_t)tile * kSegDescWords;
+    d[0] = first;
+    d[1] = end - first < (uint32_t)kTile ? end - first : (uint32_t)kTile;
+    d[2] = lo;
+    d[3] = t0 * (uint32_t)kBins + local;
+    d[4] = tile0[lo + 1] - t0;
+    d[5] = bstart[lo];
+    d[6] = end;
+    d[7] = prev_ne[lo];
+    d[8] = next_ne[lo];
+    d[9] = d[10] = d[11] = 0;
+}
+}  // namespace
+
+void radix_sort_dna_keys(const PackedText &text, uint32_t *keys32[2], uint32_t *vals[2], uint32_t *seg_mem,
+                         SegView &seg_out, Arena &arena, hipStream_t stream, Profiler *prof) {
+    const size_t n = text.n;
+    if (text.bits != 2 || text.segmented) throw HipError("radix_sort_dna_keys: plain 2-bit texts only");
+    const size_t m = arena.mark();
+    const uint32_t tiles0 = (uint32_t)div_up(n, kTile);
+    uint32_t *hist = arena.alloc<uint32_t>((size_t)kBins * ((size_t)tiles0 + kBins));
+    uint32_t *tabs = arena.alloc<uint32_t>(4 * 257);
+    uint32_t *bstart = tabs, *tile0 = tabs + 257, *prev_ne = tabs + 2 * 257, *next_ne = tabs + 3 * 257;
+    const double text_bytes = (double)n * 2 / 8.0;
+    // most significant digit first: key bits 32..39 = the first four bases
+    radix_pass<uint64_t, uint32_t>(TextSrc<2>{text.words, text.terms, false}, keys32[1], vals[1], n, 32, hist, tiles0,
+                                   text_bytes, text_bytes + 8.0 * (double)n, arena, stream, prof);
+    bucket_starts_kernel<<<1, kBins, 0, stream>>>(hist, tiles0, (uint32_t)n, bstart);
+    KERNEL_CHECK();
+    uint32_t h_start[kBins + 1], h_tab[3 * 257];
+    HIP_CHECK(hipMemcpyAsync(h_start, bstart, sizeof(h_start), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    uint32_t *h_tile0 = h_tab, *h_prev = h_tab + 257, *h_next = h_tab + 2 * 257;
+    h_tile0[0] = 0;
+    for (int b = 0; b < kBins; ++b) h_tile0[b + 1] = h_tile0[b] + (uint32_t)div_up((size_t)(h_start[b + 1] - h_start[b]), kTile);
+    uint32_t last = 0xffffffffu;
+    for (int b = 0; b < kBins; ++b) {
+        h_prev[b] = last;
+        if (h_start[b + 1] > h_start[b]) last = (uint32_t)b;
+    }
+    last = 0xffffffffu;
+    for (int b = kBins - 1; b >= 0; --b) {
+        h_next[b] = last;
+        if (h_start[b + 1] > h_start[b]) last = (uint32_t)b;
+    }
+    h_prev[256] = h_next[256] = 0;
+    HIP_CHECK(hipMemcpyAsync(tile0, h_tab, sizeof(h_tab), hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));  // h_tab is a local array
+    seg_out.num_tiles = h_tile0[kBins];
+    seg_desc_kernel<<<(unsigned)div_up(seg_out.num_tiles, kThreads), kThreads, 0, stream>>>(bstart, tile0, prev_ne, next_ne,
+                                                                                       seg_out.num_tiles, seg_mem);
+    KERNEL_CHECK();
+    seg_out.desc = seg_mem;
+    // every bucket by the low 32 key bits, least significant digit first
+    int cur = 1;
+    for (int p = 0; p < 4; ++p) {
+        radix_pass<uint32_t, uint32_t>(ArraySrc<uint32_t>{keys32[cur], vals[cur]}, keys32[cur ^ 1], vals[cur ^ 1], n,
+                                       8 * p, hist, seg_out.num_tiles, 4.0 * (double)n, 16.0 * (double)n, arena,
+                                       stream, prof, seg_out);
+        cur ^= 1;
+    }
+    arena.rewind(m);  // (cur == 1 again)
+}
+
 int radix_sort_initial_keys(const PackedText &text, uint64_t *keys[2], uint32_t *vals[2], const int *shifts,
                             int npasses, Arena &arena, hipStream_t stream, Profiler *prof) {
     const size_t n = text.n;
@@ -405,15 +498,15 @@ int radix_sort_initial_keys(const PackedText &text, uint64_t *keys[2], uint32_t 
         const double out_bytes = text_bytes + 12.0 * (double)n;
         switch (text.bits) {
         case 2:
-            radix_pass<uint64_t>(TextSrc<2>{text.words, text.terms, text.segmented}, keys[1], vals[1], n, shifts[0], hist,
+            radix_pass<uint64_t, uint64_t>(TextSrc<2>{text.words, text.terms, text.segmented}, keys[1], vals[1], n, shifts[0], hist,
                                  num_tiles, text_bytes, out_bytes, arena, stream, prof);
             break;
         case 4:
-            radix_pass<uint64_t>(TextSrc<4>{text.words, text.terms, text.segmented}, keys[1], vals[1], n, shifts[0], hist,
+            radix_pass<uint64_t, uint64_t>(TextSrc<4>{text.words, text.terms, text.segmented}, keys[1], vals[1], n, shifts[0], hist,
                                  num_tiles, text_bytes, out_bytes, arena, stream, prof);
             break;
         default:
-            radix_pass<uint64_t>(TextSrc<8>{text.words, text.terms, text.segmented}, keys[1], vals[1], n, shifts[0], hist,
+            radix_pass<uint64_t, uint64_t>(TextSrc<8>{text.words, text.terms, text.segmented}, keys[1], vals[1], n, shifts[0], hist,
                                  num_tiles, text_bytes, out_bytes, arena, stream, prof);
             break;
         }

@@ -6,6 +6,55 @@
 namespace nolzss {
 
 constexpr int kRadixBits = 8;
+constexpr int kSortTile = 4096;  // elements per tile of the radix kernels (and of the regroup kernel)
+
+// A sorted-by-bucket view of an array for SEGMENTED passes: 256 buckets (the values of a leading
+// digit that an earlier pass partitioned by), each cut into tiles that never straddle a bucket.
+// desc holds kSegDescWords words per tile (device memory): first element, element count, bucket,
+// index of (bin 0, tile) in the bin-major histogram table, distance between the tile's bins there,
+// first / end element of the bucket, nearest non-empty bucket below / above.
+constexpr int kSegDescWords = 12;
+struct SegView {
+    const uint32_t *desc = nullptr;
+    uint32_t num_tiles = 0;
+};
+
+struct TileExtent {
+    size_t first;      // first element
+    uint32_t count;    // elements (<= kSortTile)
+    uint32_t bucket;   // 0 without segmentation
+    size_t hist0;      // index of (bin 0, this tile) in the bin-major histogram table
+    uint32_t hstride;  // distance between the bins of this tile in that table
+    uint32_t bkt_first, bkt_end, prev_ne, next_ne;  // (segmented only)
+};
+
+// tile -> elements; without a SegView tiles are the consecutive kSortTile-element blocks of [0, n)
+__device__ __forceinline__ TileExtent tile_extent(uint32_t tile, size_t n, uint32_t num_tiles, const SegView &seg) {
+    TileExtent e;
+    if (seg.desc == nullptr) {
+        e.first = (size_t)tile * kSortTile;
+        e.count = (uint32_t)((n - e.first < (size_t)kSortTile) ? (n - e.first) : (size_t)kSortTile);
+        e.bucket = 0;
+        e.hist0 = tile;
+        e.hstride = num_tiles;
+        e.bkt_first = 0;
+        e.bkt_end = (uint32_t)n;
+        e.prev_ne = e.next_ne = 0;
+        return e;
+    }
+    const uint4 *d = reinterpret_cast<const uint4 *>(seg.desc + (size_t)tile * kSegDescWords);  // uniform: scalar loads
+    const uint4 a = d[0], b = d[1], c = d[2];
+    e.first = a.x;
+    e.count = a.y;
+    e.bucket = a.z;
+    e.hist0 = a.w;
+    e.hstride = b.x;
+    e.bkt_first = b.y;
+    e.bkt_end = b.z;
+    e.prev_ne = b.w;
+    e.next_ne = c.x;
+    return e;
+}
 
 // Sorts n pairs by the key digits at the given bit offsets (least significant first;
 // each digit is kRadixBits wide).  keys[0]/vals[0] hold the input; the two buffers
@@ -23,6 +72,16 @@ int radix_sort_pairs(uint32_t *keys[2], uint32_t *vals[2], size_t n, const int *
 // pairs); keys[0] / vals[0] are only used as ping-pong space from the second pass on.
 int radix_sort_initial_keys(const PackedText &text, uint64_t *keys[2], uint32_t *vals[2], const int *shifts,
                             int npasses, Arena &arena, hipStream_t stream, Profiler *prof = nullptr);
+
+// Plain 2-bit DNA (40-bit keys): the same sort with 8-byte records.  One most-significant-digit pass
+// computes the keys from the text, partitions the suffixes by their first four bases (the top 8 key
+// bits) and keeps only the LOW 32 key bits; four segmented passes then sort every bucket by those.
+// The top byte of an element is implied by the bucket it lies in (seg_out, whose tile descriptors live
+// in seg_mem: device memory for kSegDescWords * (n / kSortTile + 257) words that must outlive the call).  The sorted low halves end
+// in keys32[1], the suffixes in vals[1].  12 + 4 * 24 bytes of traffic per suffix instead of
+// 12 + 4 * 32 (hist + scatter, keys + values).
+void radix_sort_dna_keys(const PackedText &text, uint32_t *keys32[2], uint32_t *vals[2], uint32_t *seg_mem,
+                         SegView &seg_out, Arena &arena, hipStream_t stream, Profiler *prof = nullptr);
 
 // out[idx[k]] = val[k] for k < count, idx[k] < n_out (entries with idx >= n_out are dropped).
 // A random 4-byte scatter over an array much larger than the caches costs a read-modify-write

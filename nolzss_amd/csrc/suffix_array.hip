@@ -285,7 +285,10 @@ __device__ __forceinline__ MaxSum lookback_exclusive_packed(uint64_t *desc, uint
 }
 
 struct RegroupArgs {
-    const uint64_t *keys;     // round 0: sorted keys
+    const uint64_t *keys;     // round 0: sorted keys ...
+    const uint32_t *keys32;   // ... or their low halves, the top byte implied by the bucket (seg)
+    SegView seg;
+    uint32_t num_tiles;
     const uint32_t *grp;      // later rounds: (group head slot, secondary key) per list element
     const uint32_t *lo;
     const uint32_t *vals;     // suffix start per element
@@ -325,13 +328,21 @@ __global__ __launch_bounds__(kThreads) void regroup_kernel(RegroupArgs A) {
     __syncthreads();
     const uint32_t tile = s_tile;
     const uint32_t m = A.m;
-    const size_t tile_base = (size_t)tile * kFuseTile;
+    static_assert(kFuseTile == kSortTile, "the regroup tiles are the tiles of the segmented sort");
+    const TileExtent ext = tile_extent(tile, m, A.num_tiles, A.seg);
+    const size_t tile_base = ext.first;
     const int lane = lane_id();
     const int w = threadIdx.x >> 6;
     const uint64_t lt = lanemask_lt();
+    const bool bucketed = kRound0 && A.keys32 != nullptr;
 
     auto load_view = [&](size_t a) -> uint64_t {
-        if (kRound0) return A.keys[a];
+        if (kRound0) {
+            if (!bucketed) return A.keys[a];
+            // the element's bucket: the tile's own, unless a is a neighbour across the bucket's end
+            const uint32_t b = a < ext.bkt_first ? ext.prev_ne : (a >= ext.bkt_end ? ext.next_ne : ext.bucket);
+            return ((uint64_t)b << 32) | A.keys32[a];
+        }
         return ((uint64_t)A.grp[a] << 32) | A.lo[a];
     };
     // striped: item k of thread t is element tile_base + k * kThreads + t (coalesced rows).
@@ -344,25 +355,25 @@ __global__ __launch_bounds__(kThreads) void regroup_kernel(RegroupArgs A) {
 #pragma unroll
     for (int k = 0; k < kFuseItems; ++k) {
         const size_t a = tile_base + (size_t)k * kThreads + threadIdx.x;
-        const bool in = a < m;
+        const bool in = (uint32_t)k * kThreads + threadIdx.x < ext.count;
         view[k] = in ? load_view(a) : 0ull;
         slot[k] = kRound0 ? (uint32_t)a : (in ? A.act_slot[a] : 0u);
         edge[k] = 0;
         if (lane == 0 && in && a > 0) edge[k] = load_view(a - 1);
-        if (lane == 63 && a + 1 < m) edge[k] = load_view(a + 1);
+        if (lane == 63 && in && a + 1 < m) edge[k] = load_view(a + 1);
     }
     uint64_t hmask[kFuseItems], kmask[kFuseItems];  // wave-uniform: heads / kept elements of my segment
 #pragma unroll
     for (int k = 0; k < kFuseItems; ++k) {
         const size_t a = tile_base + (size_t)k * kThreads + threadIdx.x;
-        const bool in = a < m;
+        const bool in = (uint32_t)k * kThreads + threadIdx.x < ext.count;
         const uint64_t v = view[k];
         // the element in front: the previous lane's, except for lane 0
         const uint64_t pv = ((uint64_t)lane_prev((uint32_t)(v >> 32), (uint32_t)(edge[k] >> 32)) << 32) |
                             lane_prev((uint32_t)v, (uint32_t)edge[k]);
         const bool head = !in || a == 0 || v != pv;  // "past the end" counts as a head
         // is the element behind me a head?
-        const uint32_t edge_next = (lane == 63 && a + 1 < m) ? (edge[k] != v ? 1u : 0u) : 1u;
+        const uint32_t edge_next = (lane == 63 && in && a + 1 < m) ? (edge[k] != v ? 1u : 0u) : 1u;
         const bool next_head = lane_next(head ? 1u : 0u, edge_next) != 0;
         const bool keep = in && !(head && next_head);
         hmask[k] = __ballot(in && head);
@@ -440,7 +451,7 @@ __global__ __launch_bounds__(kThreads) void regroup_kernel(RegroupArgs A) {
         if (lane == 0) {
             s_excl[0] = xm;
             s_excl[1] = xs;
-            if (tile_base + kFuseTile >= m) *A.d_total = xs + agg_sum;  // the last tile
+            if (tile + 1 == A.num_tiles) *A.d_total = xs + agg_sum;  // the last tile
         }
     }
     __syncthreads();
@@ -449,7 +460,7 @@ __global__ __launch_bounds__(kThreads) void regroup_kernel(RegroupArgs A) {
 #pragma unroll
     for (int k = 0; k < kFuseItems; ++k) {
         const size_t a = tile_base + (size_t)k * kThreads + threadIdx.x;
-        const bool in = a < m;
+        const bool in = (uint32_t)k * kThreads + threadIdx.x < ext.count;
         // slot of my group head: the last head at or in front of me
         const uint64_t mine = hmask[k] & ((2ull << lane) - 1ull);
         const int hl = mine ? 63 - __builtin_clzll(mine) : lane;
@@ -822,12 +833,13 @@ uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *grp, const 
                  uint32_t *new_grp, uint32_t *scratch_idx, uint32_t *scratch_val, uint32_t *rank_val,
                  uint32_t *d_total, uint32_t *lcp = nullptr, int sym_bits = 0, int tag_bits = 0, int bits = 0,
                  const uint32_t *lcp_list = nullptr, int low_bits = 0, uint32_t dbl_h = 0,
-                 uint32_t *rank_by_slot = nullptr, const Pyramid *plcp = nullptr) {
+                 uint32_t *rank_by_slot = nullptr, const Pyramid *plcp = nullptr, const uint32_t *keys32 = nullptr,
+                 const SegView *seg = nullptr) {
     hipStream_t s = ctx.stream;
     const size_t pmark = ctx.arena.mark();
     // doubling boundaries read range minima of the LCP values decided so far
     const Pyramid Plcp = plcp ? *plcp : Pyramid{};
-    const size_t tiles = div_up(m, kFuseTile);
+    const size_t tiles = seg ? seg->num_tiles : div_up(m, kFuseTile);
     uint32_t total[2] = {0, 0};
     {
         const double bytes = kRound0 ? 20.0 * m : 28.0 * m;  // view (+ vals) in, (sa +) rank + lcp out (+ survivors)
@@ -836,7 +848,7 @@ uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *grp, const 
         uint64_t *desc = ctx.arena.alloc<uint64_t>(2 * tiles + 1);
         HIP_CHECK(hipMemsetAsync(desc, 0, (2 * tiles + 1) * sizeof(uint64_t), s));
         RegroupArgs A{};
-        A.keys = keys; A.grp = grp; A.lo = lo; A.vals = vals; A.act_slot = act_slot; A.m = m;
+        A.keys = keys; A.keys32 = keys32; A.seg = seg ? *seg : SegView{}; A.num_tiles = (uint32_t)tiles; A.grp = grp; A.lo = lo; A.vals = vals; A.act_slot = act_slot; A.m = m;
         A.sa = sa; A.rank_val = rank_val; A.rank_by_slot = rank_by_slot; A.lcp = lcp;
         A.sym_bits = sym_bits; A.tag_bits = tag_bits; A.bits = bits; A.low_bits = low_bits;
         A.lcp_list = lcp_list; A.dbl_h = dbl_h; A.Plcp = Plcp;
@@ -991,6 +1003,7 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     uint32_t *scratch_idx = arena.alloc<uint32_t>(n);
     uint32_t *scratch_val = arena.alloc<uint32_t>(n);
     uint32_t *d_total = arena.alloc<uint32_t>(2);
+    uint32_t *seg_mem = arena.alloc<uint32_t>((size_t)kSegDescWords * (div_up(n, kSortTile) + 257));  // 16-byte aligned
     uint32_t *rank = isa;
 
     // ---- round 0: order by the first K symbols -------------------------------------------
@@ -1003,6 +1016,11 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     default: k_syms = KeyLayout<8>::kSyms; break;
     }
     int cur;
+    SegView seg;
+    // (NOLZSS_DNA_FAST_MIN: smallest text that takes the bucketed sort; the tests lower it)
+    static const uint32_t dna_fast_min =
+        getenv("NOLZSS_DNA_FAST_MIN") ? (uint32_t)atoll(getenv("NOLZSS_DNA_FAST_MIN")) : (1u << 20);
+    const bool dna_fast = text.bits == 2 && !text.segmented && n >= dna_fast_min && key_passes == 5;
     {
         // only the low key_bits of the key are populated
         int key_bits = k_syms * text.bits;
@@ -1015,8 +1033,16 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         int shifts0[8], np0 = 0;
         for (int b = 0; b < key_bits && np0 < 8; b += kRadixBits) shifts0[np0++] = b;
         ProfScope ps(ctx.profiler(), "sa_sort_initial", s);
-        cur = radix_sort_initial_keys(text, keys, vals, shifts0, np0, arena, s, ctx.profiler());
-        if (np0 != key_passes || vals[cur] != sa) throw HipError("suffix array: key sort did not end in sa");
+        if (dna_fast) {
+            // plain DNA: partition by the first four bases, then sort the buckets on 8-byte records
+            uint32_t *keys32[2] = {reinterpret_cast<uint32_t *>(keys[0]), reinterpret_cast<uint32_t *>(keys[1])};
+            radix_sort_dna_keys(text, keys32, vals, seg_mem, seg, arena, s, ctx.profiler());
+            cur = 1;
+            if (vals[cur] != sa) throw HipError("suffix array: key sort did not end in sa");
+        } else {
+            cur = radix_sort_initial_keys(text, keys, vals, shifts0, np0, arena, s, ctx.profiler());
+            if (np0 != key_passes || vals[cur] != sa) throw HipError("suffix array: key sort did not end in sa");
+        }
     }
     int tag_bits = 0, low_bits = 0;
     switch (text.bits) {
@@ -1031,7 +1057,9 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     }
     uint32_t m = regroup<true>(ctx, keys[cur], nullptr, nullptr, vals[cur], nullptr, n, n, sa, rank, act_slot[0],
                                act_grp[0], scratch_idx, scratch_val, rank_val, d_total, lcp,
-                               k_syms * text.bits, tag_bits, text.bits, nullptr, low_bits, 0, rank_by_slot);
+                               k_syms * text.bits, tag_bits, text.bits, nullptr, low_bits, 0, rank_by_slot, nullptr,
+                               dna_fast ? reinterpret_cast<const uint32_t *>(keys[cur]) : nullptr,
+                               dna_fast ? &seg : nullptr);
 
     // ---- doubling rounds ------------------------------------------------------------------
     // in the rounds the 8n-byte key buffers are reused as four u32 arrays
