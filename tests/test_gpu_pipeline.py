@@ -136,3 +136,33 @@ def test_many_random_small(native):
         alpha = rng.choice([b"A", b"AC", b"ACGT", b"abcdefghijklmnopqrstuvwxyz"])
         t = bytes(rng.choice(alpha) for _ in range(n))
         assert native.factorize(t) == oracle.factorize(t), t
+
+
+def test_bucketed_key_sort_on_small_texts():
+    """The bucketed (most-significant-digit first) key sort normally starts at 2^20 bases; one child
+    process with NOLZSS_DNA_FAST_MIN=1 runs it on small DNA cases: empty buckets, buckets smaller
+    than a tile, suffixes near the end of the text."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys
+sys.path.insert(0, "tests")
+import numpy as np
+import gen, oracle_lib as oracle
+from nolzss_amd import _noLZSS as native
+cases = [b"ACGT", b"A" * 5000, (b"ACGTTGA" * 2000)[:13001], gen.random_dna(100, 1).tobytes(),
+         gen.random_dna(70_000, 3).tobytes(), gen.repeat_dna(300_000, 5, lo=16, hi=4096).tobytes(),
+         b"AC" * 40000 + b"G", gen.random_dna(3000, 12).tobytes() * 64, b"T" * 4097 + gen.random_dna(5000, 9).tobytes()]
+for t in cases:
+    got = native.factorize_array(t)
+    exp = oracle.factors_array(t)
+    assert len(got) == len(exp), (len(t), len(got), len(exp))
+    for k in ("start", "length", "ref"):
+        assert np.array_equal(got[k], exp[k]), (len(t), k)
+print("ok", len(cases))
+'''
+    env = dict(os.environ, NOLZSS_DNA_FAST_MIN="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
