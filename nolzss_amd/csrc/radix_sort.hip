@@ -62,6 +62,10 @@ template <typename KeyT> struct ArraySrc {
     const uint32_t *__restrict__ vals;
     __device__ __forceinline__ KeyT key(size_t idx) const { return keys[idx]; }
     __device__ __forceinline__ uint32_t val(size_t idx) const { return vals[idx]; }
+    // histogram passes: what to load, and the digit of what was loaded (kept apart so that all loads
+    // of a tile are issued before the first digit is needed)
+    __device__ __forceinline__ KeyT hist_raw(size_t idx, int) const { return keys[idx]; }
+    __device__ __forceinline__ uint32_t hist_digit(KeyT raw, int shift) const { return digit_of(raw, shift); }
 };
 template <int BITS> struct TextSrc {
     const uint64_t *__restrict__ words;
@@ -71,6 +75,14 @@ template <int BITS> struct TextSrc {
         return initial_key<BITS>(words, terms, segmented, (uint32_t)idx);
     }
     __device__ __forceinline__ uint32_t val(size_t idx) const { return (uint32_t)idx; }
+    // histogram passes only need the digit; the top 8 bits of a plain key are the first 8 / BITS
+    // symbols, straight from the packed text (no length tag, no terminator search)
+    __device__ __forceinline__ uint64_t hist_raw(size_t idx, int shift) const {
+        constexpr int kKeyBits = KeyLayout<BITS>::kSyms * BITS + KeyLayout<BITS>::kTagBits;
+        if (!segmented && shift == kKeyBits - kRadixBits) return sym_word<BITS>(words, idx) >> (64 - kKeyBits);
+        return key(idx);
+    }
+    __device__ __forceinline__ uint32_t hist_digit(uint64_t raw, int shift) const { return digit_of(raw, shift); }
 };
 
 template <typename KeyT, typename Src>
@@ -86,12 +98,12 @@ __global__ __launch_bounds__(kThreads) void rs_hist_kernel(Src src, size_t n, in
 #pragma unroll
     for (int j = 0; j < kKeysPerThread; ++j) {
         const uint32_t local = (uint32_t)j * kThreads + threadIdx.x;
-        k[j] = local < ext.count ? src.key(ext.first + local) : KeyT(0);
+        k[j] = local < ext.count ? (KeyT)src.hist_raw(ext.first + local, shift) : KeyT(0);
     }
 #pragma unroll
     for (int j = 0; j < kKeysPerThread; ++j) {
         const uint32_t local = (uint32_t)j * kThreads + threadIdx.x;
-        if (local < ext.count) atomicAdd(&hist[digit_of(k[j], shift)], 1u);
+        if (local < ext.count) atomicAdd(&hist[src.hist_digit(k[j], shift)], 1u);
     }
     __syncthreads();
     tile_hist[ext.hist0 + (size_t)threadIdx.x * ext.hstride] = hist[threadIdx.x];
