@@ -115,7 +115,7 @@ size_t run_plain(Context &ctx, const uint8_t *d_text, size_t n, size_t start_pos
     build_lstar(ctx, (uint32_t)n, sa, isa, lcp, Psa, Plcp, lstar);
     if (dbg) {
         copy_out(ctx, dbg->sa, sa, n);
-        copy_out(ctx, dbg->isa, isa, n);
+        copy_out(ctx, dbg->isa, isa, n);  // (1-based on the device; nolzss_debug_arrays subtracts the one)
         copy_out(ctx, dbg->lcp, lcp, n + 1);
         copy_out(ctx, dbg->lstar, lstar, n);
     }
@@ -1188,6 +1188,9 @@ int nolzss_debug_arrays(const uint8_t *text, size_t n, int device, uint32_t *sa,
         dbg.lcp = lcp;
         dbg.lstar = lstar;
         run_plain_host(ses.ctx(), text, n, 0, nullptr, &dbg);
+        HIP_CHECK(hipStreamSynchronize(ses.ctx().stream));
+        if (isa)
+            for (size_t i = 0; i < n; ++i) isa[i] -= 1u;  // the device array holds rank + 1
     });
 }
 

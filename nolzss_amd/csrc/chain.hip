@@ -281,7 +281,7 @@ __global__ __launch_bounds__(kThreads) void factor_kernel(const uint32_t *__rest
             f.length = 1;
             f.ref = i;
         } else {
-            const uint32_t r = isa[i];
+            const uint32_t r = isa[i] - 1u;  // (1-based, pipeline.hpp)
             uint32_t lo = r, hi = r + 1, steps = 0;
             while (lcp[lo] >= L) {  // lcp[0] = 0 stops the scan
                 --lo;

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(kThreads) void lpnf_fallback_kernel(const uint32_t 
     for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < count; k += stride) {
         const uint32_t i = queue[k];
         const uint32_t cap = (n - i) < i ? (n - i) : i;  // L* <= i - j <= i and L* <= n - i
-        lstar[i] = lpnf_search(Psa, Plcp, isa[i], i, lstar[i], cap);  // P(lstar[i]) holds on entry
+        lstar[i] = lpnf_search(Psa, Plcp, isa[i] - 1u, i, lstar[i], cap);  // P(lstar[i]) holds on entry
     }
 }
 

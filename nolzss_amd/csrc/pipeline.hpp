@@ -24,7 +24,7 @@ struct Context {
 PackedText pack_text(Context &ctx, const uint8_t *d_text, size_t n);
 
 // ---- stages 2+3: suffix array (prefix doubling over radix sorts) and LCP array -------------
-// sa[r] = start of the r-th smallest suffix, isa[i] = rank of suffix i (n u32 each);
+// sa[r] = start of the r-th smallest suffix, isa[i] = rank of suffix i PLUS ONE (n u32 each);
 // lcp[0] = 0, lcp[r] = lcp(suffix sa[r-1], suffix sa[r]), lcp[n] = 0 (n + 1 u32).  All
 // caller-allocated.  LCP entries between suffixes that round 0 already separates come straight
 // from the sort keys; only the others compare packed text.  Returns the doubling rounds run.

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(kThreads) void rc_fallback_kernel(const uint32_t *_
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < count; k += stride) {
         const uint32_t i = queue[k];
-        const uint32_t r = isa[i];
+        const uint32_t r = isa[i] - 1u;  // (1-based, pipeline.hpp)
         const uint32_t cap = (m - i) < i ? (m - i) : i;
         const uint32_t Lf = lpnf_search(Pmin, Plcp, r, i, code[i], cap);  // >= 1 for queued positions
         // deepest explicit ancestor of leaf(i) with depth <= L_f
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(kThreads) void rc_fallback_kernel(const uint32_t *_
         }
         lcp_interval(Plcp, r, d_u, a, b);
         const uint32_t j = pyr_range<false>(Pmin, a, b);  // best_fwd_start (:284)
-        const uint32_t rj = isa[j];
+        const uint32_t rj = isa[j] - 1u;
         const uint32_t x = r < rj ? r : rj, y = r < rj ? rj : r;
         const uint32_t l = pyr_range<false>(Plcp, x + 1, y);  // lcp(cst, i, best_fwd_start) (:324)
         const uint32_t fwd = l < i - j ? l : i - j;           // :323-325

@@ -821,11 +821,6 @@ __global__ __launch_bounds__(kThreads) void scatter_large_kernel(const uint64_t 
     }
 }
 
-__global__ __launch_bounds__(kThreads) void rank_to_isa_kernel(uint32_t *__restrict__ rank, uint32_t n) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) rank[i] -= 1u;
-}
-
 // shared tail of every round: sorted view of m active elements -> sa / rank / next active list
 template <bool kRound0>
 uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *grp, const uint32_t *lo, uint32_t *vals,
@@ -1173,11 +1168,8 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         h *= 2;
         ++rounds;
     }
-    {
-        ProfScope ps(ctx.profiler(), "sa_rank_to_isa", s);
-        rank_to_isa_kernel<<<grid_for(n, kThreads), kThreads, 0, s>>>(rank, n);
-        KERNEL_CHECK();
-    }
+    // (rank[] stays 1-based: every group is a singleton now, so rank[i] = ISA[i] + 1; the consumers
+    // subtract the one instead of a pass over the array doing it)
     {
         ProfScope ps(ctx.profiler(), "lcp_finish", s);
         const unsigned g = grid_for((size_t)n + 1, kThreads, 256u * 32u);
