@@ -25,6 +25,7 @@ namespace nolzss {
 namespace {
 
 constexpr int kThreads = 256;
+constexpr uint32_t kFarBothUnknown = 0xfffffffeu;  // far_aux: neither direction ended inside the tile
 
 // turn the two neighbour candidates into L*[i], or queue i for the exact search
 // (*dst receives L*[i] or, for queued positions, a lower bound with P(bound) true)
@@ -55,7 +56,8 @@ __global__ __launch_bounds__(kLdsThreads) void lpf_tile_kernel(const uint32_t *_
                                                                uint32_t *__restrict__ queue,
                                                                uint32_t *__restrict__ queue_count,
                                                                uint32_t *__restrict__ far_queue,
-                                                               uint32_t *__restrict__ far_count) {
+                                                               uint32_t *__restrict__ far_count,
+                                                               uint32_t *__restrict__ far_aux) {
     constexpr int NS = 2;
     __shared__ uint32_t s_sa[kLdsSpan];
     __shared__ uint32_t s_lcp[kLdsSpan + 1];
@@ -97,7 +99,18 @@ __global__ __launch_bounds__(kLdsThreads) void lpf_tile_kernel(const uint32_t *_
         far_base += (uint32_t)__popcll(far_mask[row]);
         if (rr >= n) continue;
         if (far) {
-            lstar_by_rank[rr] = 0;  // finished from global memory by lpf_far_kernel
+            // finished from global memory by lpf_far_kernel; what the direction that did end inside
+            // the tile found travels along (length in the by-rank slot, position + side in far_aux)
+            const uint32_t up = s_len[t], down = s_len[kLdsTile + t];
+            const bool fu = far_is(up, far_bit), fd = far_is(down, far_bit);
+            uint32_t known_len = 0, aux = kFarBothUnknown;
+            if (far_bit && fu != fd) {
+                known_len = fu ? down : up;
+                const uint32_t p = fu ? s_pos[kLdsTile + t] : s_pos[t];
+                aux = (known_len ? (p & 0x7fffffffu) : 0x7fffffffu) | (fu ? 0x80000000u : 0u);
+            }
+            lstar_by_rank[rr] = known_len;
+            far_aux[rr] = aux;
             continue;
         }
         lpf_decide(s_sa[t + kLdsReach], s_len[t], s_pos[t], s_len[kLdsTile + t], s_pos[kLdsTile + t],
@@ -105,11 +118,43 @@ __global__ __launch_bounds__(kLdsThreads) void lpf_tile_kernel(const uint32_t *_
     }
 }
 
+constexpr uint32_t kFarCleared = 252;  // ranks a search has passed before it is marked far (nearest_lds.hpp)
+
+// One direction of a far search: nothing qualifies within kFarCleared ranks, so the pyramids take
+// over right there (no neighbour-by-neighbour prologue).
+__device__ __forceinline__ void far_up(const uint32_t *__restrict__ sa, const Pyramid &Psa, const Pyramid &Plcp,
+                                       uint32_t r, uint32_t x, uint32_t floor, uint32_t &len, uint32_t &pos) {
+    len = 0;
+    pos = kNoPos;
+    if (r <= kFarCleared) return;
+    const int64_t q = pyr_nearest_left<false>(Psa, r - kFarCleared - 1, x);
+    if (q < 0) return;
+    const uint32_t m = pyr_range<false>(Plcp, (uint32_t)q + 1, r);
+    if (m == 0 || m < floor) return;
+    len = m;
+    pos = sa[q];
+}
+__device__ __forceinline__ void far_down(const uint32_t *__restrict__ sa, uint32_t n, const Pyramid &Psa,
+                                         const Pyramid &Plcp, uint32_t r, uint32_t x, uint32_t floor, uint32_t &len,
+                                         uint32_t &pos) {
+    len = 0;
+    pos = kNoPos;
+    if ((uint64_t)r + kFarCleared + 1 >= n) return;
+    const uint32_t q = pyr_nearest_right<false>(Psa, r + kFarCleared + 1, x);
+    if (q >= n) return;
+    const uint32_t m = pyr_range<false>(Plcp, r + 1, q);
+    if (m == 0 || m < floor) return;
+    len = m;
+    pos = sa[q];
+}
+
 // ranks whose nearest earlier suffix lies outside the LDS reach: pyramid search
 __global__ __launch_bounds__(kThreads) void lpf_far_kernel(const uint32_t *__restrict__ far_queue, uint32_t count,
                                                            const uint32_t *__restrict__ sa,
                                                            const uint32_t *__restrict__ lcp, uint32_t n,
                                                            Pyramid Psa, Pyramid Plcp,
+                                                           const uint32_t *__restrict__ by_rank,
+                                                           const uint32_t *__restrict__ far_aux, bool bounded,
                                                            uint32_t *__restrict__ lstar,
                                                            uint32_t *__restrict__ queue,
                                                            uint32_t *__restrict__ queue_count) {
@@ -117,9 +162,23 @@ __global__ __launch_bounds__(kThreads) void lpf_far_kernel(const uint32_t *__res
     for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < count; k += stride) {
         const uint32_t r = far_queue[k];
         const uint32_t i = sa[r];
+        const uint32_t aux = far_aux[r];
         uint32_t lp, jp, ls, js;
-        nearest_up<false>(sa, lcp, Psa, Plcp, r, i, 0u, lp, jp);
-        nearest_down<false>(sa, lcp, n, Psa, Plcp, r, i, lp, ls, js);  // cannot beat lp below lp
+        if (!bounded) {  // (texts beyond 2^31 symbols: no bounds were kept)
+            nearest_up<false>(sa, lcp, Psa, Plcp, r, i, 0u, lp, jp);
+            nearest_down<false>(sa, lcp, n, Psa, Plcp, r, i, lp, ls, js);  // cannot beat lp below lp
+        } else if (aux == kFarBothUnknown) {
+            far_up(sa, Psa, Plcp, r, i, 0u, lp, jp);
+            far_down(sa, n, Psa, Plcp, r, i, lp, ls, js);
+        } else if (aux >> 31) {  // the search towards larger ranks ended inside the tile
+            ls = by_rank[r];
+            js = (aux & 0x7fffffffu) == 0x7fffffffu ? kNoPos : (aux & 0x7fffffffu);
+            far_up(sa, Psa, Plcp, r, i, ls, lp, jp);
+        } else {
+            lp = by_rank[r];
+            jp = (aux & 0x7fffffffu) == 0x7fffffffu ? kNoPos : (aux & 0x7fffffffu);
+            far_down(sa, n, Psa, Plcp, r, i, lp, ls, js);
+        }
         lpf_decide(i, lp, jp, ls, js, lstar + i, queue, queue_count);
     }
 }
@@ -147,13 +206,14 @@ uint32_t build_lstar(Context &ctx, uint32_t n, const uint32_t *sa, const uint32_
     uint32_t *far_queue = ctx.arena.alloc<uint32_t>(n);
     uint32_t *counts = ctx.arena.alloc<uint32_t>(2);  // [0] exact-search queue, [1] far queue
     uint32_t *by_rank = ctx.arena.alloc<uint32_t>(n);
+    uint32_t *far_aux = ctx.arena.alloc<uint32_t>(n);
     uint32_t *scratch_idx = ctx.arena.alloc<uint32_t>(n);
     uint32_t *scratch_val = ctx.arena.alloc<uint32_t>(n);
     HIP_CHECK(hipMemsetAsync(counts, 0, 2 * sizeof(uint32_t), s));
     {
         ProfScope ps(ctx.profiler(), "lpf", s, 12.0 * (double)n);
         lpf_tile_kernel<<<(unsigned)div_up(n, kLdsTile), kLdsThreads, 0, s>>>(sa, lcp, n, by_rank, queue, counts,
-                                                                          far_queue, counts + 1);
+                                                                          far_queue, counts + 1, far_aux);
         KERNEL_CHECK();
     }
     {
@@ -171,7 +231,8 @@ uint32_t build_lstar(Context &ctx, uint32_t n, const uint32_t *sa, const uint32_
         ProfScope ps(ctx.profiler(), "lpf_far", s);
         size_t g = div_up(h[1], kThreads);
         if (g > 256u * 32u) g = 256u * 32u;
-        lpf_far_kernel<<<(unsigned)g, kThreads, 0, s>>>(far_queue, h[1], sa, lcp, n, Psa, Plcp, lstar, queue, counts);
+        lpf_far_kernel<<<(unsigned)g, kThreads, 0, s>>>(far_queue, h[1], sa, lcp, n, Psa, Plcp, by_rank, far_aux,
+                                                        n <= 0x80000000u, lstar, queue, counts);
         KERNEL_CHECK();
         ctx.read_back(counts, h, 1);
     }
