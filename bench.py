@@ -44,7 +44,9 @@ def measured_traffic_ratio():
     None if the profile summary is not there."""
     try:
         with open(ROOT / "profiles" / "r01_pmc_radix_traffic.json") as f:
-            return float(json.load(f)["rs_scatter_kernel<u64>"]["traffic_over_algorithmic"])
+            d = json.load(f)
+            cur = d.get("rs_scatter_kernel<u32,u32> at 2^30 pairs (current pipeline)")  # the dominant instantiation
+            return float((cur or d["rs_scatter_kernel<u64>"])["traffic_over_algorithmic"])
     except Exception:
         return None
 
@@ -170,7 +172,7 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (ratio * nbytes / cnt) if (ratio and cnt) else None,
                          "traffic_source": "profiles/r01_pmc_radix_traffic.json (rocprofv3 --pmc FETCH_SIZE / "
-                                           "WRITE_SIZE, separate passes): HBM bytes = 1.02 x algorithmic bytes",
+                                           "WRITE_SIZE, separate passes): HBM bytes = 1.02 x algorithmic bytes, u32 passes at 2^30 pairs",
                          "launches": cnt,
                          "avg_launch_ms": (ms / cnt) if cnt else None,
                          "algorithmic_bytes_per_launch": (nbytes / cnt) if cnt else None},
