@@ -5,14 +5,17 @@
 // distance to that rank is heavy-tailed (P(distance > k) ~ 1/(k+1) on random data), so a
 // lock-step scan makes every wavefront pay for its slowest lane.
 //
-// Scheme (per wavefront, no workgroup barriers after staging):
+// Scheme (per wavefront, no workgroup barriers after staging -- shared work lists with a barrier
+// per round were tried and lose: independent waves hide each other's LDS latency):
 //   * the workgroup stages kLdsTile ranks of SA and LCP plus a halo of kLdsReach on both sides;
-//   * round 0: every lane advances each of its searches by 8 steps, branch-free;
+//   * round 0: every lane advances each of its searches by 4 steps, branch-free (ends 4 of 5);
 //   * unfinished searches are compacted (ballot + popcount) into a per-wave work list in LDS
-//     and the wave keeps taking 64 list items at a time, 8 more steps each, until the list is
-//     empty: all lanes stay busy, total work ~ n * H(reach) instead of n * reach;
-//   * a search that leaves the reach is marked FAR and the rank is finished from global memory
-//     with the pyramids (nearest.hpp) by a separate compacted kernel.
+//     and the wave keeps taking 64 list items at a time, 8 more steps each, while the list holds
+//     more than 24 items: total work ~ n * H(reach) instead of n * reach;
+//   * the last items, each about as far from done as it has come, go to the four 16-lane rows of
+//     the wave, one search per row, a row-wide DPP prefix minimum per iteration;
+//   * a search that leaves the reach keeps its running LCP minimum as a bound (far_mark): the rank
+//     is finished from global memory with the pyramids only if that bound can still win.
 #pragma once
 #include "nearest.hpp"
 

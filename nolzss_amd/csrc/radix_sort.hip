@@ -4,18 +4,23 @@
 //   rs_hist_kernel     per 4096-key tile, a 256-bin digit histogram (LDS atomics) written
 //                      bin-major, so one linear exclusive scan yields every (bin, tile) base;
 //   scan               exclusive add-scan of the 256 x num_tiles table (scan.hip);
-//   rs_scatter_kernel  re-reads the tile, ranks every key inside its wavefront with
-//                      ballot-based peer matching (64-lane match-any over the 8 digit bits),
+//   rs_scatter_kernel  loads the whole tile (all loads in flight before anything else), ranks
+//                      every key inside its wavefront -- 8 ballots give the lanes with the same
+//                      digit, the first lane of each digit group does one returning LDS atomic on
+//                      the wave's counter, the atomics of all 16 rows are issued back to back --
 //                      sorts the tile by digit through LDS, and writes each bin's run with
 //                      consecutive lanes on consecutive addresses.
+// The pairs of a pass come from arrays or (first pass of the suffix sort) are computed from the
+// packed text; passes can be SEGMENTED: tiles that never straddle one of 256 buckets made by an
+// earlier most-significant-digit pass (radix_sort.hpp, SegView), which is how plain DNA is sorted
+// on 8-byte records.
 // HBM-bound: algorithmic traffic of the scatter kernel = 2 * (sizeof(key) + 4) bytes per pair;
-// the histogram kernel reads sizeof(key) bytes per pair.
+// the histogram kernel reads sizeof(key) bytes per pair.  4.0-4.8 TB/s on MI355X (u32 keys).
 //
 // Occupancy is what the scatter kernel lives on: keys and values take turns in ONE LDS staging
-// buffer (37 KiB per workgroup -> 4 workgroups = 16 waves per CU), which took it from 2.0 to
-// 3.3 TB/s algorithmic on MI355X.  Tiles are dealt to XCDs in contiguous ranges (blockIdx % 8
+// buffer (37 KiB per workgroup).  Tiles are dealt to XCDs in contiguous ranges (blockIdx % 8
 // shares an XCD) so that the bin runs of neighbouring tiles, adjacent in the output, meet in one
-// L2 and their partial cache lines merge there (+10 %).
+// L2 and their partial cache lines merge there: without it the scatter runs at HALF the speed.
 #include "radix_sort.hpp"
 
 #include "scan.hpp"

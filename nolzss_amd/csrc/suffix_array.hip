@@ -3,11 +3,17 @@
 // Replaces the SA/CSA part of sdsl::construct_im(cst, text, 1) that the reference calls at
 // /root/reference/src/cpp/factorizer.cpp:340,381 and factorizer_core.hpp:208.
 //
-// Method: prefix doubling with active-set filtering, every ordering step a device radix sort.
-//   round 0   key(i) = first K symbols of suffix i (bit-packed, K = 29 for 2-bit DNA) plus a
-//             length tag; one 8-pass radix sort of (key, i) orders all suffixes by K symbols.
-//   round h   only suffixes whose h-group is not yet a singleton stay active (compacted list);
-//             key = (group head rank, rank[i + h]); radix sort of the active pairs; regroup.
+// Method: a key sort, ONE direct-comparison round, then prefix doubling for what is left.
+//   round 0   key(i) = first K symbols of suffix i (bit-packed, K = 17 for 2-bit DNA) plus a
+//             length tag; the keys are computed inside the first radix pass (radix_sort.hip: one
+//             most-significant-digit pass + four bucket-segmented passes on 8-byte records for
+//             plain DNA, 5-8 passes on 12-byte records otherwise); the last pass lands in SA.
+//   regroup   one single-pass kernel per round (decoupled look-back): group heads, ranks, LCP
+//             of every boundary that appeared, compacted list of the suffixes still tied.
+//   direct    every group of <= 64 suffixes is finished by comparing the packed suffixes
+//             themselves, 512 bits per step, pair by pair through LDS (group_refine_kernel).
+//   round h   only suffixes whose group is not yet a singleton stay active; key = (group head
+//             rank, rank[i + h]); small groups sorted by counting, large ones by radix sort.
 // All arrays are 32-bit; rank[i] holds (index of the first slot of i's group) + 1, and 0 means
 // "past the end of the text", which sorts before every real suffix exactly as the reference's
 // appended terminator does.
