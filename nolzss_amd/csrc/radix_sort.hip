@@ -76,6 +76,7 @@ template <int BITS> struct TextSrc {
     const uint64_t *__restrict__ words;
     TermTable terms;
     bool segmented;
+    bool digit_from_text = true;  // MSD histogram digit straight from the packed text (no terminators in the text)
     __device__ __forceinline__ uint64_t key(size_t idx) const {
         return initial_key<BITS>(words, terms, segmented, (uint32_t)idx);
     }
@@ -84,7 +85,8 @@ template <int BITS> struct TextSrc {
     // symbols, straight from the packed text (no length tag, no terminator search)
     __device__ __forceinline__ uint64_t hist_raw(size_t idx, int shift) const {
         constexpr int kKeyBits = KeyLayout<BITS>::kSyms * BITS + KeyLayout<BITS>::kTagBits;
-        if (!segmented && shift == kKeyBits - kRadixBits) return sym_word<BITS>(words, idx) >> (64 - kKeyBits);
+        if (!segmented && digit_from_text && shift == kKeyBits - kRadixBits)
+            return sym_word<BITS>(words, idx) >> (64 - kKeyBits);
         return key(idx);
     }
     __device__ __forceinline__ uint32_t hist_digit(uint64_t raw, int shift) const { return digit_of(raw, shift); }
@@ -453,7 +455,7 @@ __global__ __launch_bounds__(kThreads) void seg_desc_kernel(const uint32_t *__re
 void radix_sort_dna_keys(const PackedText &text, uint32_t *keys32[2], uint32_t *vals[2], uint32_t *seg_mem,
                          SegView &seg_out, Arena &arena, hipStream_t stream, Profiler *prof) {
     const size_t n = text.n;
-    if (text.bits != 2 || text.segmented) throw HipError("radix_sort_dna_keys: plain 2-bit texts only");
+    if (text.bits != 2) throw HipError("radix_sort_dna_keys: 2-bit texts only");
     const size_t m = arena.mark();
     const uint32_t tiles0 = (uint32_t)div_up(n, kTile);
     uint32_t *hist = arena.alloc<uint32_t>((size_t)kBins * ((size_t)tiles0 + kBins));
@@ -461,7 +463,8 @@ void radix_sort_dna_keys(const PackedText &text, uint32_t *keys32[2], uint32_t *
     uint32_t *bstart = tabs, *tile0 = tabs + 257, *prev_ne = tabs + 2 * 257, *next_ne = tabs + 3 * 257;
     const double text_bytes = (double)n * 2 / 8.0;
     // most significant digit first: key bits 32..39 = the first four bases
-    radix_pass<uint64_t, uint32_t>(TextSrc<2>{text.words, text.terms, false}, keys32[1], vals[1], n, 32, hist, tiles0,
+    // (the plain key layout for segmented texts too; their histogram digits need the masked key)
+    radix_pass<uint64_t, uint32_t>(TextSrc<2>{text.words, text.terms, false, !text.segmented}, keys32[1], vals[1], n, 32, hist, tiles0,
                                    text_bytes, text_bytes + 8.0 * (double)n, arena, stream, prof);
     bucket_starts_kernel<<<1, kBins, 0, stream>>>(hist, tiles0, (uint32_t)n, bstart);
     KERNEL_CHECK();

@@ -295,6 +295,7 @@ struct RegroupArgs {
     const uint32_t *keys32;   // ... or their low halves, the top byte implied by the bucket (seg)
     SegView seg;
     uint32_t num_tiles;
+    uint32_t short_tag;       // round 0: elements whose length tag is below this are groups of their own
     const uint32_t *grp;      // later rounds: (group head slot, secondary key) per list element
     const uint32_t *lo;
     const uint32_t *vals;     // suffix start per element
@@ -377,7 +378,10 @@ __global__ __launch_bounds__(kThreads) void regroup_kernel(RegroupArgs A) {
         // the element in front: the previous lane's, except for lane 0
         const uint64_t pv = ((uint64_t)lane_prev((uint32_t)(v >> 32), (uint32_t)(edge[k] >> 32)) << 32) |
                             lane_prev((uint32_t)v, (uint32_t)edge[k]);
-        const bool head = !in || a == 0 || v != pv;  // "past the end" counts as a head
+        bool head = !in || a == 0 || v != pv;  // "past the end" counts as a head
+        // a suffix that meets a terminator inside the key window ties only with copies of itself at
+        // other terminators, and the stable sort has left those in their final order
+        if (kRound0 && A.short_tag) head = head || ((uint32_t)(v >> A.low_bits) & ((1u << A.tag_bits) - 1u)) < A.short_tag;
         // is the element behind me a head?
         const uint32_t edge_next = (lane == 63 && in && a + 1 < m) ? (edge[k] != v ? 1u : 0u) : 1u;
         const bool next_head = lane_next(head ? 1u : 0u, edge_next) != 0;
@@ -835,7 +839,7 @@ uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *grp, const 
                  uint32_t *d_total, uint32_t *lcp = nullptr, int sym_bits = 0, int tag_bits = 0, int bits = 0,
                  const uint32_t *lcp_list = nullptr, int low_bits = 0, uint32_t dbl_h = 0,
                  uint32_t *rank_by_slot = nullptr, const Pyramid *plcp = nullptr, const uint32_t *keys32 = nullptr,
-                 const SegView *seg = nullptr) {
+                 const SegView *seg = nullptr, uint32_t short_tag = 0) {
     hipStream_t s = ctx.stream;
     const size_t pmark = ctx.arena.mark();
     // doubling boundaries read range minima of the LCP values decided so far
@@ -849,6 +853,7 @@ uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *grp, const 
         uint64_t *desc = ctx.arena.alloc<uint64_t>(2 * tiles + 1);
         HIP_CHECK(hipMemsetAsync(desc, 0, (2 * tiles + 1) * sizeof(uint64_t), s));
         RegroupArgs A{};
+        A.short_tag = short_tag;
         A.keys = keys; A.keys32 = keys32; A.seg = seg ? *seg : SegView{}; A.num_tiles = (uint32_t)tiles; A.grp = grp; A.lo = lo; A.vals = vals; A.act_slot = act_slot; A.m = m;
         A.sa = sa; A.rank_val = rank_val; A.rank_by_slot = rank_by_slot; A.lcp = lcp;
         A.sym_bits = sym_bits; A.tag_bits = tag_bits; A.bits = bits; A.low_bits = low_bits;
@@ -982,9 +987,18 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
 
     uint64_t *keys[2] = {arena.alloc<uint64_t>(n), arena.alloc<uint64_t>(n)};
     // The value buffers of the key sort: the one the last pass lands in IS sa (no copy afterwards).
+    // (NOLZSS_DNA_FAST_MIN: smallest text that takes the bucketed sort; the tests lower it)
+    static const uint32_t dna_fast_min =
+        getenv("NOLZSS_DNA_FAST_MIN") ? (uint32_t)atoll(getenv("NOLZSS_DNA_FAST_MIN")) : (1u << 20);
+    // 2-bit texts, segmented or not, sort on the plain 40-bit key [17 bases][6-bit tag]: suffixes that
+    // meet a terminator inside the key window and tie on the key are already in their final order
+    // after the (stable) sort -- ascending start = ascending terminator -- and the regroup kernel
+    // makes each of them a group of its own.
+    const bool dna_fast = text.bits == 2 && n >= dna_fast_min;
     int key_passes = 0;
     {
-        int kb = text.segmented ? kSegSyms * 2 + kSegTagBits + kSegTermBits
+        int kb = dna_fast ? KeyLayout<2>::kSyms * 2 + KeyLayout<2>::kTagBits
+                 : text.segmented ? kSegSyms * 2 + kSegTagBits + kSegTermBits
                  : text.bits == 2 ? KeyLayout<2>::kSyms * 2 + KeyLayout<2>::kTagBits
                  : text.bits == 4 ? KeyLayout<4>::kSyms * 4 + KeyLayout<4>::kTagBits
                                   : KeyLayout<8>::kSyms * 8 + KeyLayout<8>::kTagBits;
@@ -1018,10 +1032,6 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     }
     int cur;
     SegView seg;
-    // (NOLZSS_DNA_FAST_MIN: smallest text that takes the bucketed sort; the tests lower it)
-    static const uint32_t dna_fast_min =
-        getenv("NOLZSS_DNA_FAST_MIN") ? (uint32_t)atoll(getenv("NOLZSS_DNA_FAST_MIN")) : (1u << 20);
-    const bool dna_fast = text.bits == 2 && !text.segmented && n >= dna_fast_min && key_passes == 5;
     {
         // only the low key_bits of the key are populated
         int key_bits = k_syms * text.bits;
@@ -1051,7 +1061,7 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     case 4: tag_bits = KeyLayout<4>::kTagBits; break;
     default: tag_bits = KeyLayout<8>::kTagBits; break;
     }
-    if (text.segmented) {  // [kSegSyms symbols][5-bit tag][8-bit terminator index]
+    if (text.segmented && !dna_fast) {  // [kSegSyms symbols][5-bit tag][8-bit terminator index]
         k_syms = kSegSyms;
         tag_bits = kSegTagBits;
         low_bits = kSegTermBits;
@@ -1060,7 +1070,7 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
                                act_grp[0], scratch_idx, scratch_val, rank_val, d_total, lcp,
                                k_syms * text.bits, tag_bits, text.bits, nullptr, low_bits, 0, rank_by_slot, nullptr,
                                dna_fast ? reinterpret_cast<const uint32_t *>(keys[cur]) : nullptr,
-                               dna_fast ? &seg : nullptr);
+                               dna_fast ? &seg : nullptr, dna_fast ? (uint32_t)k_syms : 0u);
 
     // ---- doubling rounds ------------------------------------------------------------------
     // in the rounds the 8n-byte key buffers are reused as four u32 arrays

@@ -148,8 +148,11 @@ __device__ __forceinline__ uint64_t initial_key(const uint64_t *__restrict__ wor
     }
     constexpr int K = KeyLayout<BITS>::kSyms;
     constexpr int TAG = KeyLayout<BITS>::kTagBits;
-    const uint64_t tag = lim < (uint32_t)K ? lim : (uint32_t)K;
-    return ((w >> (64 - K * BITS)) << TAG) | tag;
+    const uint32_t tag = lim < (uint32_t)K ? lim : (uint32_t)K;
+    uint64_t sym = w >> (64 - K * BITS);
+    // symbols behind a terminator belong to the next segment (zero behind the end of the text)
+    if (tag < (uint32_t)K) sym &= ~((1ull << (BITS * (K - (int)tag))) - 1ull);
+    return (sym << TAG) | tag;
 }
 
 }  // namespace nolzss
