@@ -115,7 +115,10 @@ __global__ __launch_bounds__(kThreads) void pack_kernel(const uint8_t *__restric
         int c = 0;
         for (int k = 0; k < (b >> 6); ++k) c += __popcll(presence[k]);
         c += __popcll(presence[b >> 6] & ((1ull << (b & 63)) - 1ull));
-        lut[b] = (uint8_t)c;
+        // bytes outside the alphabet (the unique terminators of a segmented text, which may lie above
+        // 'T') pack as code 0: their rank would not fit the symbol width and spill into the
+        // neighbouring base
+        lut[b] = ((presence[b >> 6] >> (b & 63)) & 1ull) ? (uint8_t)c : (uint8_t)0;
     }
     __syncthreads();
     const bool aligned = ((uintptr_t)text & 15) == 0;

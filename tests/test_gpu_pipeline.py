@@ -160,6 +160,21 @@ for t in cases:
     assert len(got) == len(exp), (len(t), len(got), len(exp))
     for k in ("start", "length", "ref"):
         assert np.array_equal(got[k], exp[k]), (len(t), k)
+# segmented texts on the same sort: many sequences with IDENTICAL ends (copies of a short suffix at
+# up to 124 terminators tie on the key and must come out in terminator order), reverse complement
+import random
+rng = random.Random(3)
+tail = "ACGTTGCAAGGCTA"
+groups = [["ACGT" * 3 + tail] * 40,
+          ["".join(rng.choice("ACGT") for _ in range(rng.randint(1, 60))) + tail[-rng.randint(1, 14):] for _ in range(62)],
+          ["A", "A", "AA", "AAA", "C", "CA", "AAAA"] * 8,
+          ["".join(rng.choice("ACGT") for _ in range(300)) for _ in range(5)]]
+for seqs in groups:
+    S, orig, sent = native.prepare_multiple_dna_sequences_w_rc_bytes(seqs)
+    assert native.factorize_multiple_dna_w_rc(S) == oracle.factorize_multiple_dna_w_rc(S), len(seqs)
+    S2, orig2, sent2 = native.prepare_multiple_dna_sequences_no_rc_bytes(seqs) if hasattr(native, "prepare_multiple_dna_sequences_no_rc_bytes") else (None, None, None)
+    if S2 is not None:
+        assert native.factorize(S2) == oracle.factorize(S2), len(seqs)
 print("ok", len(cases))
 '''
     env = dict(os.environ, NOLZSS_DNA_FAST_MIN="1")

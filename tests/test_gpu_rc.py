@@ -128,3 +128,31 @@ def test_rc_guards(native):
         native.factorize_multiple_dna_w_rc_array(S, start_pos=8)
     with pytest.raises(RuntimeError):
         native.factorize_dna_w_rc(b"ACGN")
+
+
+@pytest.mark.parametrize("k", [41, 62, 100, 125])
+def test_rc_many_sequences_up_to_the_limit(native, k):
+    """More than 40 sequences put sentinel bytes above 'T' into the prepared string (up to 250
+    sentinels at the limit of 125 sequences); sequences share their last bases, so copies of one
+    short suffix sit at many terminators."""
+    rng = random.Random(100 + k)
+    tail = "ACGTTGCAAGGCTA"
+    seqs = ["".join(rng.choice("ACGT") for _ in range(rng.randint(1, 80))) + tail[-rng.randint(1, 14):]
+            for _ in range(k)]
+    S, orig, sent = native.prepare_multiple_dna_sequences_w_rc_bytes(seqs)
+    S2, orig2, sent2 = oracle.prepare_multiple_dna_w_rc(seqs)
+    assert (S, orig, sent) == (S2, orig2, sent2)
+    assert max(S) > ord("T")
+    assert native.factorize_multiple_dna_w_rc(S) == oracle.factorize_multiple_dna_w_rc(S)
+    assert native.count_factors_multiple_dna_w_rc(S) == oracle.count_factors_multiple_dna_w_rc(S)
+
+
+def test_concatenation_without_rc_many_sequences(native):
+    """the no-rc concatenation (one sentinel per sequence) with 200 sequences, plain factorization of
+    the prepared string against the oracle"""
+    rng = random.Random(77)
+    seqs = ["".join(rng.choice("ACGT") for _ in range(rng.randint(1, 60))) + "GATTACA"[-rng.randint(1, 7):]
+            for _ in range(200)]
+    S, total, sent = native.prepare_multiple_dna_sequences_no_rc_bytes(seqs)
+    assert max(S) > ord("T") and len(sent) >= 199
+    assert native.factorize(S) == oracle.factorize(S)
