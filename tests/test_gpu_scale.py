@@ -206,3 +206,28 @@ def test_rc_long_palindromic_repeat(native):
     for k in ("start", "length", "ref"):
         assert np.array_equal(got[k], exp[k]), k
     assert (got["ref"] >> np.uint64(63)).sum() >= 1
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("kind", ["protein_4Mi", "bytes_2Mi", "sigma12_repeats_3Mi"])
+def test_other_alphabets_at_scale(native, kind):
+    """4-bit and 8-bit packed texts (5 to 8 sort passes on 64-bit keys, direct round on wider
+    symbols) at sizes where every kernel runs many tiles; exact against the oracle."""
+    rng = np.random.default_rng(11)
+    if kind == "protein_4Mi":
+        alphabet = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
+        t = alphabet[rng.integers(0, 20, size=1 << 22)]
+        t[1 << 21:(1 << 21) + 300_000] = t[1000:301_000]  # one long copy
+    elif kind == "bytes_2Mi":
+        t = rng.integers(1, 256, size=1 << 21, dtype=np.uint8)
+        t[1 << 20:(1 << 20) + 100_000] = t[5:100_005]
+    else:
+        alphabet = np.frombuffer(b"abcdefghijkl", dtype=np.uint8)
+        base = alphabet[rng.integers(0, 12, size=50_000)]
+        t = np.concatenate([base if rng.random() < 0.5 else alphabet[rng.integers(0, 12, size=50_000)]
+                            for _ in range(60)])
+    got = native.factorize_array(t)
+    exp = oracle.factors_array(t)
+    assert len(got) == len(exp)
+    for k in ("start", "length", "ref"):
+        assert np.array_equal(got[k], exp[k]), k
