@@ -138,6 +138,14 @@ def test_many_random_small(native):
         assert native.factorize(t) == oracle.factorize(t), t
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 4095, 4096, 4097, 8191, 8192, 8193,
+                               65535, 65536, 65537, (1 << 20) - 1, 1 << 20, (1 << 20) + 1])
+def test_sizes_around_tile_boundaries(native, n):
+    """tile sizes of the kernels are 256, 1024, 4096; 2^20 is where the bucketed key sort starts"""
+    t = gen.repeat_dna(n, 40 + n % 7, lo=8, hi=512).tobytes()
+    assert native.factorize(t) == oracle.factorize(t)
+
+
 def test_bucketed_key_sort_on_small_texts():
     """The bucketed (most-significant-digit first) key sort normally starts at 2^20 bases; one child
     process with NOLZSS_DNA_FAST_MIN=1 runs it on small DNA cases: empty buckets, buckets smaller
@@ -151,7 +159,8 @@ sys.path.insert(0, "tests")
 import numpy as np
 import gen, oracle_lib as oracle
 from nolzss_amd import _noLZSS as native
-cases = [b"ACGT", b"A" * 5000, (b"ACGTTGA" * 2000)[:13001], gen.random_dna(100, 1).tobytes(),
+sizes = [1, 2, 3, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 4095, 4096, 4097, 8191, 8192, 8193, 65535, 65536, 65537]
+cases = [gen.repeat_dna(m, 40 + m % 7, lo=8, hi=512).tobytes() for m in sizes] + [b"ACGT", b"A" * 5000, (b"ACGTTGA" * 2000)[:13001], gen.random_dna(100, 1).tobytes(),
          gen.random_dna(70_000, 3).tobytes(), gen.repeat_dna(300_000, 5, lo=16, hi=4096).tobytes(),
          b"AC" * 40000 + b"G", gen.random_dna(3000, 12).tobytes() * 64, b"T" * 4097 + gen.random_dna(5000, 9).tobytes()]
 for t in cases:
