@@ -558,7 +558,7 @@ __global__ __launch_bounds__(kThreads) void small_sort_kernel(const uint32_t *__
 
 // One workgroup refines all groups that START inside its kRefineTile list positions; every member
 // is a thread, all state lives in LDS.
-//   * Per round each still-tied member fetches the next kRefineWords * 64 bits of its own suffix
+//   * Per round each still-tied member fetches the next kRefineWords * 64 bits (128 bases) of its suffix
 //     (one random window per member per round -- never a pairwise re-read; an MI355X sustains
 //     ~40 G such windows/s, tools/gatherbench.hip) and parks it in LDS.
 //   * The comparisons are organised by PAIR, not by member: the unordered pairs of every group are
@@ -575,11 +575,11 @@ __global__ __launch_bounds__(kThreads) void small_sort_kernel(const uint32_t *__
 constexpr int kRefineTile = 256;
 constexpr int kRefineThreads = kRefineTile + (int)kSmallGroup;  // one thread per possible member
 constexpr int kRefineWaves = kRefineThreads / 64;
-constexpr int kRefineWords = 8;
-constexpr int kPairCap = 3072;  // pairs per workgroup (256 members in groups of up to ~24 fit)
+constexpr int kRefineWords = 4;
+constexpr int kPairCap = 2432;  // pairs per workgroup (256 members in groups of up to ~20 fit; 6 workgroups per CU)
 
 template <int BITS>
-__global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(4, 6))) void group_refine_kernel(
+__global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void group_refine_kernel(
     const uint32_t *__restrict__ act_slot, const uint32_t *__restrict__ act_grp, const uint32_t *__restrict__ sa,
     const uint64_t *__restrict__ words, TermTable terms, uint32_t m, uint32_t h0, uint32_t cap,
     uint32_t *__restrict__ out_lo, uint32_t *__restrict__ out_vals, uint32_t *__restrict__ lcp_list) {
