@@ -188,8 +188,9 @@ constexpr uint32_t kLcpPendingMin = kLcpPending - 64u;
 // LCP of every boundary that became known, and the compacted active list for the next round.
 // HBM traffic at round 0: 12 B read + 12 B written per suffix plus 8 B per surviving element,
 // where the five passes moved ~88 B.
-constexpr int kFuseItems = 16;
-constexpr int kFuseTile = kThreads * kFuseItems;
+constexpr int kFuseThreads = 512;  // 8 items per thread keep the registers low: 4 workgroups = 32 waves per CU
+constexpr int kFuseItems = 8;
+constexpr int kFuseTile = kFuseThreads * kFuseItems;
 constexpr uint32_t kSpinLimit = 1u << 24;  // look-back polls before the kernel gives up (sets err)
 
 __device__ __forceinline__ uint64_t desc_load(const uint64_t *p) {
@@ -328,8 +329,8 @@ __device__ __forceinline__ uint32_t lane_next(uint32_t v, uint32_t edge) {
 }
 
 template <bool kRound0>
-__global__ __launch_bounds__(kThreads) void regroup_kernel(RegroupArgs A) {
-    constexpr int kWaves = kThreads / 64;
+__global__ __launch_bounds__(kFuseThreads) void regroup_kernel(RegroupArgs A) {
+    constexpr int kWaves = kFuseThreads / 64;
     constexpr int kSegs = kFuseItems * kWaves;  // 64-element segments of the tile, in element order
     __shared__ uint32_t s_tile;
     __shared__ uint32_t s_seg_max[kSegs], s_seg_sum[kSegs];  // per segment: last head slot, kept; then prefixes
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(kThreads) void regroup_kernel(RegroupArgs A) {
         }
         return ((uint64_t)A.grp[a] << 32) | A.lo[a];
     };
-    // striped: item k of thread t is element tile_base + k * kThreads + t (coalesced rows).
+    // striped: item k of thread t is element tile_base + k * kFuseThreads + t (coalesced rows).
     // Every load of the tile goes out first (the LCP stores further down may alias the inputs as
     // far as the compiler knows; interleaved, each of the 16 rows would wait for its own round
     // trips to HBM): the view of my elements, their slots, and per row ONE neighbour -- the
@@ -364,8 +365,8 @@ __global__ __launch_bounds__(kThreads) void regroup_kernel(RegroupArgs A) {
     uint64_t view[kFuseItems], edge[kFuseItems];
 #pragma unroll
     for (int k = 0; k < kFuseItems; ++k) {
-        const size_t a = tile_base + (size_t)k * kThreads + threadIdx.x;
-        const bool in = (uint32_t)k * kThreads + threadIdx.x < ext.count;
+        const size_t a = tile_base + (size_t)k * kFuseThreads + threadIdx.x;
+        const bool in = (uint32_t)k * kFuseThreads + threadIdx.x < ext.count;
         view[k] = in ? load_view(a) : 0ull;
         slot[k] = kRound0 ? (uint32_t)a : (in ? A.act_slot[a] : 0u);
         edge[k] = 0;
@@ -375,8 +376,8 @@ __global__ __launch_bounds__(kThreads) void regroup_kernel(RegroupArgs A) {
     uint64_t hmask[kFuseItems], kmask[kFuseItems];  // wave-uniform: heads / kept elements of my segment
 #pragma unroll
     for (int k = 0; k < kFuseItems; ++k) {
-        const size_t a = tile_base + (size_t)k * kThreads + threadIdx.x;
-        const bool in = (uint32_t)k * kThreads + threadIdx.x < ext.count;
+        const size_t a = tile_base + (size_t)k * kFuseThreads + threadIdx.x;
+        const bool in = (uint32_t)k * kFuseThreads + threadIdx.x < ext.count;
         const uint64_t v = view[k];
         // the element in front: the previous lane's, except for lane 0
         const uint64_t pv = ((uint64_t)lane_prev((uint32_t)(v >> 32), (uint32_t)(edge[k] >> 32)) << 32) |
@@ -472,8 +473,8 @@ __global__ __launch_bounds__(kThreads) void regroup_kernel(RegroupArgs A) {
 
 #pragma unroll
     for (int k = 0; k < kFuseItems; ++k) {
-        const size_t a = tile_base + (size_t)k * kThreads + threadIdx.x;
-        const bool in = (uint32_t)k * kThreads + threadIdx.x < ext.count;
+        const size_t a = tile_base + (size_t)k * kFuseThreads + threadIdx.x;
+        const bool in = (uint32_t)k * kFuseThreads + threadIdx.x < ext.count;
         // slot of my group head: the last head at or in front of me
         const uint64_t mine = hmask[k] & ((2ull << lane) - 1ull);
         const int hl = mine ? 63 - __builtin_clzll(mine) : lane;
@@ -866,7 +867,7 @@ uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *grp, const 
         A.packed = n < 0x80000000u ? 1 : 0;  // slots and counts fit 31 bits
         A.ticket = reinterpret_cast<uint32_t *>(desc + 2 * tiles);
         A.d_total = d_total;
-        regroup_kernel<kRound0><<<(unsigned)tiles, kThreads, 0, s>>>(A);
+        regroup_kernel<kRound0><<<(unsigned)tiles, kFuseThreads, 0, s>>>(A);
         KERNEL_CHECK();
         HIP_CHECK(hipMemcpyAsync(d_total + 1, A.ticket + 1, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
     }
