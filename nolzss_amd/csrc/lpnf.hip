@@ -118,36 +118,6 @@ __global__ __launch_bounds__(kLdsThreads) void lpf_tile_kernel(const uint32_t *_
     }
 }
 
-constexpr uint32_t kFarCleared = 252;  // ranks a search has passed before it is marked far (nearest_lds.hpp)
-
-// One direction of a far search: nothing qualifies within kFarCleared ranks, so the pyramids take
-// over right there (no neighbour-by-neighbour prologue).
-__device__ __forceinline__ void far_up(const uint32_t *__restrict__ sa, const Pyramid &Psa, const Pyramid &Plcp,
-                                       uint32_t r, uint32_t x, uint32_t floor, uint32_t &len, uint32_t &pos) {
-    len = 0;
-    pos = kNoPos;
-    if (r <= kFarCleared) return;
-    const int64_t q = pyr_nearest_left<false>(Psa, r - kFarCleared - 1, x);
-    if (q < 0) return;
-    const uint32_t m = pyr_range<false>(Plcp, (uint32_t)q + 1, r);
-    if (m == 0 || m < floor) return;
-    len = m;
-    pos = sa[q];
-}
-__device__ __forceinline__ void far_down(const uint32_t *__restrict__ sa, uint32_t n, const Pyramid &Psa,
-                                         const Pyramid &Plcp, uint32_t r, uint32_t x, uint32_t floor, uint32_t &len,
-                                         uint32_t &pos) {
-    len = 0;
-    pos = kNoPos;
-    if ((uint64_t)r + kFarCleared + 1 >= n) return;
-    const uint32_t q = pyr_nearest_right<false>(Psa, r + kFarCleared + 1, x);
-    if (q >= n) return;
-    const uint32_t m = pyr_range<false>(Plcp, r + 1, q);
-    if (m == 0 || m < floor) return;
-    len = m;
-    pos = sa[q];
-}
-
 // ranks whose nearest earlier suffix lies outside the LDS reach: pyramid search
 __global__ __launch_bounds__(kThreads) void lpf_far_kernel(const uint32_t *__restrict__ far_queue, uint32_t count,
                                                            const uint32_t *__restrict__ sa,
@@ -168,16 +138,16 @@ __global__ __launch_bounds__(kThreads) void lpf_far_kernel(const uint32_t *__res
             nearest_up<false>(sa, lcp, Psa, Plcp, r, i, 0u, lp, jp);
             nearest_down<false>(sa, lcp, n, Psa, Plcp, r, i, lp, ls, js);  // cannot beat lp below lp
         } else if (aux == kFarBothUnknown) {
-            far_up(sa, Psa, Plcp, r, i, 0u, lp, jp);
-            far_down(sa, n, Psa, Plcp, r, i, lp, ls, js);
+            far_up<false>(sa, Psa, Plcp, r, i, 0u, lp, jp);
+            far_down<false>(sa, n, Psa, Plcp, r, i, lp, ls, js);
         } else if (aux >> 31) {  // the search towards larger ranks ended inside the tile
             ls = by_rank[r];
             js = (aux & 0x7fffffffu) == 0x7fffffffu ? kNoPos : (aux & 0x7fffffffu);
-            far_up(sa, Psa, Plcp, r, i, ls, lp, jp);
+            far_up<false>(sa, Psa, Plcp, r, i, ls, lp, jp);
         } else {
             lp = by_rank[r];
             jp = (aux & 0x7fffffffu) == 0x7fffffffu ? kNoPos : (aux & 0x7fffffffu);
-            far_down(sa, n, Psa, Plcp, r, i, lp, ls, js);
+            far_down<false>(sa, n, Psa, Plcp, r, i, lp, ls, js);
         }
         lpf_decide(i, lp, jp, ls, js, lstar + i, queue, queue_count);
     }

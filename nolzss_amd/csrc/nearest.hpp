@@ -83,6 +83,39 @@ __device__ inline void nearest_down(const uint32_t *__restrict__ sa, const uint3
     pos = sa[q];
 }
 
+// The same two searches for a rank whose search on an LDS tile (nearest_lds.hpp) left the tile's
+// reach: nothing qualifies within kFarCleared ranks, so the pyramids take over right behind them
+// (no neighbour-by-neighbour prologue).
+constexpr uint32_t kFarCleared = 252;  // ranks a search has passed before it is marked far
+
+template <bool kGreater>
+__device__ __forceinline__ void far_up(const uint32_t *__restrict__ sa, const Pyramid &Pv, const Pyramid &Plcp,
+                                       uint32_t r, uint32_t x, uint32_t floor, uint32_t &len, uint32_t &pos) {
+    len = 0;
+    pos = kNoPos;
+    if (r <= kFarCleared) return;
+    const int64_t q = pyr_nearest_left<kGreater>(Pv, r - kFarCleared - 1, x);
+    if (q < 0) return;
+    const uint32_t m = pyr_range<false>(Plcp, (uint32_t)q + 1, r);
+    if (m == 0 || m < floor) return;
+    len = m;
+    pos = sa[q];
+}
+template <bool kGreater>
+__device__ __forceinline__ void far_down(const uint32_t *__restrict__ sa, uint32_t n, const Pyramid &Pv,
+                                         const Pyramid &Plcp, uint32_t r, uint32_t x, uint32_t floor, uint32_t &len,
+                                         uint32_t &pos) {
+    len = 0;
+    pos = kNoPos;
+    if ((uint64_t)r + kFarCleared + 1 >= n) return;
+    const uint32_t q = pyr_nearest_right<kGreater>(Pv, r + kFarCleared + 1, x);
+    if (q >= n) return;
+    const uint32_t m = pyr_range<false>(Plcp, r + 1, q);
+    if (m == 0 || m < floor) return;
+    len = m;
+    pos = sa[q];
+}
+
 // I(d) around rank r: [lo, hi] with lcp[lo] < d, lcp[lo+1..hi] >= d, lcp[hi+1] < d.
 // Relies on lcp[0] = 0 and lcp[n] = 0 (d >= 1).
 __device__ inline void lcp_interval(const Pyramid &Plcp, uint32_t r, uint32_t d, uint32_t &lo, uint32_t &hi) {

@@ -93,7 +93,12 @@ __global__ __launch_bounds__(kLdsThreads) void rc_tile_kernel(const uint32_t *__
         const bool far_r = far_resolve(ru, rd, far_bit, 1u);
         if (far_f || far_r) {
             far_queue[atomicAdd(far_count, 1u)] = (uint32_t)rr;  // finish from global memory
-            code_by_rank[rr] = 0;
+            // which of the four searches left the reach (they restart behind the ranks already cleared)
+            uint32_t mask = 0;
+            if (far_bit)
+                mask = (far_is(lp, far_bit) ? 1u : 0u) | (far_is(ls, far_bit) ? 2u : 0u) | (far_is(ru, far_bit) ? 4u : 0u) |
+                       (far_is(rd, far_bit) ? 8u : 0u);
+            code_by_rank[rr] = mask;
             continue;
         }
         rc_decide(i, lp, s_pos[t], ls, s_pos[kLdsTile + t], ru > rd ? ru : rd, code_by_rank + rr, queue, queue_rc,
@@ -105,21 +110,34 @@ __global__ __launch_bounds__(kLdsThreads) void rc_tile_kernel(const uint32_t *__
 __global__ __launch_bounds__(kThreads) void rc_far_kernel(
     const uint32_t *__restrict__ far_queue, uint32_t count, const uint32_t *__restrict__ sa,
     const uint32_t *__restrict__ lcp, uint32_t m, uint32_t N, Pyramid Pmin, Pyramid Pmax, Pyramid Plcp,
-    uint32_t *__restrict__ code, uint32_t *__restrict__ queue, uint32_t *__restrict__ queue_rc,
-    uint32_t *__restrict__ queue_count) {
+    const uint32_t *__restrict__ by_rank, uint32_t *__restrict__ code, uint32_t *__restrict__ queue,
+    uint32_t *__restrict__ queue_rc, uint32_t *__restrict__ queue_count) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < count; k += stride) {
         const uint32_t r = far_queue[k];
         const uint32_t i = sa[r];
+        const uint32_t mask = by_rank[r];  // searches that left the tile's reach (0: unknown, search all from r)
         // forward: earlier suffixes, SA[q] < i
         uint32_t lp, jp, ls, js;
-        nearest_up<false>(sa, lcp, Pmin, Plcp, r, i, 0u, lp, jp);
-        nearest_down<false>(sa, lcp, m, Pmin, Plcp, r, i, lp, ls, js);
+        if (mask & 1u)
+            far_up<false>(sa, Pmin, Plcp, r, i, 0u, lp, jp);
+        else
+            nearest_up<false>(sa, lcp, Pmin, Plcp, r, i, 0u, lp, jp);
+        if (mask & 2u)
+            far_down<false>(sa, m, Pmin, Plcp, r, i, lp, ls, js);
+        else
+            nearest_down<false>(sa, lcp, m, Pmin, Plcp, r, i, lp, ls, js);
         // reverse complement: suffixes starting after 2N - i; lengths <= 1 can never be chosen
         const uint32_t thr = 2u * N - i;
         uint32_t ru, rd, unused;
-        nearest_up<true>(sa, lcp, Pmax, Plcp, r, thr, 2u, ru, unused);
-        nearest_down<true>(sa, lcp, m, Pmax, Plcp, r, thr, ru > 2u ? ru : 2u, rd, unused);
+        if (mask & 4u)
+            far_up<true>(sa, Pmax, Plcp, r, thr, 2u, ru, unused);
+        else
+            nearest_up<true>(sa, lcp, Pmax, Plcp, r, thr, 2u, ru, unused);
+        if (mask & 8u)
+            far_down<true>(sa, m, Pmax, Plcp, r, thr, ru > 2u ? ru : 2u, rd, unused);
+        else
+            nearest_down<true>(sa, lcp, m, Pmax, Plcp, r, thr, ru > 2u ? ru : 2u, rd, unused);
         rc_decide(i, lp, jp, ls, js, ru > rd ? ru : rd, code + i, queue, queue_rc, queue_count);
     }
 }
@@ -251,8 +269,8 @@ uint32_t run_rc_pipeline(Context &ctx, const uint8_t *d_S, size_t m_sz, size_t s
             ProfScope ps(ctx.profiler(), "rc_far", s);
             size_t g = div_up(h[1], kThreads);
             if (g > 256u * 32u) g = 256u * 32u;
-            rc_far_kernel<<<(unsigned)g, kThreads, 0, s>>>(far_queue, h[1], sa, lcp, m, N, Pmin, Pmax, Plcp, code,
-                                                           queue, queue_rc, counts);
+            rc_far_kernel<<<(unsigned)g, kThreads, 0, s>>>(far_queue, h[1], sa, lcp, m, N, Pmin, Pmax, Plcp, by_rank,
+                                                           code, queue, queue_rc, counts);
             KERNEL_CHECK();
             ctx.read_back(counts, h, 1);
         }
