@@ -300,6 +300,7 @@ struct RegroupArgs {
     SegView seg;
     uint32_t num_tiles;
     uint32_t short_tag;       // round 0: elements whose length tag is below this are groups of their own
+    int sa_is_current;        // the producer has already written the new order into sa (direct round)
     const uint32_t *grp;      // later rounds: (group head slot, secondary key) per list element
     const uint32_t *lo;
     const uint32_t *vals;     // suffix start per element
@@ -484,7 +485,8 @@ __global__ __launch_bounds__(kFuseThreads) void regroup_kernel(RegroupArgs A) {
             head_of = pm > xmax ? pm : xmax;
         }
         if (!in) continue;
-        if (!kRound0) A.sa[slot[k]] = A.vals[a];  // round 0: the key sort left the suffixes in sa itself
+        // (round 0: the key sort left the suffixes in sa itself; direct round: group_refine_kernel did)
+        if (!kRound0 && !A.sa_is_current) A.sa[slot[k]] = A.vals[a];
         if (A.rank_by_slot)
             A.rank_by_slot[slot[k]] = head_of + 1u;  // rank[] itself is written later, in one pass
         else
@@ -581,9 +583,9 @@ constexpr int kPairCap = 2432;  // pairs per workgroup (256 members in groups of
 
 template <int BITS>
 __global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void group_refine_kernel(
-    const uint32_t *__restrict__ act_slot, const uint32_t *__restrict__ act_grp, const uint32_t *__restrict__ sa,
+    const uint32_t *__restrict__ act_slot, const uint32_t *__restrict__ act_grp, uint32_t *sa,
     const uint64_t *__restrict__ words, TermTable terms, uint32_t m, uint32_t h0, uint32_t cap,
-    uint32_t *__restrict__ out_lo, uint32_t *__restrict__ out_vals, uint32_t *__restrict__ lcp_list) {
+    uint32_t *__restrict__ out_lo, uint32_t *__restrict__ lcp_list) {
     constexpr int kW32 = 2 * kRefineWords;  // window in 32-bit words, text order
     constexpr int kChunks = kW32 / 4;
     constexpr uint32_t kPer32 = 32 / BITS;
@@ -611,12 +613,13 @@ __global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(
     uint32_t my_pos = 0, my_lim = 0, my_term = 0;
     int my_gl = 0, my_gs = 0, my_j = 0;  // first member (local), group size (0: not mine), my index
     bool starts_here = false;
-    uint32_t j = 0;
+    uint32_t j = 0, my_head = 0;  // my index in the group, slot of the group's first member
     bool last = false;
     s_goff[t] = 0;  // doubles as the group size table until the pair offsets are written
     if (a < m) {
         const uint32_t g = act_grp[a];
         const uint32_t slot = act_slot[a];
+        my_head = g;
         last = a + 1 == m || act_grp[a + 1] != g;
         my_pos = sa[slot];
         j = slot - g;  // my index inside the group
@@ -632,10 +635,7 @@ __global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(
         const bool large = starts_here ? (sz == 0 || sz > kSmallGroup) : false;
         // too large for this round: stays one group, in place.  Its first kSmallGroup members are
         // written by the tile it starts in, the others by the tile that owns their list position.
-        if ((large && j < kSmallGroup) || (a < a1 && j >= kSmallGroup)) {
-            out_lo[a] = 0;
-            out_vals[a] = my_pos;
-        }
+        if ((large && j < kSmallGroup) || (a < a1 && j >= kSmallGroup)) out_lo[a] = 0;  // (sa keeps its order)
         if (starts_here && !large) {
             my_gs = (int)sz;
             my_j = (int)j;
@@ -671,10 +671,7 @@ __global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(
             gend = s_goff[my_gl] + (uint32_t)(my_gs * (my_gs - 1) / 2);
             handled = gend <= (uint32_t)kPairCap;
             if (handled && my_j == my_gs - 1) atomicMax(&s_npairs, gend);
-            if (!handled) {  // no room for its pairs: the group stays as it is
-                out_lo[a] = 0;
-                out_vals[a] = my_pos;
-            }
+            if (!handled) out_lo[a] = 0;  // no room for its pairs: the group stays as it is
         }
         __syncthreads();
         npairs = s_npairs;
@@ -794,7 +791,10 @@ __global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(
         const uint32_t cls = s_cls[t], ties_before = s_goff[t];
         const size_t pos = a0 + my_gl + cls + ties_before;
         out_lo[pos] = cls;
-        out_vals[pos] = my_pos;
+        // the new order goes straight into the suffix array: my group occupies the slots from my_head
+        // on, in list order (only members of the group, all threads of this workgroup, ever read or
+        // write those slots, and every read happened before the barriers above)
+        sa[my_head + cls + ties_before] = my_pos;
         // LCP to the predecessor in the new order: the closest smaller member shares the
         // longest prefix; a tied predecessor (then this is not a new head) stays pending
         lcp_list[pos] = ties_before ? kLcpPending : s_best[t];
@@ -843,7 +843,7 @@ uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *grp, const 
                  uint32_t *d_total, uint32_t *lcp = nullptr, int sym_bits = 0, int tag_bits = 0, int bits = 0,
                  const uint32_t *lcp_list = nullptr, int low_bits = 0, uint32_t dbl_h = 0,
                  uint32_t *rank_by_slot = nullptr, const Pyramid *plcp = nullptr, const uint32_t *keys32 = nullptr,
-                 const SegView *seg = nullptr, uint32_t short_tag = 0) {
+                 const SegView *seg = nullptr, uint32_t short_tag = 0, bool sa_is_current = false) {
     hipStream_t s = ctx.stream;
     const size_t pmark = ctx.arena.mark();
     // doubling boundaries read range minima of the LCP values decided so far
@@ -858,6 +858,7 @@ uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *grp, const 
         HIP_CHECK(hipMemsetAsync(desc, 0, (2 * tiles + 1) * sizeof(uint64_t), s));
         RegroupArgs A{};
         A.short_tag = short_tag;
+        A.sa_is_current = sa_is_current ? 1 : 0;
         A.keys = keys; A.keys32 = keys32; A.seg = seg ? *seg : SegView{}; A.num_tiles = (uint32_t)tiles; A.grp = grp; A.lo = lo; A.vals = vals; A.act_slot = act_slot; A.m = m;
         A.sa = sa; A.rank_val = rank_val; A.rank_by_slot = rank_by_slot; A.lcp = lcp;
         A.sym_bits = sym_bits; A.tag_bits = tag_bits; A.bits = bits; A.low_bits = low_bits;
@@ -1117,22 +1118,23 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
             switch (text.bits) {
             case 2:
                 group_refine_kernel<2><<<g, kRefineThreads, 0, s>>>(slot, grp, sa, text.words, text.terms, m, (uint32_t)h, cap,
-                                                              out_lo, out_vals, lcp_list);
+                                                              out_lo, lcp_list);
                 break;
             case 4:
                 group_refine_kernel<4><<<g, kRefineThreads, 0, s>>>(slot, grp, sa, text.words, text.terms, m, (uint32_t)h, cap,
-                                                              out_lo, out_vals, lcp_list);
+                                                              out_lo, lcp_list);
                 break;
             default:
                 group_refine_kernel<8><<<g, kRefineThreads, 0, s>>>(slot, grp, sa, text.words, text.terms, m, (uint32_t)h, cap,
-                                                              out_lo, out_vals, lcp_list);
+                                                              out_lo, lcp_list);
                 break;
             }
             KERNEL_CHECK();
         }
         m = regroup<false>(ctx, nullptr, grp, out_lo, out_vals, slot, m, n, sa, rank, act_slot[a_cur ^ 1],
                            act_grp[a_cur ^ 1], scratch_idx, scratch_val, rank_val, d_total, lcp,
-                           0, 0, 0, lcp_list, 0, (uint32_t)h, rank_by_slot);
+                           0, 0, 0, lcp_list, 0, (uint32_t)h, rank_by_slot, nullptr, nullptr, nullptr, 0u,
+                           /*sa_is_current=*/true);
         a_cur ^= 1;
         if (trace) fprintf(stderr, "[nolzss]   direct round (cap %u symbols): %u still tied\n", cap, m);
         // h stays K: the large groups are only K-sorted
