@@ -263,3 +263,32 @@ def test_per_sequence_fasta_and_ref_target_fasta(pkg, tmp_path):
     assert struct.unpack("<8sQQQQQ", raw[-48:]) == (b"noLZSSv2", z, 0, 0, 48, len(S))
     with pytest.raises(RuntimeError, match="Cannot open input file"):
         _noLZSS.factorize_file_dna_w_rc(str(tmp_path / "nope"))
+
+
+def test_concurrent_host_threads(pkg):
+    """The bindings release the GIL around the native call (bindings.cpp:70): several Python threads
+    factorizing different texts at once must each get their own answer."""
+    import threading
+    from nolzss_amd import _noLZSS as native
+    texts = [gen.repeat_dna(300_000 + 37_000 * k, seed=900 + k, lo=16, hi=4096) for k in range(6)]
+    texts += [gen.random_dna(500_000 + 11 * k, seed=800 + k) for k in range(3)]
+    expected = [oracle.count_factors(t) for t in texts]
+    errors = []
+
+    def worker(tid):
+        try:
+            for rep in range(3):
+                for k in range(len(texts)):
+                    j = (k + tid) % len(texts)
+                    z = native.count_factors(texts[j])
+                    if z != expected[j]:
+                        errors.append((tid, rep, j, z, expected[j]))
+        except Exception as e:  # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
