@@ -109,7 +109,7 @@ size_t run_plain(Context &ctx, const uint8_t *d_text, size_t n, size_t start_pos
     {
         ProfScope ps(ctx.profiler(), "pyramids", s);
         Psa = build_pyramid(sa, (uint32_t)n, false, arena, s);
-        Plcp = build_pyramid(lcp, (uint32_t)n + 1, false, arena, s);
+        Plcp = build_lcp_pyramid(ctx, text, sa, lcp);
     }
     uint32_t *lstar = arena.alloc<uint32_t>(n);
     build_lstar(ctx, (uint32_t)n, sa, isa, lcp, Psa, Plcp, lstar);

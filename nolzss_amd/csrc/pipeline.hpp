@@ -1,6 +1,7 @@
 // pipeline.hpp -- per-device context and the stage entry points of the factorization pipeline.
 #pragma once
 #include "common.hpp"
+#include "pyramid.hpp"
 #include "text.hpp"
 
 namespace nolzss {
@@ -29,6 +30,9 @@ PackedText pack_text(Context &ctx, const uint8_t *d_text, size_t n);
 // caller-allocated.  LCP entries between suffixes that round 0 already separates come straight
 // from the sort keys; only the others compare packed text.  Returns the doubling rounds run.
 int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint32_t *isa, uint32_t *lcp);
+// The range-minimum pyramid over lcp[0..n]; checks on the way that the construction left no boundary
+// undecided (and compares those suffixes in the text if it did).
+Pyramid build_lcp_pyramid(Context &ctx, const PackedText &text, const uint32_t *sa, uint32_t *lcp);
 
 struct Pyramid;
 

@@ -7,30 +7,39 @@ namespace {
 
 constexpr int kThreads = 256;
 
+// flag_min / flag (optional, first level of the LCP pyramid): *flag is set if any base entry is
+// >= flag_min, i.e. still holds a "pending" code of the suffix-array construction
 template <bool kMax>
 __global__ __launch_bounds__(kThreads) void pyramid_level_kernel(const uint32_t *__restrict__ in, uint32_t len_in,
-                                                                 uint32_t *__restrict__ out, uint32_t len_out) {
+                                                                 uint32_t *__restrict__ out, uint32_t len_out,
+                                                                 uint32_t flag_min, uint32_t *__restrict__ flag) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < len_out; j += stride) {
         const size_t base = j << kPyrShift;
-        uint32_t res = kMax ? 0u : 0xffffffffu;
+        uint32_t res = kMax ? 0u : 0xffffffffu, top = 0u;
         if (base + kPyrFan <= len_in) {
             const uint4 *v = reinterpret_cast<const uint4 *>(in + base);  // level arrays are 256-B aligned
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const uint4 x = v[k];
                 res = pyr_op<kMax>(res, pyr_op<kMax>(pyr_op<kMax>(x.x, x.y), pyr_op<kMax>(x.z, x.w)));
+                if (!kMax) top = pyr_op<true>(top, pyr_op<true>(pyr_op<true>(x.x, x.y), pyr_op<true>(x.z, x.w)));
             }
         } else {
-            for (size_t q = base; q < len_in; ++q) res = pyr_op<kMax>(res, in[q]);
+            for (size_t q = base; q < len_in; ++q) {
+                res = pyr_op<kMax>(res, in[q]);
+                top = pyr_op<true>(top, in[q]);
+            }
         }
         out[j] = res;
+        if (!kMax && flag && top >= flag_min) atomicOr(flag, 1u);
     }
 }
 
 }  // namespace
 
-Pyramid build_pyramid(const uint32_t *base, uint32_t len, bool is_max, Arena &arena, hipStream_t stream) {
+Pyramid build_pyramid(const uint32_t *base, uint32_t len, bool is_max, Arena &arena, hipStream_t stream,
+                      uint32_t flag_min, uint32_t *flag) {
     Pyramid P{};
     P.lvl[0] = base;
     P.len[0] = len;
@@ -44,9 +53,11 @@ Pyramid build_pyramid(const uint32_t *base, uint32_t len, bool is_max, Arena &ar
         size_t g = div_up(len_out, kThreads);
         if (g > 8192) g = 8192;
         if (is_max)
-            pyramid_level_kernel<true><<<(unsigned)g, kThreads, 0, stream>>>(P.lvl[P.nlev - 1], len_in, out, len_out);
+            pyramid_level_kernel<true><<<(unsigned)g, kThreads, 0, stream>>>(P.lvl[P.nlev - 1], len_in, out, len_out, 0u,
+                                                                             nullptr);
         else
-            pyramid_level_kernel<false><<<(unsigned)g, kThreads, 0, stream>>>(P.lvl[P.nlev - 1], len_in, out, len_out);
+            pyramid_level_kernel<false><<<(unsigned)g, kThreads, 0, stream>>>(P.lvl[P.nlev - 1], len_in, out, len_out,
+                                                                              flag_min, P.nlev == 1 ? flag : nullptr);
         KERNEL_CHECK();
         P.lvl[P.nlev] = out;
         P.len[P.nlev] = len_out;

@@ -21,8 +21,10 @@ struct Pyramid {
     int nlev;
 };
 
-// Builds the upper levels over `base` (len entries) in arena memory.
-Pyramid build_pyramid(const uint32_t *base, uint32_t len, bool is_max, Arena &arena, hipStream_t stream);
+// Builds the upper levels over `base` (len entries) in arena memory.  With `flag` (min pyramids
+// only), *flag is OR-ed with 1 if some base entry is >= flag_min.
+Pyramid build_pyramid(const uint32_t *base, uint32_t len, bool is_max, Arena &arena, hipStream_t stream,
+                      uint32_t flag_min = 0, uint32_t *flag = nullptr);
 
 template <bool kMax> __device__ __forceinline__ bool pyr_hit(uint32_t v, uint32_t x) {
     return kMax ? (v > x) : (v < x);

@@ -236,7 +236,7 @@ uint32_t run_rc_pipeline(Context &ctx, const uint8_t *d_S, size_t m_sz, size_t s
         ProfScope ps(ctx.profiler(), "pyramids", s);
         Pmin = build_pyramid(sa, m, false, arena, s);
         Pmax = build_pyramid(sa, m, true, arena, s);
-        Plcp = build_pyramid(lcp, m + 1, false, arena, s);
+        Plcp = build_lcp_pyramid(ctx, text, sa, lcp);
     }
     // code[] spans all of S (entries >= N are unused) so that rank order -> text order is a
     // permutation scatter
