@@ -26,6 +26,7 @@
 #include "scan.hpp"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace nolzss {
 namespace {
@@ -262,7 +263,14 @@ void radix_pass(Src src, OutT *keys_out, uint32_t *vals_out, size_t n, int shift
         scan_exclusive_add_u32(hist, hist, (size_t)kBins * num_tiles, nullptr, arena, stream);
     }
     {
-        ProfScope ps(prof, "rs_scatter", stream, scatter_bytes);
+        // classes of launches, so that the bandwidth of the large passes can be told from the many
+        // small sorts of the doubling rounds: rs_scatter.{text|u64|u32}[.small]
+        const bool small = n < (size_t(1) << 24);
+        const char *cls = std::is_same<Src, ArraySrc<KeyT>>::value
+                              ? (sizeof(KeyT) == 8 ? (small ? "rs_scatter.u64.small" : "rs_scatter.u64")
+                                                   : (small ? "rs_scatter.u32.small" : "rs_scatter.u32"))
+                              : "rs_scatter.text";
+        ProfScope ps(prof, cls, stream, scatter_bytes);
         const uint32_t grid = (uint32_t)div_up(num_tiles, 8) * 8;
         rs_scatter_kernel<KeyT, OutT, Src><<<grid, kThreads, 0, stream>>>(src, keys_out, vals_out, n, shift, hist,
                                                                           num_tiles, seg);
