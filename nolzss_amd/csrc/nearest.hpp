@@ -3,7 +3,7 @@
 //
 // From rank r, walk towards smaller (up) or larger (down) ranks until a suffix start SA[q]
 // qualifies (kGreater ? SA[q] > x : SA[q] < x), carrying the running minimum of the LCP values
-// crossed, i.e. the LCP between suffix SA[r] and suffix SA[q].  The first kNeighbourSteps ranks
+// crossed, i.e. the LCP between suffix SA[r] and suffix SA[q].  The first kNeighbourSteps (4) ranks
 // are read directly (neighbouring lanes read neighbouring entries: L1/L2-served); if nothing
 // qualifies there the search continues in the min/max pyramid over SA and the LCP minimum of the
 // skipped stretch comes from the LCP pyramid.
@@ -12,7 +12,7 @@
 
 namespace nolzss {
 
-constexpr uint32_t kNeighbourSteps = 32;
+constexpr uint32_t kNeighbourSteps = 4;
 constexpr uint32_t kNoPos = 0xffffffffu;
 
 template <bool kGreater> __device__ __forceinline__ bool qualifies(uint32_t v, uint32_t x) {
