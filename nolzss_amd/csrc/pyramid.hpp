@@ -33,6 +33,49 @@ template <bool kMax> __device__ __forceinline__ uint32_t pyr_op(uint32_t a, uint
     return kMax ? (a > b ? a : b) : (a < b ? a : b);
 }
 
+// The queries read whole aligned 16-entry blocks (one 64-byte line, four 16-byte loads in flight
+// together) and decide in registers: walking a block entry by entry makes every step a dependent
+// load, and the walks of the far / exact / factor kernels are nothing but such chains.  Every level
+// array (and the base arrays, which come from the arena) is 256-byte aligned and padded, so a block
+// that starts below len can be read in full; entries at or beyond len are masked out.
+struct PyrBlock {
+    uint32_t v[kPyrFan];
+};
+__device__ __forceinline__ PyrBlock pyr_load_block(const uint32_t *__restrict__ A, uint32_t block_start) {
+    PyrBlock B;
+    const uint4 *p = reinterpret_cast<const uint4 *>(A + block_start);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint4 x = p[k];
+        B.v[4 * k] = x.x;
+        B.v[4 * k + 1] = x.y;
+        B.v[4 * k + 2] = x.z;
+        B.v[4 * k + 3] = x.w;
+    }
+    return B;
+}
+// bit j set iff entry block_start + j exists (< len) and its value is < x (kMax: > x)
+template <bool kMax>
+__device__ __forceinline__ uint32_t pyr_hit_mask(const PyrBlock &B, uint32_t block_start, uint32_t len, uint32_t x) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int j = 0; j < (int)kPyrFan; ++j) m |= (pyr_hit<kMax>(B.v[j], x) ? 1u : 0u) << j;
+    const uint32_t left = len - block_start;
+    return left >= kPyrFan ? m : (m & ((1u << left) - 1u));
+}
+// min (kMax: max) of the entries j0..j1 (inclusive, inside the block)
+template <bool kMax>
+__device__ __forceinline__ uint32_t pyr_block_reduce(const PyrBlock &B, uint32_t j0, uint32_t j1) {
+    uint32_t res = kMax ? 0u : 0xffffffffu;
+#pragma unroll
+    for (int j = 0; j < (int)kPyrFan; ++j) {
+        const bool in = (uint32_t)j >= j0 && (uint32_t)j <= j1;
+        const uint32_t v = in ? B.v[j] : (kMax ? 0u : 0xffffffffu);
+        res = pyr_op<kMax>(res, v);
+    }
+    return res;
+}
+
 // Largest q in [0, r] whose base value is < x (kMax: > x); -1 if none.
 template <bool kMax>
 __device__ inline int64_t pyr_nearest_left(const Pyramid &P, uint32_t r, uint32_t x) {
@@ -40,28 +83,22 @@ __device__ inline int64_t pyr_nearest_left(const Pyramid &P, uint32_t r, uint32_
     uint32_t idx = r, q;
     for (;;) {
         const uint32_t bstart = idx & ~(kPyrFan - 1);
-        const uint32_t *A = P.lvl[l];
-        bool found = false;
-        for (q = idx;; --q) {
-            if (pyr_hit<kMax>(A[q], x)) {
-                found = true;
-                break;
-            }
-            if (q == bstart) break;
+        const PyrBlock B = pyr_load_block(P.lvl[l], bstart);
+        const uint32_t m = pyr_hit_mask<kMax>(B, bstart, P.len[l], x) & ((2u << (idx - bstart)) - 1u);  // entries <= idx
+        if (m) {
+            q = bstart + (31u - (uint32_t)__clz((int)m));
+            break;
         }
-        if (found) break;
         if ((idx >> kPyrShift) == 0) return -1;
         idx = (idx >> kPyrShift) - 1;
         ++l;
     }
     while (l > 0) {
         --l;
-        const uint32_t *A = P.lvl[l];
         const uint32_t base = q << kPyrShift;
-        uint32_t c = base + kPyrFan - 1;
-        if (c >= P.len[l]) c = P.len[l] - 1;
-        while (!pyr_hit<kMax>(A[c], x) && c > base) --c;
-        q = c;
+        const PyrBlock B = pyr_load_block(P.lvl[l], base);
+        const uint32_t m = pyr_hit_mask<kMax>(B, base, P.len[l], x);
+        q = m ? base + (31u - (uint32_t)__clz((int)m)) : base;
     }
     return (int64_t)q;
 }
@@ -74,17 +111,13 @@ __device__ inline uint32_t pyr_nearest_right(const Pyramid &P, uint32_t r, uint3
     int l = 0;
     uint32_t idx = r, q;
     for (;;) {
-        uint32_t bend = idx | (kPyrFan - 1);
-        if (bend >= P.len[l]) bend = P.len[l] - 1;
-        const uint32_t *A = P.lvl[l];
-        bool found = false;
-        for (q = idx; q <= bend; ++q) {
-            if (pyr_hit<kMax>(A[q], x)) {
-                found = true;
-                break;
-            }
+        const uint32_t bstart = idx & ~(kPyrFan - 1);
+        const PyrBlock B = pyr_load_block(P.lvl[l], bstart);
+        const uint32_t m = pyr_hit_mask<kMax>(B, bstart, P.len[l], x) & ~((1u << (idx - bstart)) - 1u);  // entries >= idx
+        if (m) {
+            q = bstart + (uint32_t)__builtin_ctz(m);
+            break;
         }
-        if (found) break;
         const uint32_t nxt = (idx >> kPyrShift) + 1;
         if (l + 1 >= P.nlev || nxt >= P.len[l + 1]) return none;
         idx = nxt;
@@ -92,12 +125,12 @@ __device__ inline uint32_t pyr_nearest_right(const Pyramid &P, uint32_t r, uint3
     }
     while (l > 0) {
         --l;
-        const uint32_t *A = P.lvl[l];
-        uint32_t c = q << kPyrShift;
+        const uint32_t c = q << kPyrShift;
         uint32_t end = c + kPyrFan - 1;
         if (end >= P.len[l]) end = P.len[l] - 1;
-        while (!pyr_hit<kMax>(A[c], x) && c < end) ++c;
-        q = c;
+        const PyrBlock B = pyr_load_block(P.lvl[l], c);
+        const uint32_t m = pyr_hit_mask<kMax>(B, c, P.len[l], x);
+        q = m ? c + (uint32_t)__builtin_ctz(m) : end;
     }
     return q;
 }
@@ -108,14 +141,25 @@ template <bool kMax> __device__ inline uint32_t pyr_range(const Pyramid &P, uint
     int l = 0;
     for (;;) {
         const uint32_t *A = P.lvl[l];
-        if (b - a < 2 * kPyrFan) {
-            for (uint32_t q = a; q <= b; ++q) res = pyr_op<kMax>(res, A[q]);
+        if (b - a < 2 * kPyrFan) {  // at most three blocks
+            for (uint32_t bs = a & ~(kPyrFan - 1); bs <= b; bs += kPyrFan) {
+                const PyrBlock B = pyr_load_block(A, bs);
+                const uint32_t j0 = a > bs ? a - bs : 0u;
+                const uint32_t j1 = b - bs < kPyrFan - 1 ? b - bs : kPyrFan - 1;
+                res = pyr_op<kMax>(res, pyr_block_reduce<kMax>(B, j0, j1));
+            }
             return res;
         }
         const uint32_t a_up = (a + kPyrFan - 1) >> kPyrShift;
         const uint32_t b_up = (b + 1) >> kPyrShift;
-        for (uint32_t q = a; q < (a_up << kPyrShift); ++q) res = pyr_op<kMax>(res, A[q]);
-        for (uint32_t q = (b_up << kPyrShift); q <= b; ++q) res = pyr_op<kMax>(res, A[q]);
+        if (a & (kPyrFan - 1)) {  // entries a .. end of a's block
+            const uint32_t bs = a & ~(kPyrFan - 1);
+            res = pyr_op<kMax>(res, pyr_block_reduce<kMax>(pyr_load_block(A, bs), a - bs, kPyrFan - 1));
+        }
+        if ((b + 1) & (kPyrFan - 1)) {  // start of b's block .. b
+            const uint32_t bs = b & ~(kPyrFan - 1);
+            res = pyr_op<kMax>(res, pyr_block_reduce<kMax>(pyr_load_block(A, bs), 0u, b - bs));
+        }
         a = a_up;
         b = b_up - 1;
         ++l;
