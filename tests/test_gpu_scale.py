@@ -231,3 +231,18 @@ def test_other_alphabets_at_scale(native, kind):
     assert len(got) == len(exp)
     for k in ("start", "length", "ref"):
         assert np.array_equal(got[k], exp[k]), k
+
+
+@pytest.mark.timeout(600)
+def test_differential_fuzz_short():
+    """tools/fuzz.py for a few seconds: random texts of many shapes (tandem repeats, runs, copies with
+    edits, small and large alphabets, prepared multi-sequence strings), plain and RC, against the
+    oracle; the child process also takes the bucketed sort for every 2-bit text."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for env_extra, seed in (({}, "11"), ({"NOLZSS_DNA_FAST_MIN": "1"}, "12")):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz.py"), "8", seed], cwd=root,
+                           env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "no mismatch" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
