@@ -196,8 +196,11 @@ void nolzss_free_fasta_per_sequence_result(nolzss_fasta_per_sequence_result *r);
  *            src/noLZSS/genomics/fasta.py:110-122 (C++ analogue:
  *            parallel_fasta_processor.cpp:360-385).  Sequence j is factorized on
  *            devices[j % n_dev]-th device of the list in longest-first order; out[j] / z[j]
- *            are per sequence (out may be NULL for counts only).  Free with
- *            nolzss_free_batch(). */
+ *            are per sequence (out may be NULL for counts only).
+ *            Short records (fewer than NOLZSS_BATCH_MERGE_BELOW bases, default 2^21) that hold only
+ *            A/C/G/T are factorized TOGETHER, as independent sequences of one device run (same
+ *            results; 35 -> 3000 Mbases/s for 4 Ki-base records): out[j] may therefore point into a
+ *            block shared with other records.  Free ONLY with nolzss_free_batch(). */
 int nolzss_factorize_batch(const uint8_t *const *texts, const size_t *lens, size_t m,
                            const int *devices, size_t n_dev, nolzss_factor ***out, size_t **z);
 void nolzss_free_batch(nolzss_factor **out, size_t *z, size_t m);
@@ -220,6 +223,8 @@ int nolzss_debug_sort_pairs(uint64_t *keys, uint32_t *vals, size_t n, int device
 int nolzss_debug_scan(uint32_t *data, size_t n, int mode, int device);
 /* Capacity and high-water mark (bytes) of the device arena of `device` (lane 0). */
 int nolzss_debug_arena(int device, size_t *capacity, size_t *peak);
+/* Records factorized since the library was loaded by merged runs / one pipeline run each. */
+void nolzss_debug_batch_counters(uint64_t *merged_records, uint64_t *single_records);
 
 #ifdef __cplusplus
 }

@@ -93,6 +93,8 @@ def _load():
     lib.nolzss_debug_sort_pairs.argtypes = [vp, vp, sz, C.c_int]
     lib.nolzss_debug_scan.argtypes = [vp, sz, C.c_int, C.c_int]
     lib.nolzss_debug_arena.argtypes = [C.c_int, szp, szp]
+    lib.nolzss_debug_batch_counters.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.nolzss_debug_batch_counters.restype = None
     return lib
 
 
@@ -113,6 +115,7 @@ EXPORTED_SYMBOLS = [
     "nolzss_factorize_dna_rc_w_ref_fasta_files", "nolzss_write_factors_dna_w_reference_fasta_files_to_binary",
     "nolzss_free_batch", "nolzss_profile_enable", "nolzss_profile_reset", "nolzss_profile_report",
     "nolzss_debug_arrays", "nolzss_debug_sort_pairs", "nolzss_debug_scan", "nolzss_debug_arena",
+    "nolzss_debug_batch_counters",
 ]
 
 

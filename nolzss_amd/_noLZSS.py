@@ -164,20 +164,31 @@ def factorize_batch(texts, devices=None, want_factors: bool = True):
     zs = C.POINTER(C.c_size_t)()
     check(lib.nolzss_factorize_batch(ptrs, lens, m, devs, len(devices),
                                      C.byref(out) if want_factors else None, C.byref(zs)))
-    try:
-        counts = [zs[j] for j in range(m)]
-        arrays = None
-        if want_factors:
-            arrays = []
-            for j in range(m):
-                if counts[j] == 0 or not out[j]:
-                    arrays.append(np.zeros(0, dtype=FACTOR_DTYPE))
-                else:
-                    raw = np.ctypeslib.as_array(C.cast(out[j], C.POINTER(C.c_uint64)), shape=(counts[j] * 3,))
-                    arrays.append(raw.copy().view(FACTOR_DTYPE))
-    finally:
-        lib.nolzss_free_batch(out if want_factors else None, zs, m)
+    owner = _BatchResult(out if want_factors else None, zs, m)
+    counts = np.ctypeslib.as_array(zs, shape=(m,)).tolist() if m else []
+    if not want_factors:
+        return counts, None
+    # the arrays are views of the library's blocks (a merged run delivers the factors of thousands of
+    # records in one block); the blocks live as long as any of the views
+    arrays = []
+    for j in range(m):
+        if counts[j] == 0 or not out[j]:
+            arrays.append(np.zeros(0, dtype=FACTOR_DTYPE))
+        else:
+            raw = (C.c_uint64 * (3 * counts[j])).from_address(out[j])
+            raw._owner = owner
+            arrays.append(np.frombuffer(raw, dtype=FACTOR_DTYPE))
     return counts, arrays
+
+
+class _BatchResult:
+    """Frees the result of nolzss_factorize_batch when the last array that views it is gone."""
+
+    def __init__(self, out, zs, m):
+        self.out, self.zs, self.m = out, zs, m
+
+    def __del__(self):
+        lib.nolzss_free_batch(self.out, self.zs, self.m)
 
 
 # ---- reverse-complement DNA mode -----------------------------------------------------------
@@ -649,6 +660,13 @@ def debug_arena():
     cap, peak = C.c_size_t(), C.c_size_t()
     check(lib.nolzss_debug_arena(_default_device, C.byref(cap), C.byref(peak)))
     return cap.value, peak.value
+
+
+def debug_batch_counters():
+    """(records factorized by merged runs, records factorized one pipeline run each) since load."""
+    a, b = C.c_uint64(), C.c_uint64()
+    lib.nolzss_debug_batch_counters(C.byref(a), C.byref(b))
+    return a.value, b.value
 
 
 def debug_scan(data, mode: int):

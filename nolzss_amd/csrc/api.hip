@@ -9,6 +9,8 @@
 #include <sys/stat.h>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <sys/mman.h>
 #include <fstream>
 #include <memory>
 #include <mutex>
@@ -876,6 +878,10 @@ void write_fasta_file(const char *out_path, const FastaFactors &ff) {
     write_v2_file(out_path, ff.factors, ff.z, ff.parse.ids.size(), ff.sentinel_idx.size(), total, extra);
 }
 
+// the batch worker (defined with the merged batch further down)
+void factorize_many(const uint8_t *const *texts, const size_t *lens, size_t m, const int *devices, size_t n_dev,
+                    size_t *zs, nolzss_factor **fs, std::vector<void *> &blocks);
+
 }  // namespace
 }  // namespace nolzss
 
@@ -1022,22 +1028,42 @@ int nolzss_factorize_fasta_per_sequence(const char *fasta_path, int with_rc, int
         }
         std::memcpy(res.sequence_ids, blob.data(), blob.size());
         res.sequence_ids_bytes = blob.size();
+        // no-rc records go through the batch worker (short ones merged into one device run)
+        std::vector<size_t> plain_z(m, 0);
+        std::vector<nolzss_factor *> plain_f(m, nullptr);
+        std::vector<void *> blocks;
+        struct FreeBlocks {
+            std::vector<void *> &b;
+            ~FreeBlocks() {
+                for (void *p : b) std::free(p);
+            }
+        } free_blocks{blocks};
         try {
+            const bool need_f = keep || out_dir;
+            if (!with_rc && m) {  // the reference strips the last base here (fasta_processor.cpp:469-471)
+                std::vector<const uint8_t *> ptrs(m);
+                std::vector<size_t> lens(m);
+                for (size_t j = 0; j < m; ++j) {
+                    ptrs[j] = reinterpret_cast<const uint8_t *>(parse.sequences[j].data());
+                    lens[j] = parse.sequences[j].size() - 1;
+                    if (lens[j] > 0) check_text_args(ptrs[j], lens[j], 0);
+                }
+                factorize_many(ptrs.data(), lens.data(), m, &device, 1, plain_z.data(),
+                               need_f ? plain_f.data() : nullptr, blocks);
+            }
             for (size_t j = 0; j < m; ++j) {
                 const std::string &seq = parse.sequences[j];
                 nolzss_factor *f = nullptr;
                 size_t z = 0;
-                const bool need_f = keep || out_dir;
                 if (with_rc) {  // prepare({seq}) + factorize_multiple_dna_w_rc, fasta_processor.cpp:446-451
                     dna_w_rc_common(reinterpret_cast<const uint8_t *>(seq.data()), seq.size(), device,
                                     need_f ? &f : nullptr, &z);
-                } else {  // the reference strips the last base here (:469-471)
-                    const size_t len = seq.size() - 1;
-                    if (len > 0) {
-                        check_text_args(seq.data(), len, 0);
-                        Session ses(device, nullptr);
-                        z = run_plain_host(ses.ctx(), reinterpret_cast<const uint8_t *>(seq.data()), len, 0,
-                                           need_f ? &f : nullptr, nullptr);
+                } else {
+                    z = plain_z[j];
+                    if (need_f && z) {  // a block of the batch worker may hold many records: own copy
+                        f = static_cast<nolzss_factor *>(std::malloc(sizeof(nolzss_factor) * z));
+                        if (!f) throw std::bad_alloc();
+                        std::memcpy(f, plain_f[j], sizeof(nolzss_factor) * z);
                     }
                 }
                 std::unique_ptr<nolzss_factor, decltype(&std::free)> hold(f, &std::free);
@@ -1063,6 +1089,311 @@ int nolzss_factorize_fasta_per_sequence(const char *fasta_path, int with_rc, int
     });
 }
 
+}  // extern "C"
+
+namespace nolzss {
+namespace {
+
+// ---- merged batch: many short nucleotide records in ONE pipeline run ----------------------------
+// A record of a few thousand bases cannot fill the GPU, and one pipeline run costs the same ~100
+// launches and a dozen read-backs whatever its size (0.12 ms per 4 Ki-base record with four lanes:
+// 35 Mbases/s).  Short records are therefore concatenated, one separator byte between them, and
+// factorized together as INDEPENDENT sequences (text.hpp, TermTable::seq_shift): suffixes order by
+// (record, suffix), so no match crosses a record, the separators become literal factors, and the
+// records' factor lists are the stretches between them, rebased to the record's start.
+constexpr uint8_t kBatchSeparator = 0x01;
+constexpr size_t kMergeChunkBases = size_t(1) << 25;  // bases per merged run (5.5 Gbases/s on the device from 2^24 up)
+constexpr size_t kMergeLanes = 2;  // runs in flight per device: one gathers / downloads while the other computes
+
+// smallest j with recs[j].start >= the position of separator k: the separator's own literal factor
+__global__ void batch_bounds_kernel(const nolzss_factor *__restrict__ recs, uint32_t z,
+                                    const uint32_t *__restrict__ seps, uint32_t nsep, uint32_t *__restrict__ fidx,
+                                    uint32_t *__restrict__ err) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nsep) return;
+    const uint64_t target = seps[k];
+    uint32_t lo = 0, hi = z;
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (recs[mid].start >= target)
+            hi = mid;
+        else
+            lo = mid + 1;
+    }
+    fidx[k] = lo;
+    // a separator matches nothing: it must be a factor of length 1 that starts exactly there
+    if (lo >= z || recs[lo].start != target || recs[lo].length != 1) atomicOr(err, 1u);
+}
+
+// record-relative coordinates: start and ref minus the first position of the factor's record
+__global__ void batch_rebase_kernel(nolzss_factor *__restrict__ recs, uint32_t z, TermTable terms) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= z) return;
+    const uint64_t p = recs[j].start;
+    const uint32_t k = term_lower_bound(terms, (uint32_t)p);
+    const uint64_t base = k ? (uint64_t)terms.pos[k - 1] + 1 : 0;
+    recs[j].start = p - base;
+    recs[j].ref -= base;
+}
+
+// Factorizes records ids[0..c) (all non-empty) in one run.  Returns false, with nothing written, when
+// the records hold anything but A/C/G/T.  Factors of all records arrive in ONE malloc'ed block
+// (appended to `blocks`); fs[id] points into it.
+// pinned upload buffer of the context (kept: pinning costs more than the copy it speeds up)
+uint8_t *host_stage(Context &ctx, size_t bytes) {
+    if (bytes > ctx.h_stage_cap) {
+        if (ctx.h_stage) (void)hipHostFree(ctx.h_stage);
+        ctx.h_stage = nullptr;
+        ctx.h_stage_cap = 0;
+        const size_t cap = (bytes + (size_t(1) << 22)) & ~((size_t(1) << 22) - 1);
+        HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&ctx.h_stage), cap));
+        ctx.h_stage_cap = cap;
+    }
+    return ctx.h_stage;
+}
+
+// host memory for a block of factor records: large blocks on transparent huge pages, where the
+// first touch of the download costs one fault per 2 MiB instead of one per 4 KiB
+void *alloc_factor_block(size_t bytes) {
+    constexpr size_t kHuge = size_t(1) << 21;
+    if (bytes >= 4 * kHuge) {
+        void *p = nullptr;
+        if (posix_memalign(&p, kHuge, (bytes + kHuge - 1) & ~(kHuge - 1)) == 0 && p) {
+            (void)madvise(p, (bytes + kHuge - 1) & ~(kHuge - 1), MADV_HUGEPAGE);
+            return p;
+        }
+    }
+    return std::malloc(bytes);
+}
+
+bool run_merged_chunk(Context &ctx, const uint8_t *const *texts, const size_t *lens, const std::vector<size_t> &ids,
+                      size_t *zs, nolzss_factor **fs, std::vector<void *> *blocks) {
+    const bool trace = getenv("NOLZSS_TRACE") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
+    const size_t c = ids.size();
+    size_t n = c - 1;
+    for (size_t j : ids) n += lens[j];
+    uint8_t *host = host_stage(ctx, n);
+    std::vector<uint32_t> seps;
+    seps.reserve(c - 1);
+    {
+        size_t at = 0;
+        for (size_t k = 0; k < c; ++k) {
+            std::memcpy(host + at, texts[ids[k]], lens[ids[k]]);
+            at += lens[ids[k]];
+            if (k + 1 < c) {
+                seps.push_back((uint32_t)at);
+                host[at++] = kBatchSeparator;
+            }
+        }
+    }
+    const double t_concat = since();
+    Arena &arena = ctx.arena;
+    hipStream_t s = ctx.stream;
+    arena.reserve(arena_bytes_for(n) + n + 16 * c + (size_t(1) << 20));
+    const size_t mark = arena.mark();
+    struct Rewind {
+        Arena &a;
+        size_t m;
+        ~Rewind() { a.rewind(m); }
+    } rewind{arena, mark};
+    uint8_t *d_text = arena.alloc<uint8_t>(n);
+    HIP_CHECK(hipMemcpyAsync(d_text, host, n, hipMemcpyHostToDevice, s));
+    PackedText text;
+    if (!pack_independent_text(ctx, d_text, n, seps, text)) return false;
+    uint32_t *sa = arena.alloc<uint32_t>(n);
+    uint32_t *isa = arena.alloc<uint32_t>(n);
+    uint32_t *lcp = arena.alloc<uint32_t>(n + 1);
+    build_suffix_array(ctx, text, sa, isa, lcp);
+    const Pyramid Psa = build_pyramid(sa, (uint32_t)n, false, arena, s);
+    const Pyramid Plcp = build_lcp_pyramid(ctx, text, sa, lcp);
+    uint32_t *lstar = arena.alloc<uint32_t>(n);
+    build_lstar(ctx, (uint32_t)n, sa, isa, lcp, Psa, Plcp, lstar);
+    void *d_recs = nullptr;
+    const uint32_t z = resolve_chain(ctx, (uint32_t)n, 0, lstar, sa, isa, lcp, Psa, Plcp, &d_recs);
+    nolzss_factor *recs = static_cast<nolzss_factor *>(d_recs);
+    // where the records' factor lists start and end
+    std::vector<uint32_t> fidx(c, z);
+    if (c > 1) {
+        uint32_t *d_fidx = arena.alloc<uint32_t>(c);
+        HIP_CHECK(hipMemsetAsync(d_fidx + (c - 1), 0, sizeof(uint32_t), s));  // error flag
+        batch_bounds_kernel<<<(unsigned)div_up(c - 1, 256), 256, 0, s>>>(recs, z, text.terms.pos, (uint32_t)(c - 1),
+                                                                         d_fidx, d_fidx + (c - 1));
+        KERNEL_CHECK();
+        HIP_CHECK(hipMemcpyAsync(fidx.data(), d_fidx, c * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        if (fidx[c - 1]) throw HipError("merged batch: a separator is not a literal factor");
+        fidx[c - 1] = z;
+    }
+    nolzss_factor *block = nullptr;
+    if (fs && z) {
+        batch_rebase_kernel<<<(unsigned)div_up(z, 256), 256, 0, s>>>(recs, z, text.terms);
+        KERNEL_CHECK();
+        block = static_cast<nolzss_factor *>(alloc_factor_block(sizeof(nolzss_factor) * (size_t)z));
+        if (!block) throw std::bad_alloc();
+        const hipError_t e = hipMemcpyAsync(block, recs, sizeof(nolzss_factor) * (size_t)z, hipMemcpyDeviceToHost, s);
+        if (e != hipSuccess) {
+            std::free(block);
+            HIP_CHECK(e);
+        }
+    }
+    const hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+        std::free(block);
+        HIP_CHECK(e);
+    }
+    ctx.prof.collect();
+    if (trace)
+        fprintf(stderr, "[nolzss] merged batch run: %zu records, %zu symbols, %u factors: gather %.1f ms, device%s %.1f ms\n",
+                c, n, z, t_concat, block ? " + download" : "", since() - t_concat);
+    if (block) blocks->push_back(block);
+    for (size_t k = 0; k < c; ++k) {
+        const uint32_t a = k ? fidx[k - 1] + 1 : 0, b = fidx[k];
+        zs[ids[k]] = b - a;
+        if (fs) fs[ids[k]] = (block && b > a) ? block + a : nullptr;
+    }
+    return true;
+}
+
+std::atomic<uint64_t> g_merged_records{0}, g_single_records{0};
+
+// blocks behind the factor arrays of a batch result (nolzss_free_batch)
+std::mutex g_batch_mu;
+std::map<nolzss_factor **, std::vector<void *>> g_batch_blocks;
+
+size_t merge_below() {  // records shorter than this are merged (0: never)
+    const char *e = getenv("NOLZSS_BATCH_MERGE_BELOW");
+    return e ? (size_t)atoll(e) : (size_t(1) << 21);
+}
+
+// The shared worker of the batch entry points: factorizes m records, zs[j] factors each; fs (optional)
+// receives the arrays, every malloc'ed block behind them is appended to `blocks`.
+void factorize_many(const uint8_t *const *texts, const size_t *lens, size_t m, const int *devices, size_t n_dev,
+                    size_t *zs, nolzss_factor **fs, std::vector<void *> &blocks) {
+    // 1. which records are merged: short, non-empty ones, in chunks of consecutive records
+    const size_t below = merge_below();
+    std::vector<size_t> singles;
+    std::vector<std::vector<size_t>> chunks;
+    {
+        // equal shares: as many runs as the limit asks for, each with its part of the bases
+        size_t short_bases = 0;
+        for (size_t j = 0; j < m; ++j)
+            if (lens[j] && lens[j] < below) short_bases += lens[j] + 1;
+        const size_t runs = div_up(short_bases ? short_bases : 1, kMergeChunkBases);
+        const size_t share = div_up(short_bases, runs);
+        std::vector<size_t> cur;
+        size_t cur_bases = 0;
+        for (size_t j = 0; j < m; ++j) {
+            if (lens[j] == 0) continue;  // z = 0
+            if (lens[j] >= below) {
+                singles.push_back(j);
+                continue;
+            }
+            cur.push_back(j);
+            cur_bases += lens[j] + 1;
+            if (cur_bases >= share || cur.size() >= (size_t(1) << 23)) {
+                chunks.push_back(std::move(cur));
+                cur.clear();
+                cur_bases = 0;
+            }
+        }
+        if (!cur.empty()) chunks.push_back(std::move(cur));
+        for (auto it = chunks.begin(); it != chunks.end();)
+            if (it->size() < 2) {  // nothing to merge with
+                singles.push_back((*it)[0]);
+                it = chunks.erase(it);
+            } else {
+                ++it;
+            }
+    }
+    std::mutex out_mu;
+    // 2. merged chunks: kMergeLanes host threads per device, each with its own stream and arena
+    if (!chunks.empty()) {
+        const size_t workers = n_dev * kMergeLanes;
+        std::vector<int> status(workers, NOLZSS_OK);
+        std::vector<std::string> messages(workers);
+        std::atomic<size_t> next{0};
+        auto worker = [&](size_t w) {
+            status[w] = guarded([&] {
+                Session ses(devices[w % n_dev], nullptr, (int)(w / n_dev));  // the devices first, then their second lanes
+                for (;;) {
+                    const size_t k = next.fetch_add(1);
+                    if (k >= chunks.size()) break;
+                    std::vector<void *> mine;
+                    const bool ok = run_merged_chunk(ses.ctx(), texts, lens, chunks[k], zs, fs, &mine);
+                    std::lock_guard<std::mutex> lk(out_mu);
+                    if (ok) {
+                        blocks.insert(blocks.end(), mine.begin(), mine.end());
+                        g_merged_records += chunks[k].size();
+                    } else  // other alphabets: one by one
+                        singles.insert(singles.end(), chunks[k].begin(), chunks[k].end());
+                }
+            });
+            if (status[w] != NOLZSS_OK) messages[w] = g_error;
+        };
+        std::vector<std::thread> threads;
+        for (size_t w = 0; w < workers && w < chunks.size(); ++w) threads.emplace_back(worker, w);
+        for (auto &t : threads) t.join();
+        for (size_t w = 0; w < workers; ++w)
+            if (status[w] != NOLZSS_OK) throw std::runtime_error("batch worker failed: " + messages[w]);
+    }
+    if (singles.empty()) return;
+    // 3. the others one by one: longest-processing-time-first assignment of sequences to devices
+    std::stable_sort(singles.begin(), singles.end(), [&](size_t a, size_t b) { return lens[a] > lens[b]; });
+    std::vector<std::vector<size_t>> plan(n_dev);
+    std::vector<size_t> load(n_dev, 0);
+    for (size_t j : singles) {
+        const size_t d = (size_t)(std::min_element(load.begin(), load.end()) - load.begin());
+        plan[d].push_back(j);
+        load[d] += lens[j];
+    }
+    // Several pipelines per device: a 4 Mi-base sequence neither fills the GPU for long nor
+    // hides its own launch / read-back gaps, so each device runs `lanes` sequences at a time,
+    // every lane with its own stream and arena, fed from the device's queue.
+    static const size_t lanes = [] {
+        const char *e = getenv("NOLZSS_BATCH_LANES");
+        const long v = e ? atol(e) : 4;
+        return (size_t)(v < 1 ? 1 : (v > kMaxLanes ? kMaxLanes : v));
+    }();
+    std::vector<int> status(n_dev * lanes, NOLZSS_OK);
+    std::vector<std::string> messages(n_dev * lanes);
+    std::vector<std::atomic<size_t>> next(n_dev);
+    for (auto &a : next) a.store(0);
+    auto worker = [&](size_t d, size_t lane) {
+        const size_t w = d * lanes + lane;
+        status[w] = guarded([&] {
+            Session ses(devices[d], nullptr, (int)lane);
+            for (;;) {
+                const size_t k = next[d].fetch_add(1);
+                if (k >= plan[d].size()) break;
+                const size_t j = plan[d][k];
+                zs[j] = run_plain_host(ses.ctx(), texts[j], lens[j], 0, fs ? &fs[j] : nullptr, nullptr);
+                ++g_single_records;
+                if (fs && fs[j]) {
+                    std::lock_guard<std::mutex> lk(out_mu);
+                    blocks.push_back(fs[j]);
+                }
+            }
+        });
+        if (status[w] != NOLZSS_OK) messages[w] = g_error;
+    };
+    {
+        std::vector<std::thread> threads;
+        for (size_t d = 0; d < n_dev; ++d)
+            for (size_t lane = 0; lane < lanes; ++lane)
+                if (lane < plan[d].size()) threads.emplace_back(worker, d, lane);
+        for (auto &t : threads) t.join();
+    }
+    for (size_t d = 0; d < status.size(); ++d)
+        if (status[d] != NOLZSS_OK) throw std::runtime_error("batch worker failed: " + messages[d]);
+}
+
+}  // namespace
+}  // namespace nolzss
+
+extern "C" {
+
 int nolzss_factorize_batch(const uint8_t *const *texts, const size_t *lens, size_t m, const int *devices,
                            size_t n_dev, nolzss_factor ***out, size_t **z) {
     return guarded([&] {
@@ -1080,69 +1411,46 @@ int nolzss_factorize_batch(const uint8_t *const *texts, const size_t *lens, size
             std::free(fs);
             throw std::bad_alloc();
         }
-        // longest-processing-time-first assignment of sequences to devices
-        std::vector<size_t> order(m);
-        std::iota(order.begin(), order.end(), size_t(0));
-        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return lens[a] > lens[b]; });
-        std::vector<std::vector<size_t>> plan(n_dev);
-        std::vector<size_t> load(n_dev, 0);
-        for (size_t j : order) {
-            const size_t d = (size_t)(std::min_element(load.begin(), load.end()) - load.begin());
-            plan[d].push_back(j);
-            load[d] += lens[j];
-        }
-        // Several pipelines per device: a 4 Mi-base sequence neither fills the GPU for long nor
-        // hides its own launch / read-back gaps, so each device runs `lanes` sequences at a time,
-        // every lane with its own stream and arena, fed from the device's queue.
-        static const size_t lanes = [] {
-            const char *e = getenv("NOLZSS_BATCH_LANES");
-            const long v = e ? atol(e) : 4;
-            return (size_t)(v < 1 ? 1 : (v > kMaxLanes ? kMaxLanes : v));
-        }();
-        std::vector<int> status(n_dev * lanes, NOLZSS_OK);
-        std::vector<std::string> messages(n_dev * lanes);
-        std::vector<std::atomic<size_t>> next(n_dev);
-        for (auto &a : next) a.store(0);
-        auto worker = [&](size_t d, size_t lane) {
-            const size_t w = d * lanes + lane;
-            status[w] = guarded([&] {
-                Session ses(devices[d], nullptr, (int)lane);
-                for (;;) {
-                    const size_t k = next[d].fetch_add(1);
-                    if (k >= plan[d].size()) break;
-                    const size_t j = plan[d][k];
-                    zs[j] = run_plain_host(ses.ctx(), texts[j], lens[j], 0, fs ? &fs[j] : nullptr, nullptr);
-                }
-            });
-            if (status[w] != NOLZSS_OK) messages[w] = g_error;
-        };
-        {
-            std::vector<std::thread> threads;
-            for (size_t d = 0; d < n_dev; ++d)
-                for (size_t lane = 0; lane < lanes; ++lane)
-                    if (lane < plan[d].size()) threads.emplace_back(worker, d, lane);
-            for (auto &t : threads) t.join();
-        }
-        for (size_t d = 0; d < status.size(); ++d)
-            if (status[d] != NOLZSS_OK) {
-                if (fs) {
-                    for (size_t j = 0; j < m; ++j) std::free(fs[j]);
-                    std::free(fs);
-                }
-                std::free(zs);
-                throw std::runtime_error("batch worker failed: " + messages[d]);
+        std::vector<void *> blocks;
+        try {
+            factorize_many(texts, lens, m, devices, n_dev, zs, fs, blocks);
+            if (fs) {
+                std::lock_guard<std::mutex> lk(g_batch_mu);
+                g_batch_blocks[fs] = std::move(blocks);
             }
+        } catch (...) {
+            for (void *b : blocks) std::free(b);
+            std::free(fs);
+            std::free(zs);
+            throw;
+        }
         *z = zs;
         if (out) *out = fs;
     });
 }
 
+// out[j] may point INTO a block shared by many records: only this function knows what to free
 void nolzss_free_batch(nolzss_factor **out, size_t *z, size_t m) {
+    (void)m;
     if (out) {
-        for (size_t j = 0; j < m; ++j) std::free(out[j]);
+        std::vector<void *> blocks;
+        {
+            std::lock_guard<std::mutex> lk(g_batch_mu);
+            auto it = g_batch_blocks.find(out);
+            if (it != g_batch_blocks.end()) {
+                blocks = std::move(it->second);
+                g_batch_blocks.erase(it);
+            }
+        }
+        for (void *b : blocks) std::free(b);
         std::free(out);
     }
     std::free(z);
+}
+
+void nolzss_debug_batch_counters(uint64_t *merged_records, uint64_t *single_records) {
+    if (merged_records) *merged_records = g_merged_records.load();
+    if (single_records) *single_records = g_single_records.load();
 }
 
 int nolzss_profile_enable(int device, int on) {

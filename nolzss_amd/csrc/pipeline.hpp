@@ -4,6 +4,8 @@
 #include "pyramid.hpp"
 #include "text.hpp"
 
+#include <vector>
+
 namespace nolzss {
 
 struct Context {
@@ -12,6 +14,8 @@ struct Context {
     Arena arena;
     Profiler prof;
     uint32_t *h_pinned = nullptr;  // 64 words of pinned host memory for small read-backs
+    uint8_t *h_stage = nullptr;    // pinned host staging for uploads (grow-only, merged batch)
+    size_t h_stage_cap = 0;
 
     Profiler *profiler() { return prof.enabled() ? &prof : nullptr; }
     // copy `count` (<= 64) device words to host and wait for them
@@ -23,6 +27,10 @@ struct Context {
 // A text of upper-case nucleotides plus at most 250 byte values that occur exactly once each is
 // packed SEGMENTED at 2 bits per base, the unique bytes becoming terminators (text.hpp).
 PackedText pack_text(Context &ctx, const uint8_t *d_text, size_t n);
+// Many INDEPENDENT nucleotide sequences in one text (text.hpp, TermTable::seq_shift): records of
+// A/C/G/T with one separator byte at each of the sorted positions.  false if the text holds other bytes.
+bool pack_independent_text(Context &ctx, const uint8_t *d_text, size_t n, const std::vector<uint32_t> &separators,
+                           PackedText &out);
 
 // ---- stages 2+3: suffix array (prefix doubling over radix sorts) and LCP array -------------
 // sa[r] = start of the r-th smallest suffix, isa[i] = rank of suffix i PLUS ONE (n u32 each);

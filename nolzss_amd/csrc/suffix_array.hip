@@ -300,6 +300,7 @@ struct RegroupArgs {
     SegView seg;
     uint32_t num_tiles;
     uint32_t short_tag;       // round 0: elements whose length tag is below this are groups of their own
+    uint32_t seq_shift;       // round 0, independent sequences: key bits from here up = number of the sequence
     int sa_is_current;        // the producer has already written the new order into sa (direct round)
     const uint32_t *grp;      // later rounds: (group head slot, secondary key) per list element
     const uint32_t *lo;
@@ -429,6 +430,7 @@ __global__ __launch_bounds__(kFuseThreads) void regroup_kernel(RegroupArgs A) {
                 uint32_t ls = x ? (uint32_t)__clzll((long long)x) / (uint32_t)A.bits : 0xffffffffu;
                 ls = ls < ta ? ls : ta;
                 l = ls < tb ? ls : tb;
+                if (A.seq_shift && (v >> A.seq_shift) != (pv >> A.seq_shift)) l = 0;  // different sequences
             }
             A.lcp[a] = l;
         }
@@ -843,7 +845,8 @@ uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *grp, const 
                  uint32_t *d_total, uint32_t *lcp = nullptr, int sym_bits = 0, int tag_bits = 0, int bits = 0,
                  const uint32_t *lcp_list = nullptr, int low_bits = 0, uint32_t dbl_h = 0,
                  uint32_t *rank_by_slot = nullptr, const Pyramid *plcp = nullptr, const uint32_t *keys32 = nullptr,
-                 const SegView *seg = nullptr, uint32_t short_tag = 0, bool sa_is_current = false) {
+                 const SegView *seg = nullptr, uint32_t short_tag = 0, bool sa_is_current = false,
+                 uint32_t seq_shift = 0) {
     hipStream_t s = ctx.stream;
     const size_t pmark = ctx.arena.mark();
     // doubling boundaries read range minima of the LCP values decided so far
@@ -858,6 +861,7 @@ uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *grp, const 
         HIP_CHECK(hipMemsetAsync(desc, 0, (2 * tiles + 1) * sizeof(uint64_t), s));
         RegroupArgs A{};
         A.short_tag = short_tag;
+        A.seq_shift = seq_shift;
         A.sa_is_current = sa_is_current ? 1 : 0;
         A.keys = keys; A.keys32 = keys32; A.seg = seg ? *seg : SegView{}; A.num_tiles = (uint32_t)tiles; A.grp = grp; A.lo = lo; A.vals = vals; A.act_slot = act_slot; A.m = m;
         A.sa = sa; A.rank_val = rank_val; A.rank_by_slot = rank_by_slot; A.lcp = lcp;
@@ -886,6 +890,9 @@ uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *grp, const 
 }
 
 }  // namespace
+
+void finish_packing(Context &ctx, PackedText &t, const uint8_t *d_text, size_t n,
+                    const std::vector<uint32_t> &terminators, const unsigned long long *presence);
 
 PackedText pack_text(Context &ctx, const uint8_t *d_text, size_t n) {
     hipStream_t s = ctx.stream;
@@ -941,7 +948,33 @@ PackedText pack_text(Context &ctx, const uint8_t *d_text, size_t n) {
             }
         }
     }
-    // terminator table: the given positions (sorted) and always the end of the text
+    finish_packing(ctx, t, d_text, n, terminators, presence);
+    return t;
+}
+
+namespace {
+// coarse index of a long terminator table (text.hpp): one binary search per 4096-symbol block
+__global__ __launch_bounds__(kThreads) void term_coarse_kernel(const uint32_t *__restrict__ pos, uint32_t count,
+                                                               uint32_t blocks, uint32_t *__restrict__ coarse) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= blocks) return;
+    const uint64_t p = (uint64_t)b << kTermBlockShift;
+    uint32_t lo = 0, hi = count - 1;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if ((uint64_t)pos[mid] >= p)
+            hi = mid;
+        else
+            lo = mid + 1;
+    }
+    coarse[b] = lo;
+}
+}  // namespace
+
+// terminator table (the given sorted positions and always the end of the text), then the packed words
+void finish_packing(Context &ctx, PackedText &t, const uint8_t *d_text, size_t n,
+                    const std::vector<uint32_t> &terminators, const unsigned long long *presence) {
+    hipStream_t s = ctx.stream;
     std::vector<uint32_t> table = terminators;
     table.push_back((uint32_t)n);
     uint32_t *d_terms = ctx.arena.alloc<uint32_t>(table.size());
@@ -949,6 +982,13 @@ PackedText pack_text(Context &ctx, const uint8_t *d_text, size_t n) {
     HIP_CHECK(hipStreamSynchronize(s));  // table is a local vector
     t.terms.pos = d_terms;
     t.terms.count = (uint32_t)table.size();
+    if (table.size() > 256) {
+        const uint32_t blocks = (uint32_t)(n >> kTermBlockShift) + 3;
+        uint32_t *coarse = ctx.arena.alloc<uint32_t>(blocks);
+        term_coarse_kernel<<<(unsigned)div_up(blocks, kThreads), kThreads, 0, s>>>(d_terms, t.terms.count, blocks, coarse);
+        KERNEL_CHECK();
+        t.terms.coarse = coarse;
+    }
 
     const size_t nwords = div_up(n * (size_t)t.bits, 64) + kRefineWords + 4;  // zero pad: windows read past the end
     uint64_t *words = ctx.arena.alloc<uint64_t>(nwords);
@@ -963,7 +1003,37 @@ PackedText pack_text(Context &ctx, const uint8_t *d_text, size_t n) {
         KERNEL_CHECK();
     }
     t.words = words;
-    return t;
+}
+
+// The merged per-sequence batch: d_text holds upper-case nucleotide records with ONE separator byte
+// (any byte that is not a nucleotide) at each of the given sorted positions.  Returns false -- and
+// packs nothing -- if the text holds anything else (the caller then takes the records one by one).
+bool pack_independent_text(Context &ctx, const uint8_t *d_text, size_t n, const std::vector<uint32_t> &separators,
+                           PackedText &t) {
+    hipStream_t s = ctx.stream;
+    uint32_t *count = ctx.arena.alloc<uint32_t>(1);
+    uint32_t *pos = ctx.arena.alloc<uint32_t>(kMaxTermScan);
+    HIP_CHECK(hipMemsetAsync(count, 0, sizeof(uint32_t), s));
+    size_t g = div_up(n, kThreads);
+    if (g > 8192) g = 8192;
+    find_terminators_kernel<<<(unsigned)g, kThreads, 0, s>>>(d_text, (uint32_t)n, count, pos);
+    KERNEL_CHECK();
+    uint32_t h_count = 0;
+    ctx.read_back(count, &h_count, 1);
+    // the separators are not nucleotides, so an equal count means: nothing else is there
+    if (h_count != (uint32_t)separators.size()) return false;
+    unsigned long long h_presence[4] = {0, 0, 0, 0};
+    for (unsigned char c : {'A', 'C', 'G', 'T'}) h_presence[c >> 6] |= 1ull << (c & 63);
+    unsigned long long *presence = ctx.arena.alloc<unsigned long long>(4);
+    HIP_CHECK(hipMemcpy(presence, h_presence, 32, hipMemcpyHostToDevice));
+    t = PackedText{};
+    t.n = (uint32_t)n;
+    t.sigma = 4;
+    t.bits = 2;
+    t.segmented = true;
+    finish_packing(ctx, t, d_text, n, separators, presence);
+    if (!separators.empty()) t.terms.seq_shift = 40;  // KeyLayout<2>: 17 bases + 6-bit tag
+    return true;
 }
 
 // finishes the LCP entries that round 0 could not decide: both suffixes share their first
@@ -999,10 +1069,19 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     // meet a terminator inside the key window and tie on the key are already in their final order
     // after the (stable) sort -- ascending start = ascending terminator -- and the regroup kernel
     // makes each of them a group of its own.
-    const bool dna_fast = text.bits == 2 && n >= dna_fast_min;
+    // independent sequences (merged batch): the number of the sequence sits above the plain 40-bit key
+    const bool independent = text.terms.seq_shift != 0;
+    int seq_bits = 0;
+    if (independent) {
+        if (text.bits != 2 || text.terms.seq_shift != 40) throw HipError("suffix array: independent sequences need the 2-bit key layout");
+        while (seq_bits < 24 && (1u << seq_bits) < text.terms.count) ++seq_bits;
+        if ((1u << seq_bits) < text.terms.count) throw HipError("suffix array: too many independent sequences");
+    }
+    const bool dna_fast = text.bits == 2 && n >= dna_fast_min && !independent;
     int key_passes = 0;
     {
         int kb = dna_fast ? KeyLayout<2>::kSyms * 2 + KeyLayout<2>::kTagBits
+                 : independent ? 40 + seq_bits
                  : text.segmented ? kSegSyms * 2 + kSegTagBits + kSegTermBits
                  : text.bits == 2 ? KeyLayout<2>::kSyms * 2 + KeyLayout<2>::kTagBits
                  : text.bits == 4 ? KeyLayout<4>::kSyms * 4 + KeyLayout<4>::kTagBits
@@ -1046,6 +1125,7 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         default: key_bits += KeyLayout<8>::kTagBits; break;
         }
         if (text.segmented) key_bits = kSegSyms * 2 + kSegTagBits + kSegTermBits;
+        if (independent) key_bits = 40 + seq_bits;
         int shifts0[8], np0 = 0;
         for (int b = 0; b < key_bits && np0 < 8; b += kRadixBits) shifts0[np0++] = b;
         ProfScope ps(ctx.profiler(), "sa_sort_initial", s);
@@ -1066,7 +1146,7 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     case 4: tag_bits = KeyLayout<4>::kTagBits; break;
     default: tag_bits = KeyLayout<8>::kTagBits; break;
     }
-    if (text.segmented && !dna_fast) {  // [kSegSyms symbols][5-bit tag][8-bit terminator index]
+    if (text.segmented && !dna_fast && !independent) {  // [kSegSyms symbols][5-bit tag][8-bit terminator index]
         k_syms = kSegSyms;
         tag_bits = kSegTagBits;
         low_bits = kSegTermBits;
@@ -1075,7 +1155,8 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
                                act_grp[0], scratch_idx, scratch_val, rank_val, d_total, lcp,
                                k_syms * text.bits, tag_bits, text.bits, nullptr, low_bits, 0, rank_by_slot, nullptr,
                                dna_fast ? reinterpret_cast<const uint32_t *>(keys[cur]) : nullptr,
-                               dna_fast ? &seg : nullptr, dna_fast ? (uint32_t)k_syms : 0u);
+                               dna_fast ? &seg : nullptr, dna_fast ? (uint32_t)k_syms : 0u, false,
+                               text.terms.seq_shift);
 
     // ---- doubling rounds ------------------------------------------------------------------
     // in the rounds the 8n-byte key buffers are reused as four u32 arrays

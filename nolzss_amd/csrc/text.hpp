@@ -16,14 +16,29 @@ namespace nolzss {
 // nearer terminator, and at a terminator the suffix that reaches it first is the smaller one
 // (equal distance: the lower terminator index) -- the order the reference's unique sentinels give
 // up to a relabelling of symbols, which the factorization does not depend on.
+//
+// INDEPENDENT sequences (the merged per-sequence batch, api.hip): seq_shift != 0 puts the terminator
+// index of a suffix -- the number of its sequence -- above bit seq_shift of its round-0 sort key.
+// Suffixes then order by (sequence, suffix): the suffix array is the concatenation of the suffix
+// arrays of the sequences, the LCP between neighbours of different sequences is 0, and every later
+// stage (candidates, cursor, factor records) stays inside one sequence without knowing about it.
+constexpr int kTermBlockShift = 12;
 struct TermTable {
     const uint32_t *pos = nullptr;  // sorted terminator positions, pos[count-1] = n
     uint32_t count = 0;
+    // optional (tables with many terminators): coarse[b] = smallest k with pos[k] >= b << kTermBlockShift,
+    // clamped to count - 1; (n >> kTermBlockShift) + 3 entries
+    const uint32_t *coarse = nullptr;
+    uint32_t seq_shift = 0;
 };
 
 // smallest k with pos[k] >= p (exists for every suffix start p < n)
 __device__ __forceinline__ uint32_t term_lower_bound(const TermTable &t, uint32_t p) {
     uint32_t lo = 0, hi = t.count - 1;
+    if (t.coarse) {
+        lo = t.coarse[p >> kTermBlockShift];
+        hi = t.coarse[(p >> kTermBlockShift) + 1];
+    }
     while (lo < hi) {
         const uint32_t mid = (lo + hi) >> 1;
         if (t.pos[mid] >= p)
@@ -139,7 +154,7 @@ __device__ __forceinline__ uint64_t initial_key(const uint64_t *__restrict__ wor
     const uint64_t w = sym_word<BITS>(words, i);
     const uint32_t k = term_lower_bound(terms, i);
     const uint32_t lim = terms.pos[k] - i;  // symbols before the next terminator
-    if (BITS == 2 && segmented) {
+    if (BITS == 2 && segmented && terms.seq_shift == 0) {
         const uint32_t tag = lim < (uint32_t)kSegSyms ? lim : (uint32_t)kSegSyms;
         uint64_t sym = w >> (64 - kSegSyms * 2);
         if (tag < (uint32_t)kSegSyms) sym &= ~((1ull << (2 * (kSegSyms - tag))) - 1ull);
@@ -152,7 +167,8 @@ __device__ __forceinline__ uint64_t initial_key(const uint64_t *__restrict__ wor
     uint64_t sym = w >> (64 - K * BITS);
     // symbols behind a terminator belong to the next segment (zero behind the end of the text)
     if (tag < (uint32_t)K) sym &= ~((1ull << (BITS * (K - (int)tag))) - 1ull);
-    return (sym << TAG) | tag;
+    const uint64_t key = (sym << TAG) | tag;
+    return terms.seq_shift ? key | ((uint64_t)k << terms.seq_shift) : key;
 }
 
 }  // namespace nolzss

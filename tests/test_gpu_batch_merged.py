@@ -1,0 +1,152 @@
+"""GPU parity of the MERGED batch: short nucleotide records factorized together in one pipeline run
+as independent sequences (api.hip, run_merged_chunk) must give, record by record, exactly what the
+oracle -- and the one-record-at-a-time path -- gives.
+reference: the per-sequence loop of genomics.read_nucleotide_fasta (src/noLZSS/genomics/fasta.py:110-122)
+"""
+import os
+
+import numpy as np
+import pytest
+
+import gen
+import oracle_lib as oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def native():
+    from nolzss_amd import _noLZSS
+    assert _noLZSS.device_count() >= 1, "no MI355X visible"
+    return _noLZSS
+
+
+class merge_below:
+    """NOLZSS_BATCH_MERGE_BELOW for the duration of a block (the library reads it on every call)."""
+
+    def __init__(self, value):
+        self.value = value
+
+    def __enter__(self):
+        self.old = os.environ.get("NOLZSS_BATCH_MERGE_BELOW")
+        if self.value is None:
+            os.environ.pop("NOLZSS_BATCH_MERGE_BELOW", None)
+        else:
+            os.environ["NOLZSS_BATCH_MERGE_BELOW"] = str(self.value)
+
+    def __exit__(self, *exc):
+        if self.old is None:
+            os.environ.pop("NOLZSS_BATCH_MERGE_BELOW", None)
+        else:
+            os.environ["NOLZSS_BATCH_MERGE_BELOW"] = self.old
+
+
+def _same(a, b):
+    return len(a) == len(b) and all(np.array_equal(a[k], b[k]) for k in ("start", "length", "ref"))
+
+
+def _records(rng, count, lo, hi, repeat=True):
+    recs = []
+    for k in range(count):
+        n = int(rng.integers(lo, hi + 1))
+        recs.append(gen.repeat_dna(n, seed=7000 + k) if repeat and n >= 64 else gen.random_dna(n, seed=7000 + k))
+    return recs
+
+
+def test_merged_equals_oracle_record_by_record(native):
+    rng = np.random.default_rng(11)
+    recs = _records(rng, 300, 1, 3000)
+    # records that are copies of each other must not see each other; runs; the four one-base records
+    recs += [recs[5].copy(), recs[5].copy(), recs[17][:100].copy()]
+    recs += [np.frombuffer(b"A" * 777, dtype=np.uint8), np.frombuffer(b"ACGT" * 300, dtype=np.uint8)]
+    recs += [np.frombuffer(c, dtype=np.uint8) for c in (b"A", b"C", b"G", b"T", b"AA", b"TTTTTTTTTTTTTTTTTTTTTTTTT")]
+    merged0, single0 = native.debug_batch_counters()
+    counts, arrays = native.factorize_batch(recs, want_factors=True)
+    merged1, single1 = native.debug_batch_counters()
+    assert (merged1 - merged0, single1 - single0) == (len(recs), 0)  # the merged path is what ran
+    for j, r in enumerate(recs):
+        exp = oracle.factors_array(r)
+        assert counts[j] == len(exp), j
+        assert _same(arrays[j], exp), j
+    counts2, none = native.factorize_batch(recs, want_factors=False)
+    assert counts2 == counts and none is None
+
+
+def test_merged_equals_one_by_one_on_larger_records(native):
+    rng = np.random.default_rng(12)
+    recs = _records(rng, 40, 20000, 300000)
+    recs += [recs[3].copy()]
+    merged0, single0 = native.debug_batch_counters()
+    with merge_below(0):
+        c1, a1 = native.factorize_batch(recs, want_factors=True)
+    merged1, single1 = native.debug_batch_counters()
+    assert (merged1 - merged0, single1 - single0) == (0, len(recs))
+    c2, a2 = native.factorize_batch(recs, want_factors=True)
+    assert native.debug_batch_counters() == (merged1 + len(recs), single1)
+    assert c1 == c2
+    for j in range(len(recs)):
+        assert _same(a1[j], a2[j]), j
+    for j in (0, 19, 40):
+        assert _same(a2[j], oracle.factors_array(recs[j])), j
+
+
+def test_few_records_and_empty_ones(native):
+    """fewer than 256 separators (plain terminator search), empty records in between, a single record"""
+    recs = [gen.random_dna(500, 1), np.zeros(0, dtype=np.uint8), gen.repeat_dna(4000, 2), gen.random_dna(1, 3),
+            np.zeros(0, dtype=np.uint8)]
+    counts, arrays = native.factorize_batch(recs, want_factors=True)
+    for j, r in enumerate(recs):
+        exp = oracle.factors_array(r) if len(r) else None
+        assert counts[j] == (len(exp) if exp is not None else 0)
+        if exp is not None:
+            assert _same(arrays[j], exp)
+        else:
+            assert len(arrays[j]) == 0
+    one = [gen.repeat_dna(3000, 9)]
+    counts, arrays = native.factorize_batch(one, want_factors=True)
+    assert _same(arrays[0], oracle.factors_array(one[0]))
+
+
+def test_other_alphabets_fall_back(native):
+    """a record with anything but A/C/G/T sends its chunk through the one-by-one path: same results"""
+    rng = np.random.default_rng(13)
+    recs = _records(rng, 50, 10, 2000)
+    recs[20] = np.frombuffer(b"ACGTNNNNACGTNACGTTTGACN" * 20, dtype=np.uint8)
+    recs[31] = np.frombuffer(b"abracadabra" * 9, dtype=np.uint8)
+    recs[32] = np.frombuffer(b"AC\x01GT\x01AC\x01GT", dtype=np.uint8)  # the separator byte inside a record
+    merged0, single0 = native.debug_batch_counters()
+    counts, arrays = native.factorize_batch(recs, want_factors=True)
+    assert native.debug_batch_counters() == (merged0, single0 + len(recs))
+    for j, r in enumerate(recs):
+        assert _same(arrays[j], oracle.factors_array(r)), j
+
+
+def test_chunks_split_and_mix_with_long_records(native):
+    """a merge limit in the middle of the size range: long records one by one, the others merged"""
+    rng = np.random.default_rng(14)
+    recs = _records(rng, 120, 100, 9000)
+    merged0, single0 = native.debug_batch_counters()
+    with merge_below(4000):
+        counts, arrays = native.factorize_batch(recs, want_factors=True)
+    long_ones = sum(1 for r in recs if len(r) >= 4000)
+    assert 0 < long_ones < len(recs)
+    assert native.debug_batch_counters() == (merged0 + len(recs) - long_ones, single0 + long_ones)
+    for j, r in enumerate(recs):
+        assert _same(arrays[j], oracle.factors_array(r)), j
+
+
+@pytest.mark.timeout(600)
+def test_many_short_records(native):
+    """4096 records of 150..6000 bases (one merged run of ~12 Mi bases): a sample against the oracle,
+    every count against the one-by-one path"""
+    rng = np.random.default_rng(15)
+    recs = _records(rng, 4096, 150, 6000)
+    counts, arrays = native.factorize_batch(recs, want_factors=True)
+    for j in rng.choice(len(recs), size=200, replace=False).tolist():
+        assert _same(arrays[j], oracle.factors_array(recs[j])), j
+    with merge_below(0):
+        c1, _ = native.factorize_batch(recs, want_factors=False)
+    assert c1 == counts
+    for j, r in enumerate(recs):  # tilings
+        f = arrays[j]
+        assert f["start"][0] == 0 and int(f["start"][-1] + f["length"][-1]) == len(r)
