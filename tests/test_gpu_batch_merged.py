@@ -150,3 +150,55 @@ def test_many_short_records(native):
     for j, r in enumerate(recs):  # tilings
         f = arrays[j]
         assert f["start"][0] == 0 and int(f["start"][-1] + f["length"][-1]) == len(r)
+
+
+@pytest.mark.timeout(900)
+def test_read_sized_records_by_the_hundred_thousand(native):
+    """200 000 records of 30..300 bases: 18 bits of record number in the sort key (8 radix passes),
+    dozens of separators per 4096-symbol block of the coarse terminator index"""
+    rng = np.random.default_rng(16)
+    base = gen.repeat_dna(1 << 20, seed=99)
+    lens = rng.integers(30, 301, size=200000)
+    offs = rng.integers(0, (1 << 20) - 300, size=200000)
+    recs = [base[o:o + l] for o, l in zip(offs.tolist(), lens.tolist())]
+    merged0, single0 = native.debug_batch_counters()
+    counts, arrays = native.factorize_batch(recs, want_factors=True)
+    assert native.debug_batch_counters() == (merged0 + len(recs), single0)
+    for j in rng.choice(len(recs), size=1500, replace=False).tolist():
+        assert _same(arrays[j], oracle.factors_array(recs[j])), j
+    total = 0
+    for j, f in enumerate(arrays):
+        assert len(f) == counts[j] and f["start"][0] == 0
+        total += int(f["length"].sum())
+    assert total == int(lens.sum())
+
+
+def test_differential_fuzz_of_tiny_records(native):
+    """a few seconds of random batches of very short records over sub-alphabets (long runs, periodic
+    records, records that are prefixes / copies of each other) against the oracle"""
+    import time
+    rng = np.random.default_rng(17)
+    t_end = time.time() + 6.0
+    cases = 0
+    while time.time() < t_end:
+        sigma = int(rng.integers(1, 5))
+        letters = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.permutation(4)[:sigma]]
+        m = int(rng.integers(2, 400))
+        recs = []
+        for _ in range(m):
+            kind = rng.integers(0, 4)
+            n = int(rng.integers(1, 60))
+            if kind == 0 and recs:
+                src = recs[int(rng.integers(0, len(recs)))]
+                r = src[:max(1, int(rng.integers(1, len(src) + 1)))].copy()
+            elif kind == 1:
+                unit = letters[rng.integers(0, sigma, size=int(rng.integers(1, 5)))]
+                r = np.tile(unit, n)[:max(1, n)]
+            else:
+                r = letters[rng.integers(0, sigma, size=n)]
+            recs.append(np.ascontiguousarray(r, dtype=np.uint8))
+        counts, arrays = native.factorize_batch(recs, want_factors=True)
+        for j, r in enumerate(recs):
+            assert _same(arrays[j], oracle.factors_array(r)), (cases, j, bytes(r))
+        cases += 1
+    assert cases >= 5
