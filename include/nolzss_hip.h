@@ -203,6 +203,15 @@ void nolzss_free_fasta_per_sequence_result(nolzss_fasta_per_sequence_result *r);
  *            block shared with other records.  Free ONLY with nolzss_free_batch(). */
 int nolzss_factorize_batch(const uint8_t *const *texts, const size_t *lens, size_t m,
                            const int *devices, size_t n_dev, nolzss_factor ***out, size_t **z);
+/* The same with the reverse complement of every record: record j as factorize_dna_w_rc would
+ * (prepare_multiple_dna_sequences_w_rc({seq}) + factorize_multiple_dna_w_rc, the per-record step of
+ * factorize_fasta_dna_w_rc_per_sequence, fasta_processor.cpp:446-451; lower case accepted, refs of
+ * reverse-complement factors carry NOLZSS_RC_MASK).  Short records are merged in the layout of
+ * factorizer.cpp:128-169 (T1 s T2 s .. Tk s rc(Tk) s .. rc(T1) s) for any number of records, each
+ * record seeing only itself and its own reverse complement.  An invalid nucleotide fails the call
+ * like the reference ("Invalid nucleotide ... found in sequence 0"). */
+int nolzss_factorize_batch_dna_w_rc(const uint8_t *const *texts, const size_t *lens, size_t m,
+                                    const int *devices, size_t n_dev, nolzss_factor ***out, size_t **z);
 void nolzss_free_batch(nolzss_factor **out, size_t *z, size_t m);
 
 /* ---- measurement hooks -------------------------------------------------------------------- */

@@ -84,6 +84,7 @@ def _load():
     lib.nolzss_factorize_batch.argtypes = [
         C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), sz, C.POINTER(C.c_int), sz,
         C.POINTER(C.POINTER(C.c_void_p)), C.POINTER(C.POINTER(C.c_size_t))]
+    lib.nolzss_factorize_batch_dna_w_rc.argtypes = lib.nolzss_factorize_batch.argtypes
     lib.nolzss_free_batch.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), sz]
     lib.nolzss_free_batch.restype = None
     lib.nolzss_profile_enable.argtypes = [C.c_int, C.c_int]
@@ -115,7 +116,7 @@ EXPORTED_SYMBOLS = [
     "nolzss_factorize_dna_rc_w_ref_fasta_files", "nolzss_write_factors_dna_w_reference_fasta_files_to_binary",
     "nolzss_free_batch", "nolzss_profile_enable", "nolzss_profile_reset", "nolzss_profile_report",
     "nolzss_debug_arrays", "nolzss_debug_sort_pairs", "nolzss_debug_scan", "nolzss_debug_arena",
-    "nolzss_debug_batch_counters",
+    "nolzss_debug_batch_counters", "nolzss_factorize_batch_dna_w_rc",
 ]
 
 

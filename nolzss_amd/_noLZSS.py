@@ -151,9 +151,11 @@ def factorize_device(data_ptr: int, n: int, stream: int = 0, emit: int = 2, star
     return z.value, (_take(out, z.value) if emit == 2 else None)
 
 
-def factorize_batch(texts, devices=None, want_factors: bool = True):
+def factorize_batch(texts, devices=None, want_factors: bool = True, with_rc: bool = False):
     """Extension: the per-sequence shard unit of read_nucleotide_fasta
-    (reference: genomics/fasta.py:110-122).  Returns (counts, [factor arrays] or None)."""
+    (reference: genomics/fasta.py:110-122).  Returns (counts, [factor arrays] or None).
+    with_rc: every record as factorize_dna_w_rc would (ref carries RC_MASK for reverse-complement
+    factors; the per-record step of factorize_fasta_dna_w_rc_per_sequence)."""
     devices = list(devices) if devices is not None else [_default_device]
     bufs = [_as_buffer(t) for t in texts]
     m = len(bufs)
@@ -162,8 +164,8 @@ def factorize_batch(texts, devices=None, want_factors: bool = True):
     devs = (C.c_int * len(devices))(*devices)
     out = C.POINTER(C.c_void_p)()
     zs = C.POINTER(C.c_size_t)()
-    check(lib.nolzss_factorize_batch(ptrs, lens, m, devs, len(devices),
-                                     C.byref(out) if want_factors else None, C.byref(zs)))
+    entry = lib.nolzss_factorize_batch_dna_w_rc if with_rc else lib.nolzss_factorize_batch
+    check(entry(ptrs, lens, m, devs, len(devices), C.byref(out) if want_factors else None, C.byref(zs)))
     owner = _BatchResult(out if want_factors else None, zs, m)
     counts = np.ctypeslib.as_array(zs, shape=(m,)).tolist() if m else []
     if not want_factors:

@@ -456,7 +456,8 @@ int nolzss_count_factors_multiple_dna_w_rc(const uint8_t *S, size_t S_len, size_
 
 // noLZSS::factorize_dna_w_rc: one sequence; the prepared string is built on the device so that only
 // the n input bytes cross PCIe
-static void dna_w_rc_common(const uint8_t *text, size_t n, int device, nolzss_factor **out, size_t *z) {
+static void dna_w_rc_common(const uint8_t *text, size_t n, int device, nolzss_factor **out, size_t *z,
+                            int lane = 0) {
     *z = 0;
     if (out) *out = nullptr;
     if (n == 0) return;  // factorizer_core.hpp:143
@@ -464,7 +465,7 @@ static void dna_w_rc_common(const uint8_t *text, size_t n, int device, nolzss_fa
     const size_t m = 2 * n + 2;
     if (m > kMaxText) throw std::invalid_argument("text too long: the device pipeline uses 32-bit indices");
     if (!rc_guards(m, 0)) return;
-    Session ses(device, nullptr);
+    Session ses(device, nullptr, lane);
     Context &ctx = ses.ctx();
     ctx.arena.reserve(arena_bytes_for(m) + m + n);
     uint8_t *d_T = ctx.arena.alloc<uint8_t>(n);
@@ -880,7 +881,7 @@ void write_fasta_file(const char *out_path, const FastaFactors &ff) {
 
 // the batch worker (defined with the merged batch further down)
 void factorize_many(const uint8_t *const *texts, const size_t *lens, size_t m, const int *devices, size_t n_dev,
-                    size_t *zs, nolzss_factor **fs, std::vector<void *> &blocks);
+                    bool with_rc, size_t *zs, nolzss_factor **fs, std::vector<void *> &blocks);
 
 }  // namespace
 }  // namespace nolzss
@@ -1028,7 +1029,7 @@ int nolzss_factorize_fasta_per_sequence(const char *fasta_path, int with_rc, int
         }
         std::memcpy(res.sequence_ids, blob.data(), blob.size());
         res.sequence_ids_bytes = blob.size();
-        // no-rc records go through the batch worker (short ones merged into one device run)
+        // the records go through the batch worker (short ones merged into one device run)
         std::vector<size_t> plain_z(m, 0);
         std::vector<nolzss_factor *> plain_f(m, nullptr);
         std::vector<void *> blocks;
@@ -1040,31 +1041,26 @@ int nolzss_factorize_fasta_per_sequence(const char *fasta_path, int with_rc, int
         } free_blocks{blocks};
         try {
             const bool need_f = keep || out_dir;
-            if (!with_rc && m) {  // the reference strips the last base here (fasta_processor.cpp:469-471)
+            if (m) {
+                // with rc: prepare({seq}) + factorize_multiple_dna_w_rc per record (fasta_processor.cpp:446-451);
+                // without: the reference strips the last base of every record (:469-471)
                 std::vector<const uint8_t *> ptrs(m);
                 std::vector<size_t> lens(m);
                 for (size_t j = 0; j < m; ++j) {
                     ptrs[j] = reinterpret_cast<const uint8_t *>(parse.sequences[j].data());
-                    lens[j] = parse.sequences[j].size() - 1;
+                    lens[j] = with_rc ? parse.sequences[j].size() : parse.sequences[j].size() - 1;
                     if (lens[j] > 0) check_text_args(ptrs[j], lens[j], 0);
                 }
-                factorize_many(ptrs.data(), lens.data(), m, &device, 1, plain_z.data(),
+                factorize_many(ptrs.data(), lens.data(), m, &device, 1, with_rc != 0, plain_z.data(),
                                need_f ? plain_f.data() : nullptr, blocks);
             }
             for (size_t j = 0; j < m; ++j) {
-                const std::string &seq = parse.sequences[j];
                 nolzss_factor *f = nullptr;
-                size_t z = 0;
-                if (with_rc) {  // prepare({seq}) + factorize_multiple_dna_w_rc, fasta_processor.cpp:446-451
-                    dna_w_rc_common(reinterpret_cast<const uint8_t *>(seq.data()), seq.size(), device,
-                                    need_f ? &f : nullptr, &z);
-                } else {
-                    z = plain_z[j];
-                    if (need_f && z) {  // a block of the batch worker may hold many records: own copy
-                        f = static_cast<nolzss_factor *>(std::malloc(sizeof(nolzss_factor) * z));
-                        if (!f) throw std::bad_alloc();
-                        std::memcpy(f, plain_f[j], sizeof(nolzss_factor) * z);
-                    }
+                const size_t z = plain_z[j];
+                if (need_f && z) {  // a block of the batch worker may hold many records: own copy
+                    f = static_cast<nolzss_factor *>(std::malloc(sizeof(nolzss_factor) * z));
+                    if (!f) throw std::bad_alloc();
+                    std::memcpy(f, plain_f[j], sizeof(nolzss_factor) * z);
                 }
                 std::unique_ptr<nolzss_factor, decltype(&std::free)> hold(f, &std::free);
                 res.counts[j] = z;
@@ -1133,7 +1129,9 @@ __global__ void batch_rebase_kernel(nolzss_factor *__restrict__ recs, uint32_t z
     const uint32_t k = term_lower_bound(terms, (uint32_t)p);
     const uint64_t base = k ? (uint64_t)terms.pos[k - 1] + 1 : 0;
     recs[j].start = p - base;
-    recs[j].ref -= base;
+    // (reverse-complement factors carry NOLZSS_RC_MASK in the top bit of ref, over a position of T)
+    const uint64_t ref = recs[j].ref, flag = ref & (1ull << 63);
+    recs[j].ref = ((ref ^ flag) - base) | flag;
 }
 
 // Factorizes records ids[0..c) (all non-empty) in one run.  Returns false, with nothing written, when
@@ -1167,7 +1165,7 @@ void *alloc_factor_block(size_t bytes) {
 }
 
 bool run_merged_chunk(Context &ctx, const uint8_t *const *texts, const size_t *lens, const std::vector<size_t> &ids,
-                      size_t *zs, nolzss_factor **fs, std::vector<void *> *blocks) {
+                      bool with_rc, size_t *zs, nolzss_factor **fs, std::vector<void *> *blocks) {
     const bool trace = getenv("NOLZSS_TRACE") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
     auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
@@ -1191,7 +1189,8 @@ bool run_merged_chunk(Context &ctx, const uint8_t *const *texts, const size_t *l
     const double t_concat = since();
     Arena &arena = ctx.arena;
     hipStream_t s = ctx.stream;
-    arena.reserve(arena_bytes_for(n) + n + 16 * c + (size_t(1) << 20));
+    const size_t m2 = 2 * n + 2;  // with_rc: T' sep revcomp(T') sep
+    arena.reserve((with_rc ? arena_bytes_for(m2) + m2 : arena_bytes_for(n)) + n + 32 * c + (size_t(1) << 20));
     const size_t mark = arena.mark();
     struct Rewind {
         Arena &a;
@@ -1201,17 +1200,32 @@ bool run_merged_chunk(Context &ctx, const uint8_t *const *texts, const size_t *l
     uint8_t *d_text = arena.alloc<uint8_t>(n);
     HIP_CHECK(hipMemcpyAsync(d_text, host, n, hipMemcpyHostToDevice, s));
     PackedText text;
-    if (!pack_independent_text(ctx, d_text, n, seps, text)) return false;
-    uint32_t *sa = arena.alloc<uint32_t>(n);
-    uint32_t *isa = arena.alloc<uint32_t>(n);
-    uint32_t *lcp = arena.alloc<uint32_t>(n + 1);
-    build_suffix_array(ctx, text, sa, isa, lcp);
-    const Pyramid Psa = build_pyramid(sa, (uint32_t)n, false, arena, s);
-    const Pyramid Plcp = build_lcp_pyramid(ctx, text, sa, lcp);
-    uint32_t *lstar = arena.alloc<uint32_t>(n);
-    build_lstar(ctx, (uint32_t)n, sa, isa, lcp, Psa, Plcp, lstar);
     void *d_recs = nullptr;
-    const uint32_t z = resolve_chain(ctx, (uint32_t)n, 0, lstar, sa, isa, lcp, Psa, Plcp, &d_recs);
+    uint32_t z = 0;
+    if (with_rc) {
+        // the layout of prepare_multiple_dna_sequences_w_rc (factorizer.cpp:128-169) for any number of
+        // records: segment t and segment 2c - 1 - t are a record and its reverse complement
+        uint8_t *d_S = arena.alloc<uint8_t>(m2);
+        prepare_batch_rc_on_device(ctx, d_text, (uint32_t)n, kBatchSeparator, d_S);
+        std::vector<uint32_t> terms(seps);
+        terms.reserve(2 * c);
+        terms.push_back((uint32_t)n);
+        for (size_t k = seps.size(); k-- > 0;) terms.push_back((uint32_t)(2 * n - seps[k]));
+        terms.push_back((uint32_t)(2 * n + 1));
+        if (!pack_independent_text(ctx, d_S, m2, terms, text, true)) return false;
+        z = run_rc_pipeline_packed(ctx, text, 0, &d_recs);
+    } else {
+        if (!pack_independent_text(ctx, d_text, n, seps, text)) return false;
+        uint32_t *sa = arena.alloc<uint32_t>(n);
+        uint32_t *isa = arena.alloc<uint32_t>(n);
+        uint32_t *lcp = arena.alloc<uint32_t>(n + 1);
+        build_suffix_array(ctx, text, sa, isa, lcp);
+        const Pyramid Psa = build_pyramid(sa, (uint32_t)n, false, arena, s);
+        const Pyramid Plcp = build_lcp_pyramid(ctx, text, sa, lcp);
+        uint32_t *lstar = arena.alloc<uint32_t>(n);
+        build_lstar(ctx, (uint32_t)n, sa, isa, lcp, Psa, Plcp, lstar);
+        z = resolve_chain(ctx, (uint32_t)n, 0, lstar, sa, isa, lcp, Psa, Plcp, &d_recs);
+    }
     nolzss_factor *recs = static_cast<nolzss_factor *>(d_recs);
     // where the records' factor lists start and end
     std::vector<uint32_t> fidx(c, z);
@@ -1258,6 +1272,16 @@ bool run_merged_chunk(Context &ctx, const uint8_t *const *texts, const size_t *l
 
 std::atomic<uint64_t> g_merged_records{0}, g_single_records{0};
 
+// a worker thread failed: the same kind of error, with the same text, for the calling thread
+[[noreturn]] void rethrow_worker_error(int status, const std::string &message) {
+    switch (status) {
+    case NOLZSS_ERR_INVALID_ARGUMENT: throw std::invalid_argument(message);
+    case NOLZSS_ERR_NOMEM: throw std::bad_alloc();
+    case NOLZSS_ERR_DEVICE: throw HipError(message);
+    default: throw std::runtime_error(message);
+    }
+}
+
 // blocks behind the factor arrays of a batch result (nolzss_free_batch)
 std::mutex g_batch_mu;
 std::map<nolzss_factor **, std::vector<void *>> g_batch_blocks;
@@ -1270,9 +1294,11 @@ size_t merge_below() {  // records shorter than this are merged (0: never)
 // The shared worker of the batch entry points: factorizes m records, zs[j] factors each; fs (optional)
 // receives the arrays, every malloc'ed block behind them is appended to `blocks`.
 void factorize_many(const uint8_t *const *texts, const size_t *lens, size_t m, const int *devices, size_t n_dev,
-                    size_t *zs, nolzss_factor **fs, std::vector<void *> &blocks) {
+                    bool with_rc, size_t *zs, nolzss_factor **fs, std::vector<void *> &blocks) {
     // 1. which records are merged: short, non-empty ones, in chunks of consecutive records
-    const size_t below = merge_below();
+    // (with_rc: each record as T s0 revcomp(T) s1, dna_w_rc_common; a run holds both strands)
+    const size_t below = with_rc ? merge_below() / 2 : merge_below();
+    const size_t run_bases = with_rc ? kMergeChunkBases / 2 : kMergeChunkBases;
     std::vector<size_t> singles;
     std::vector<std::vector<size_t>> chunks;
     {
@@ -1280,7 +1306,7 @@ void factorize_many(const uint8_t *const *texts, const size_t *lens, size_t m, c
         size_t short_bases = 0;
         for (size_t j = 0; j < m; ++j)
             if (lens[j] && lens[j] < below) short_bases += lens[j] + 1;
-        const size_t runs = div_up(short_bases ? short_bases : 1, kMergeChunkBases);
+        const size_t runs = div_up(short_bases ? short_bases : 1, run_bases);
         const size_t share = div_up(short_bases, runs);
         std::vector<size_t> cur;
         size_t cur_bases = 0;
@@ -1321,7 +1347,7 @@ void factorize_many(const uint8_t *const *texts, const size_t *lens, size_t m, c
                     const size_t k = next.fetch_add(1);
                     if (k >= chunks.size()) break;
                     std::vector<void *> mine;
-                    const bool ok = run_merged_chunk(ses.ctx(), texts, lens, chunks[k], zs, fs, &mine);
+                    const bool ok = run_merged_chunk(ses.ctx(), texts, lens, chunks[k], with_rc, zs, fs, &mine);
                     std::lock_guard<std::mutex> lk(out_mu);
                     if (ok) {
                         blocks.insert(blocks.end(), mine.begin(), mine.end());
@@ -1336,7 +1362,7 @@ void factorize_many(const uint8_t *const *texts, const size_t *lens, size_t m, c
         for (size_t w = 0; w < workers && w < chunks.size(); ++w) threads.emplace_back(worker, w);
         for (auto &t : threads) t.join();
         for (size_t w = 0; w < workers; ++w)
-            if (status[w] != NOLZSS_OK) throw std::runtime_error("batch worker failed: " + messages[w]);
+            if (status[w] != NOLZSS_OK) rethrow_worker_error(status[w], messages[w]);
     }
     if (singles.empty()) return;
     // 3. the others one by one: longest-processing-time-first assignment of sequences to devices
@@ -1363,12 +1389,16 @@ void factorize_many(const uint8_t *const *texts, const size_t *lens, size_t m, c
     auto worker = [&](size_t d, size_t lane) {
         const size_t w = d * lanes + lane;
         status[w] = guarded([&] {
-            Session ses(devices[d], nullptr, (int)lane);
+            std::unique_ptr<Session> ses;  // (dna_w_rc_common opens the lane's session itself)
+            if (!with_rc) ses.reset(new Session(devices[d], nullptr, (int)lane));
             for (;;) {
                 const size_t k = next[d].fetch_add(1);
                 if (k >= plan[d].size()) break;
                 const size_t j = plan[d][k];
-                zs[j] = run_plain_host(ses.ctx(), texts[j], lens[j], 0, fs ? &fs[j] : nullptr, nullptr);
+                if (with_rc)
+                    dna_w_rc_common(texts[j], lens[j], devices[d], fs ? &fs[j] : nullptr, &zs[j], (int)lane);
+                else
+                    zs[j] = run_plain_host(ses->ctx(), texts[j], lens[j], 0, fs ? &fs[j] : nullptr, nullptr);
                 ++g_single_records;
                 if (fs && fs[j]) {
                     std::lock_guard<std::mutex> lk(out_mu);
@@ -1386,7 +1416,7 @@ void factorize_many(const uint8_t *const *texts, const size_t *lens, size_t m, c
         for (auto &t : threads) t.join();
     }
     for (size_t d = 0; d < status.size(); ++d)
-        if (status[d] != NOLZSS_OK) throw std::runtime_error("batch worker failed: " + messages[d]);
+        if (status[d] != NOLZSS_OK) rethrow_worker_error(status[d], messages[d]);
 }
 
 }  // namespace
@@ -1394,8 +1424,8 @@ void factorize_many(const uint8_t *const *texts, const size_t *lens, size_t m, c
 
 extern "C" {
 
-int nolzss_factorize_batch(const uint8_t *const *texts, const size_t *lens, size_t m, const int *devices,
-                           size_t n_dev, nolzss_factor ***out, size_t **z) {
+static int factorize_batch_impl(const uint8_t *const *texts, const size_t *lens, size_t m, const int *devices,
+                                size_t n_dev, bool with_rc, nolzss_factor ***out, size_t **z) {
     return guarded([&] {
         if (!z) throw std::invalid_argument("output pointer is null");
         *z = nullptr;
@@ -1413,7 +1443,7 @@ int nolzss_factorize_batch(const uint8_t *const *texts, const size_t *lens, size
         }
         std::vector<void *> blocks;
         try {
-            factorize_many(texts, lens, m, devices, n_dev, zs, fs, blocks);
+            factorize_many(texts, lens, m, devices, n_dev, with_rc, zs, fs, blocks);
             if (fs) {
                 std::lock_guard<std::mutex> lk(g_batch_mu);
                 g_batch_blocks[fs] = std::move(blocks);
@@ -1427,6 +1457,16 @@ int nolzss_factorize_batch(const uint8_t *const *texts, const size_t *lens, size
         *z = zs;
         if (out) *out = fs;
     });
+}
+
+int nolzss_factorize_batch(const uint8_t *const *texts, const size_t *lens, size_t m, const int *devices,
+                           size_t n_dev, nolzss_factor ***out, size_t **z) {
+    return factorize_batch_impl(texts, lens, m, devices, n_dev, false, out, z);
+}
+
+int nolzss_factorize_batch_dna_w_rc(const uint8_t *const *texts, const size_t *lens, size_t m, const int *devices,
+                                    size_t n_dev, nolzss_factor ***out, size_t **z) {
+    return factorize_batch_impl(texts, lens, m, devices, n_dev, true, out, z);
 }
 
 // out[j] may point INTO a block shared by many records: only this function knows what to free

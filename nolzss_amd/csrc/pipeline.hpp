@@ -29,8 +29,9 @@ struct Context {
 PackedText pack_text(Context &ctx, const uint8_t *d_text, size_t n);
 // Many INDEPENDENT nucleotide sequences in one text (text.hpp, TermTable::seq_shift): records of
 // A/C/G/T with one separator byte at each of the sorted positions.  false if the text holds other bytes.
+// mirror: the text is T1 $ .. Tk $ rc(Tk) $ .. rc(T1) $ and segment t belongs with segment 2k - 1 - t.
 bool pack_independent_text(Context &ctx, const uint8_t *d_text, size_t n, const std::vector<uint32_t> &separators,
-                           PackedText &out);
+                           PackedText &out, bool mirror = false);
 
 // ---- stages 2+3: suffix array (prefix doubling over radix sorts) and LCP array -------------
 // sa[r] = start of the r-th smallest suffix, isa[i] = rank of suffix i PLUS ONE (n u32 each);
@@ -56,6 +57,11 @@ uint32_t resolve_chain(Context &ctx, uint32_t n, uint32_t start_pos, const uint3
 
 // ---- reverse-complement mode (rc.hip): whole pipeline over the prepared string S -------------
 uint32_t run_rc_pipeline(Context &ctx, const uint8_t *d_S, size_t m, size_t start_pos, void **d_factors_out);
+// the same over a text that has already been packed (merged batch)
+uint32_t run_rc_pipeline_packed(Context &ctx, const PackedText &text, size_t start_pos, void **d_factors_out);
+// d_S (2n + 2 bytes) = T' sep revcomp(T') sep for the n bytes d_T = upper-case records with separator bytes
+// between them; bytes that are not nucleotides (the separators) are copied to their mirror position.
+void prepare_batch_rc_on_device(Context &ctx, const uint8_t *d_T, uint32_t n, uint8_t separator, uint8_t *d_S);
 // d_S (2n + 2 bytes) = prepared string of the single sequence d_T; returns the index of the first
 // invalid nucleotide or 0xffffffff.
 uint32_t prepare_single_rc_on_device(Context &ctx, const uint8_t *d_T, uint32_t n, uint8_t *d_S);

@@ -203,7 +203,39 @@ __global__ __launch_bounds__(kThreads) void rc_prepare_kernel(const uint8_t *__r
     }
 }
 
+// the same for a batch: T = records with separator bytes between them; whatever is not a nucleotide
+// keeps its value on both strands (pack_independent_text checks afterwards that only separators did)
+__global__ __launch_bounds__(kThreads) void rc_prepare_batch_kernel(const uint8_t *__restrict__ T, uint32_t n,
+                                                                    uint8_t separator, uint8_t *__restrict__ S) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        uint8_t c = T[i];
+        if (c >= 'a' && c <= 'z') c = (uint8_t)(c - 'a' + 'A');
+        uint8_t comp = c;
+        switch (c) {
+        case 'A': comp = 'T'; break;
+        case 'C': comp = 'G'; break;
+        case 'G': comp = 'C'; break;
+        case 'T': comp = 'A'; break;
+        default: break;
+        }
+        S[i] = c;
+        S[2 * (size_t)n - i] = comp;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        S[n] = separator;
+        S[2 * (size_t)n + 1] = separator;
+    }
+}
+
 }  // namespace
+
+void prepare_batch_rc_on_device(Context &ctx, const uint8_t *d_T, uint32_t n, uint8_t separator, uint8_t *d_S) {
+    size_t g = div_up((size_t)n + 1, kThreads);
+    if (g > 8192) g = 8192;
+    rc_prepare_batch_kernel<<<(unsigned)g, kThreads, 0, ctx.stream>>>(d_T, n, separator, d_S);
+    KERNEL_CHECK();
+}
 
 uint32_t prepare_single_rc_on_device(Context &ctx, const uint8_t *d_T, uint32_t n, uint8_t *d_S) {
     uint32_t *first_bad = ctx.arena.alloc<uint32_t>(1);
@@ -221,12 +253,16 @@ uint32_t prepare_single_rc_on_device(Context &ctx, const uint8_t *d_T, uint32_t 
 }
 
 uint32_t run_rc_pipeline(Context &ctx, const uint8_t *d_S, size_t m_sz, size_t start_pos, void **d_factors_out) {
-    const uint32_t m = (uint32_t)m_sz;
+    const PackedText text = pack_text(ctx, d_S, m_sz);  // segmented 2-bit packing is detected there
+    return run_rc_pipeline_packed(ctx, text, start_pos, d_factors_out);
+}
+
+uint32_t run_rc_pipeline_packed(Context &ctx, const PackedText &text, size_t start_pos, void **d_factors_out) {
+    const uint32_t m = text.n;
     const uint32_t N = m / 2 - 1;
     hipStream_t s = ctx.stream;
     Arena &arena = ctx.arena;
 
-    PackedText text = pack_text(ctx, d_S, m);  // segmented 2-bit packing is detected there
     uint32_t *sa = arena.alloc<uint32_t>(m);
     uint32_t *isa = arena.alloc<uint32_t>(m);
     uint32_t *lcp = arena.alloc<uint32_t>((size_t)m + 1);

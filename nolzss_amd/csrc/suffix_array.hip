@@ -1009,7 +1009,7 @@ void finish_packing(Context &ctx, PackedText &t, const uint8_t *d_text, size_t n
 // (any byte that is not a nucleotide) at each of the given sorted positions.  Returns false -- and
 // packs nothing -- if the text holds anything else (the caller then takes the records one by one).
 bool pack_independent_text(Context &ctx, const uint8_t *d_text, size_t n, const std::vector<uint32_t> &separators,
-                           PackedText &t) {
+                           PackedText &t, bool mirror) {
     hipStream_t s = ctx.stream;
     uint32_t *count = ctx.arena.alloc<uint32_t>(1);
     uint32_t *pos = ctx.arena.alloc<uint32_t>(kMaxTermScan);
@@ -1033,6 +1033,7 @@ bool pack_independent_text(Context &ctx, const uint8_t *d_text, size_t n, const 
     t.segmented = true;
     finish_packing(ctx, t, d_text, n, separators, presence);
     if (!separators.empty()) t.terms.seq_shift = 40;  // KeyLayout<2>: 17 bases + 6-bit tag
+    t.terms.mirror = mirror ? 1u : 0u;
     return true;
 }
 
@@ -1155,7 +1156,10 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
                                act_grp[0], scratch_idx, scratch_val, rank_val, d_total, lcp,
                                k_syms * text.bits, tag_bits, text.bits, nullptr, low_bits, 0, rank_by_slot, nullptr,
                                dna_fast ? reinterpret_cast<const uint32_t *>(keys[cur]) : nullptr,
-                               dna_fast ? &seg : nullptr, dna_fast ? (uint32_t)k_syms : 0u, false,
+                               dna_fast ? &seg : nullptr,
+                               // (mirrored independent sequences have two terminators each: a short suffix
+                               // can tie with its copy at the other one)
+                               (dna_fast || (independent && text.terms.mirror)) ? (uint32_t)k_syms : 0u, false,
                                text.terms.seq_shift);
 
     // ---- doubling rounds ------------------------------------------------------------------

@@ -30,6 +30,9 @@ struct TermTable {
     // clamped to count - 1; (n >> kTermBlockShift) + 3 entries
     const uint32_t *coarse = nullptr;
     uint32_t seq_shift = 0;
+    // independent sequences WITH their reverse complements (T1 $ .. Tk $ rc(Tk) $ .. rc(T1) $): segment t and
+    // segment 2k - 1 - t belong to the same sequence
+    uint32_t mirror = 0;
 };
 
 // smallest k with pos[k] >= p (exists for every suffix start p < n)
@@ -168,7 +171,13 @@ __device__ __forceinline__ uint64_t initial_key(const uint64_t *__restrict__ wor
     // symbols behind a terminator belong to the next segment (zero behind the end of the text)
     if (tag < (uint32_t)K) sym &= ~((1ull << (BITS * (K - (int)tag))) - 1ull);
     const uint64_t key = (sym << TAG) | tag;
-    return terms.seq_shift ? key | ((uint64_t)k << terms.seq_shift) : key;
+    if (terms.seq_shift == 0) return key;
+    uint32_t seq = k;
+    if (terms.mirror) {
+        const uint32_t other = terms.count - 2 - k;
+        seq = k < other ? k : other;
+    }
+    return key | ((uint64_t)seq << terms.seq_shift);
 }
 
 }  // namespace nolzss

@@ -202,3 +202,90 @@ def test_differential_fuzz_of_tiny_records(native):
             assert _same(arrays[j], oracle.factors_array(r)), (cases, j, bytes(r))
         cases += 1
     assert cases >= 5
+
+
+# ---- with reverse complement: record j as factorize_dna_w_rc(record j) -------------------------------
+
+def _rc_expected(rec):
+    S, _, _ = oracle.prepare_multiple_dna_w_rc([bytes(rec)])
+    return oracle.factors_array_multiple_dna_w_rc(S)
+
+
+def _palindromic(rng, n):
+    """a record whose second half is the reverse complement of its first (rc factors for sure)"""
+    comp = np.zeros(256, dtype=np.uint8)
+    for a, b in zip(b"ACGT", b"TGCA"):
+        comp[a] = b
+    half = gen.random_dna(max(1, n // 2), int(rng.integers(1 << 30)))
+    return np.concatenate([half, comp[half[::-1]]])
+
+
+def test_rc_merged_equals_oracle_record_by_record(native):
+    rng = np.random.default_rng(21)
+    recs = _records(rng, 200, 1, 2500)
+    recs += [_palindromic(rng, int(rng.integers(2, 3000))) for _ in range(60)]
+    recs += [recs[5].copy(), recs[205].copy(), recs[17][:100].copy()]
+    recs += [np.frombuffer(c, dtype=np.uint8) for c in (b"A", b"T", b"AT", b"ACGT", b"A" * 300, b"AT" * 200, b"acgtTTgca")]
+    merged0, single0 = native.debug_batch_counters()
+    counts, arrays = native.factorize_batch(recs, want_factors=True, with_rc=True)
+    assert native.debug_batch_counters() == (merged0 + len(recs), single0)
+    n_rc = 0
+    for j, r in enumerate(recs):
+        exp = _rc_expected(r)
+        assert counts[j] == len(exp), j
+        assert _same(arrays[j], exp), j
+        n_rc += int((exp["ref"] >> 63).sum())
+    assert n_rc > 100  # reverse-complement factors were exercised
+    counts2, none = native.factorize_batch(recs, want_factors=False, with_rc=True)
+    assert counts2 == counts and none is None
+
+
+def test_rc_merged_equals_one_by_one(native):
+    rng = np.random.default_rng(22)
+    recs = _records(rng, 30, 5000, 120000) + [_palindromic(rng, 50000)]
+    with merge_below(0):
+        c1, a1 = native.factorize_batch(recs, want_factors=True, with_rc=True)
+    merged0, _ = native.debug_batch_counters()
+    c2, a2 = native.factorize_batch(recs, want_factors=True, with_rc=True)
+    assert native.debug_batch_counters()[0] == merged0 + len(recs)
+    assert c1 == c2
+    for j in range(len(recs)):
+        assert _same(a1[j], a2[j]), j
+    assert _same(a2[30], _rc_expected(recs[30]))
+
+
+def test_rc_invalid_nucleotide_fails_like_the_reference(native):
+    recs = [gen.random_dna(100, 1), np.frombuffer(b"ACGTNACGT", dtype=np.uint8), gen.random_dna(50, 2)]
+    with pytest.raises(RuntimeError, match="Invalid nucleotide 'N'"):
+        native.factorize_batch(recs, want_factors=True, with_rc=True)
+
+
+def test_rc_differential_fuzz_of_tiny_records(native):
+    import time
+    rng = np.random.default_rng(23)
+    t_end = time.time() + 6.0
+    cases = 0
+    while time.time() < t_end:
+        sigma = int(rng.integers(1, 5))
+        letters = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.permutation(4)[:sigma]]
+        m = int(rng.integers(2, 300))
+        recs = []
+        for _ in range(m):
+            kind = rng.integers(0, 5)
+            n = int(rng.integers(1, 60))
+            if kind == 0 and recs:
+                src = recs[int(rng.integers(0, len(recs)))]
+                r = src[:max(1, int(rng.integers(1, len(src) + 1)))].copy()
+            elif kind == 1:
+                unit = letters[rng.integers(0, sigma, size=int(rng.integers(1, 5)))]
+                r = np.tile(unit, n)[:max(1, n)]
+            elif kind == 2:
+                r = _palindromic(rng, n + 1)
+            else:
+                r = letters[rng.integers(0, sigma, size=n)]
+            recs.append(np.ascontiguousarray(r, dtype=np.uint8))
+        counts, arrays = native.factorize_batch(recs, want_factors=True, with_rc=True)
+        for j, r in enumerate(recs):
+            assert _same(arrays[j], _rc_expected(r)), (cases, j, bytes(r))
+        cases += 1
+    assert cases >= 5
