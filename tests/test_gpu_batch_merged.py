@@ -289,3 +289,40 @@ def test_rc_differential_fuzz_of_tiny_records(native):
             assert _same(arrays[j], _rc_expected(r)), (cases, j, bytes(r))
         cases += 1
     assert cases >= 5
+
+
+@pytest.mark.parametrize("count", [255, 256, 257, 258, 512, 513])
+def test_record_counts_around_table_and_key_width_boundaries(native, count):
+    """256 / 257 terminators switch the coarse terminator index on; powers of two change the number of
+    record bits in the sort key"""
+    rng = np.random.default_rng(300 + count)
+    recs = _records(rng, count, 1, 400)
+    counts, arrays = native.factorize_batch(recs, want_factors=True)
+    for j, r in enumerate(recs):
+        assert _same(arrays[j], oracle.factors_array(r)), j
+    half = recs[:(count + 1) // 2]  # with rc the table holds two terminators per record
+    counts, arrays = native.factorize_batch(half, want_factors=True, with_rc=True)
+    for j, r in enumerate(half):
+        assert _same(arrays[j], _rc_expected(r)), j
+
+
+@pytest.mark.timeout(600)
+def test_several_runs_in_flight(native):
+    """~90 Mi bases of records: three merged runs, two of them in flight at a time on their own lanes"""
+    rng = np.random.default_rng(31)
+    base = gen.repeat_dna(1 << 22, seed=5)
+    lens = rng.integers(20000, 130000, size=1200)
+    offs = rng.integers(0, (1 << 22) - 130000, size=1200)
+    recs = [base[o:o + l] for o, l in zip(offs.tolist(), lens.tolist())]
+    assert int(lens.sum()) > (2 << 25)
+    merged0, single0 = native.debug_batch_counters()
+    counts, arrays = native.factorize_batch(recs, want_factors=True)
+    assert native.debug_batch_counters() == (merged0 + len(recs), single0)
+    with merge_below(0):
+        c1, _ = native.factorize_batch(recs, want_factors=False)
+    assert c1 == counts
+    for j in rng.choice(len(recs), size=40, replace=False).tolist():
+        assert _same(arrays[j], oracle.factors_array(recs[j])), j
+    crc, arc = native.factorize_batch(recs[:500], want_factors=True, with_rc=True)
+    for j in rng.choice(500, size=20, replace=False).tolist():
+        assert _same(arc[j], _rc_expected(recs[j])), j
