@@ -1032,7 +1032,7 @@ bool pack_independent_text(Context &ctx, const uint8_t *d_text, size_t n, const 
     t.bits = 2;
     t.segmented = true;
     finish_packing(ctx, t, d_text, n, separators, presence);
-    if (!separators.empty()) t.terms.seq_shift = 40;  // KeyLayout<2>: 17 bases + 6-bit tag
+    if (!separators.empty()) t.terms.seq_shift = kIndKeyBits;
     t.terms.mirror = mirror ? 1u : 0u;
     return true;
 }
@@ -1074,7 +1074,7 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     const bool independent = text.terms.seq_shift != 0;
     int seq_bits = 0;
     if (independent) {
-        if (text.bits != 2 || text.terms.seq_shift != 40) throw HipError("suffix array: independent sequences need the 2-bit key layout");
+        if (text.bits != 2 || text.terms.seq_shift != (uint32_t)kIndKeyBits) throw HipError("suffix array: independent sequences need the 2-bit key layout");
         while (seq_bits < 24 && (1u << seq_bits) < text.terms.count) ++seq_bits;
         if ((1u << seq_bits) < text.terms.count) throw HipError("suffix array: too many independent sequences");
     }
@@ -1082,7 +1082,7 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     int key_passes = 0;
     {
         int kb = dna_fast ? KeyLayout<2>::kSyms * 2 + KeyLayout<2>::kTagBits
-                 : independent ? 40 + seq_bits
+                 : independent ? kIndKeyBits + seq_bits
                  : text.segmented ? kSegSyms * 2 + kSegTagBits + kSegTermBits
                  : text.bits == 2 ? KeyLayout<2>::kSyms * 2 + KeyLayout<2>::kTagBits
                  : text.bits == 4 ? KeyLayout<4>::kSyms * 4 + KeyLayout<4>::kTagBits
@@ -1126,7 +1126,7 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         default: key_bits += KeyLayout<8>::kTagBits; break;
         }
         if (text.segmented) key_bits = kSegSyms * 2 + kSegTagBits + kSegTermBits;
-        if (independent) key_bits = 40 + seq_bits;
+        if (independent) key_bits = kIndKeyBits + seq_bits;
         int shifts0[8], np0 = 0;
         for (int b = 0; b < key_bits && np0 < 8; b += kRadixBits) shifts0[np0++] = b;
         ProfScope ps(ctx.profiler(), "sa_sort_initial", s);
@@ -1146,6 +1146,10 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     case 2: tag_bits = KeyLayout<2>::kTagBits; break;
     case 4: tag_bits = KeyLayout<4>::kTagBits; break;
     default: tag_bits = KeyLayout<8>::kTagBits; break;
+    }
+    if (independent) {  // [record][kIndSyms bases][4-bit tag]
+        k_syms = kIndSyms;
+        tag_bits = kIndTagBits;
     }
     if (text.segmented && !dna_fast && !independent) {  // [kSegSyms symbols][5-bit tag][8-bit terminator index]
         k_syms = kSegSyms;

@@ -23,6 +23,10 @@ namespace nolzss {
 // arrays of the sequences, the LCP between neighbours of different sequences is 0, and every later
 // stage (candidates, cursor, factor records) stays inside one sequence without knowing about it.
 constexpr int kTermBlockShift = 12;
+// their key: [record number][12 bases][4-bit length tag].  Records are short (api.hip merges records
+// below 2^21 bases), so 12 bases separate as well as 17 do in a 2^30-base text, and every 8 key bits
+// less is a radix pass less.
+constexpr int kIndSyms = 12, kIndTagBits = 4, kIndKeyBits = kIndSyms * 2 + kIndTagBits;
 struct TermTable {
     const uint32_t *pos = nullptr;  // sorted terminator positions, pos[count-1] = n
     uint32_t count = 0;
@@ -164,20 +168,24 @@ __device__ __forceinline__ uint64_t initial_key(const uint64_t *__restrict__ wor
         return (sym << (kSegTagBits + kSegTermBits)) | ((uint64_t)tag << kSegTermBits) |
                (tag < (uint32_t)kSegSyms ? (uint64_t)(k & 255u) : 0ull);
     }
+    if (BITS == 2 && terms.seq_shift != 0) {  // independent sequences
+        const uint32_t tag = lim < (uint32_t)kIndSyms ? lim : (uint32_t)kIndSyms;
+        uint64_t sym = w >> (64 - kIndSyms * 2);
+        if (tag < (uint32_t)kIndSyms) sym &= ~((1ull << (2 * (kIndSyms - (int)tag))) - 1ull);
+        uint32_t seq = k;
+        if (terms.mirror) {
+            const uint32_t other = terms.count - 2 - k;
+            seq = k < other ? k : other;
+        }
+        return (sym << kIndTagBits) | tag | ((uint64_t)seq << terms.seq_shift);
+    }
     constexpr int K = KeyLayout<BITS>::kSyms;
     constexpr int TAG = KeyLayout<BITS>::kTagBits;
     const uint32_t tag = lim < (uint32_t)K ? lim : (uint32_t)K;
     uint64_t sym = w >> (64 - K * BITS);
     // symbols behind a terminator belong to the next segment (zero behind the end of the text)
     if (tag < (uint32_t)K) sym &= ~((1ull << (BITS * (K - (int)tag))) - 1ull);
-    const uint64_t key = (sym << TAG) | tag;
-    if (terms.seq_shift == 0) return key;
-    uint32_t seq = k;
-    if (terms.mirror) {
-        const uint32_t other = terms.count - 2 - k;
-        seq = k < other ? k : other;
-    }
-    return key | ((uint64_t)seq << terms.seq_shift);
+    return (sym << TAG) | tag;
 }
 
 }  // namespace nolzss
