@@ -232,6 +232,9 @@ int nolzss_debug_sort_pairs(uint64_t *keys, uint32_t *vals, size_t n, int device
 int nolzss_debug_scan(uint32_t *data, size_t n, int mode, int device);
 /* Capacity and high-water mark (bytes) of the device arena of `device` (lane 0). */
 int nolzss_debug_arena(int device, size_t *capacity, size_t *peak);
+/* Gives the device arenas that no call is using back to the driver (they are otherwise kept between
+ * calls and only grow; the library does this by itself when a reservation fails). */
+int nolzss_debug_trim_arenas(int device, size_t *released_bytes);
 /* Records factorized since the library was loaded by merged runs / one pipeline run each. */
 void nolzss_debug_batch_counters(uint64_t *merged_records, uint64_t *single_records);
 

@@ -664,6 +664,13 @@ def debug_arena():
     return cap.value, peak.value
 
 
+def debug_trim_arenas() -> int:
+    """Releases the idle device arenas of the default device; returns the bytes given back."""
+    r = C.c_size_t()
+    check(lib.nolzss_debug_trim_arenas(_default_device, C.byref(r)))
+    return r.value
+
+
 def debug_batch_counters():
     """(records factorized by merged runs, records factorized one pipeline run each) since load."""
     a, b = C.c_uint64(), C.c_uint64()

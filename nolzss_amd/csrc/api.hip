@@ -83,6 +83,35 @@ struct Session {
     Context &ctx() { return dc.ctx; }
 };
 
+// Arenas are kept between calls and never shrink.  When the device runs out of memory, the idle ones
+// (other lanes of the device that no call holds at the moment) are given back and the reservation is
+// tried once more.
+size_t trim_idle_arenas(int device, const Context *keep) {
+    size_t released = 0;
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    for (auto &kv : g_ctx) {
+        DeviceContext &dc = *kv.second;
+        if (&dc.ctx == keep || kv.first / kMaxLanes != device) continue;
+        std::unique_lock<std::mutex> idle(dc.mu, std::try_to_lock);
+        if (!idle.owns_lock()) continue;
+        released += dc.ctx.arena.capacity();
+        dc.ctx.arena.release();
+    }
+    return released;
+}
+
+void reserve_arena(Context &ctx, size_t bytes) {
+    if (bytes <= ctx.arena.capacity()) return;
+    try {
+        ctx.arena.reserve(bytes);
+        return;
+    } catch (const HipError &) {
+        (void)hipGetLastError();
+    }
+    trim_idle_arenas(ctx.device, &ctx);
+    ctx.arena.reserve(bytes);
+}
+
 struct DebugOut {
     uint32_t *sa = nullptr, *isa = nullptr, *lcp = nullptr, *lstar = nullptr;
 };
@@ -145,7 +174,7 @@ size_t run_plain_host(Context &ctx, const uint8_t *text, size_t n, size_t start_
                       DebugOut *dbg) {
     if (out) *out = nullptr;
     if (n == 0 || start_pos >= n) return 0;
-    ctx.arena.reserve(arena_bytes_for(n) + n);
+    reserve_arena(ctx, arena_bytes_for(n) + n);
     const size_t mark = ctx.arena.mark();
     uint8_t *d_text = ctx.arena.alloc<uint8_t>(n);
     {
@@ -286,7 +315,7 @@ size_t run_rc_host(Context &ctx, const uint8_t *S, size_t m, size_t start_pos, n
     if (out) *out = nullptr;
     if (m > kMaxText) throw std::invalid_argument("text too long: the device pipeline uses 32-bit indices");
     if (!rc_guards(m, start_pos)) return 0;
-    ctx.arena.reserve(arena_bytes_for(m) + m);
+    reserve_arena(ctx, arena_bytes_for(m) + m);
     const size_t mark = ctx.arena.mark();
     size_t z = 0;
     try {
@@ -392,7 +421,7 @@ int nolzss_factorize_device(const void *d_text, size_t n, size_t start_pos, int 
         if (emit == 2 && !out_host) throw std::invalid_argument("emit = 2 needs out_host");
         check_text_args(d_text, n, start_pos);
         Session ses(device, stream);
-        ses.ctx().arena.reserve(arena_bytes_for(n));
+        reserve_arena(ses.ctx(), arena_bytes_for(n));
         *z = run_plain(ses.ctx(), static_cast<const uint8_t *>(d_text), n, start_pos,
                        emit == 2 ? out_host : nullptr, nullptr, emit == 1);
     });
@@ -467,7 +496,7 @@ static void dna_w_rc_common(const uint8_t *text, size_t n, int device, nolzss_fa
     if (!rc_guards(m, 0)) return;
     Session ses(device, nullptr, lane);
     Context &ctx = ses.ctx();
-    ctx.arena.reserve(arena_bytes_for(m) + m + n);
+    reserve_arena(ctx, arena_bytes_for(m) + m + n);
     uint8_t *d_T = ctx.arena.alloc<uint8_t>(n);
     uint8_t *d_S = ctx.arena.alloc<uint8_t>(m);
     HIP_CHECK(hipMemcpyAsync(d_T, text, n, hipMemcpyHostToDevice, ctx.stream));
@@ -1190,7 +1219,7 @@ bool run_merged_chunk(Context &ctx, const uint8_t *const *texts, const size_t *l
     Arena &arena = ctx.arena;
     hipStream_t s = ctx.stream;
     const size_t m2 = 2 * n + 2;  // with_rc: T' sep revcomp(T') sep
-    arena.reserve((with_rc ? arena_bytes_for(m2) + m2 : arena_bytes_for(n)) + n + 32 * c + (size_t(1) << 20));
+    reserve_arena(ctx, (with_rc ? arena_bytes_for(m2) + m2 : arena_bytes_for(n)) + n + 32 * c + (size_t(1) << 20));
     const size_t mark = arena.mark();
     struct Rewind {
         Arena &a;
@@ -1410,9 +1439,21 @@ void factorize_many(const uint8_t *const *texts, const size_t *lens, size_t m, c
     };
     {
         std::vector<std::thread> threads;
-        for (size_t d = 0; d < n_dev; ++d)
-            for (size_t lane = 0; lane < lanes; ++lane)
+        for (size_t d = 0; d < n_dev; ++d) {
+            // no more lanes than arenas for the device's longest record fit its memory
+            size_t fit = lanes;
+            if (!plan[d].empty()) {
+                const size_t longest = lens[plan[d][0]];
+                const size_t need = arena_bytes_for(with_rc ? 2 * longest + 2 : longest) + 3 * longest;
+                size_t free_b = 0, total_b = 0;
+                if (hipSetDevice(devices[d]) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                    fit = (size_t)((double)total_b * 0.85) / need;
+                    fit = fit < 1 ? 1 : (fit > lanes ? lanes : fit);
+                }
+            }
+            for (size_t lane = 0; lane < fit; ++lane)
                 if (lane < plan[d].size()) threads.emplace_back(worker, d, lane);
+        }
         for (auto &t : threads) t.join();
     }
     for (size_t d = 0; d < status.size(); ++d)
@@ -1486,6 +1527,14 @@ void nolzss_free_batch(nolzss_factor **out, size_t *z, size_t m) {
         std::free(out);
     }
     std::free(z);
+}
+
+int nolzss_debug_trim_arenas(int device, size_t *released) {
+    return guarded([&] {
+        HIP_CHECK(hipSetDevice(device));
+        const size_t r = trim_idle_arenas(device, nullptr);
+        if (released) *released = r;
+    });
 }
 
 void nolzss_debug_batch_counters(uint64_t *merged_records, uint64_t *single_records) {

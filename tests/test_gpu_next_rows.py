@@ -292,3 +292,23 @@ def test_concurrent_host_threads(pkg):
     for t in threads:
         t.join()
     assert not errors, errors[:3]
+
+
+def test_arenas_are_given_back_and_taken_again(pkg):
+    """the device arenas are kept between calls; trimming them (what the library does by itself when a
+    reservation fails) must leave every lane usable"""
+    native = pkg._noLZSS
+    recs = [gen.random_dna(1 << 18, 40 + k) for k in range(8)]
+    import os
+    os.environ["NOLZSS_BATCH_MERGE_BELOW"] = "0"   # one run per record: four lanes take arenas
+    try:
+        c1, _ = native.factorize_batch(recs, want_factors=False)
+        assert native.debug_arena()[0] > 0
+        released = native.debug_trim_arenas()
+        assert released >= 4 * 108 * (1 << 18)
+        assert native.debug_arena()[0] == 0
+        c2, _ = native.factorize_batch(recs, want_factors=False)
+    finally:
+        os.environ.pop("NOLZSS_BATCH_MERGE_BELOW", None)
+    assert c1 == c2
+    assert native.count_factors(recs[0]) == c1[0]
