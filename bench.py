@@ -190,7 +190,7 @@ def main():
                                    if k not in nested},
             "kernels_ms_per_step": {k: stats[k][1] / a.steps for k in sorted(nested) if k in stats},
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:  # the CPU leg runs on rank 0 of the one-GPU run only
             out["cpu_baseline"] = cpu_baseline(text, 1 << a.cpu_sample_log2)
         print(json.dumps(out), flush=True)
     if world > 1:
