@@ -97,8 +97,13 @@ template <typename KeyT, typename Src>
 __global__ __launch_bounds__(kThreads) void rs_hist_kernel(Src src, size_t n, int shift,
                                                            uint32_t *__restrict__ tile_hist,
                                                            uint32_t num_tiles, SegView seg) {
-    __shared__ uint32_t hist[kBins];
-    hist[threadIdx.x] = 0;
+    // four interleaved copies of the histogram, one per lane & 3: a pass whose digit takes only a few
+    // values (the lowest key byte is mostly the length tag) would otherwise send all 64 lanes of an
+    // LDS atomic to the same few addresses, which the LDS executes one after the other
+    constexpr int kCopies = 4;
+    __shared__ __align__(16) uint32_t hist[kBins * kCopies];
+#pragma unroll
+    for (int c = 0; c < kCopies; ++c) hist[c * kBins + threadIdx.x] = 0;
     __syncthreads();
     const TileExtent ext = tile_extent(blockIdx.x, n, num_tiles, seg);
     // all loads first: the compiler does not move loads across the LDS atomics
@@ -108,13 +113,15 @@ __global__ __launch_bounds__(kThreads) void rs_hist_kernel(Src src, size_t n, in
         const uint32_t local = (uint32_t)j * kThreads + threadIdx.x;
         k[j] = local < ext.count ? (KeyT)src.hist_raw(ext.first + local, shift) : KeyT(0);
     }
+    const uint32_t copy = threadIdx.x & (kCopies - 1);
 #pragma unroll
     for (int j = 0; j < kKeysPerThread; ++j) {
         const uint32_t local = (uint32_t)j * kThreads + threadIdx.x;
-        if (local < ext.count) atomicAdd(&hist[src.hist_digit(k[j], shift)], 1u);
+        if (local < ext.count) atomicAdd(&hist[src.hist_digit(k[j], shift) * kCopies + copy], 1u);
     }
     __syncthreads();
-    tile_hist[ext.hist0 + (size_t)threadIdx.x * ext.hstride] = hist[threadIdx.x];
+    const uint4 c4 = reinterpret_cast<const uint4 *>(hist)[threadIdx.x];
+    tile_hist[ext.hist0 + (size_t)threadIdx.x * ext.hstride] = c4.x + c4.y + c4.z + c4.w;
 }
 
 template <typename KeyT, typename OutT, typename Src>
