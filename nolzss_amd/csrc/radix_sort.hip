@@ -72,6 +72,8 @@ template <typename KeyT> struct ArraySrc {
     // of a tile are issued before the first digit is needed)
     __device__ __forceinline__ KeyT hist_raw(size_t idx, int) const { return keys[idx]; }
     __device__ __forceinline__ uint32_t hist_digit(KeyT raw, int shift) const { return digit_of(raw, shift); }
+    __device__ __forceinline__ bool digits_from_window(int) const { return false; }
+    __device__ __forceinline__ uint64_t window(size_t) const { return 0; }
 };
 template <int BITS> struct TextSrc {
     const uint64_t *__restrict__ words;
@@ -91,6 +93,14 @@ template <int BITS> struct TextSrc {
         return key(idx);
     }
     __device__ __forceinline__ uint32_t hist_digit(uint64_t raw, int shift) const { return digit_of(raw, shift); }
+    // the most significant digits of 16 CONSECUTIVE suffixes are 8-bit windows of one 64-bit piece of a
+    // 2-bit text: a histogram thread can take 16 neighbours with two loads instead of 16 strided
+    // elements with 32
+    __device__ __forceinline__ bool digits_from_window(int shift) const {
+        constexpr int kKeyBits = KeyLayout<BITS>::kSyms * BITS + KeyLayout<BITS>::kTagBits;
+        return BITS == 2 && !segmented && digit_from_text && shift == kKeyBits - kRadixBits;
+    }
+    __device__ __forceinline__ uint64_t window(size_t idx) const { return sym_word<BITS>(words, idx); }
 };
 
 template <typename KeyT, typename Src>
@@ -106,18 +116,28 @@ __global__ __launch_bounds__(kThreads) void rs_hist_kernel(Src src, size_t n, in
     for (int c = 0; c < kCopies; ++c) hist[c * kBins + threadIdx.x] = 0;
     __syncthreads();
     const TileExtent ext = tile_extent(blockIdx.x, n, num_tiles, seg);
-    // all loads first: the compiler does not move loads across the LDS atomics
-    KeyT k[kKeysPerThread];
-#pragma unroll
-    for (int j = 0; j < kKeysPerThread; ++j) {
-        const uint32_t local = (uint32_t)j * kThreads + threadIdx.x;
-        k[j] = local < ext.count ? (KeyT)src.hist_raw(ext.first + local, shift) : KeyT(0);
-    }
     const uint32_t copy = threadIdx.x & (kCopies - 1);
+    if (src.digits_from_window(shift)) {
+        static_assert(kKeysPerThread == 16, "16 two-bit symbols and an 8-bit digit fit one 64-bit window");
+        const uint32_t local0 = threadIdx.x * (uint32_t)kKeysPerThread;
+        const uint64_t w = local0 < ext.count ? src.window(ext.first + local0) : 0ull;
 #pragma unroll
-    for (int j = 0; j < kKeysPerThread; ++j) {
-        const uint32_t local = (uint32_t)j * kThreads + threadIdx.x;
-        if (local < ext.count) atomicAdd(&hist[src.hist_digit(k[j], shift) * kCopies + copy], 1u);
+        for (int j = 0; j < kKeysPerThread; ++j)
+            if (local0 + (uint32_t)j < ext.count)
+                atomicAdd(&hist[(uint32_t)((w >> (64 - kRadixBits - 2 * j)) & (uint64_t)(kBins - 1)) * kCopies + copy], 1u);
+    } else {
+        // all loads first: the compiler does not move loads across the LDS atomics
+        KeyT k[kKeysPerThread];
+#pragma unroll
+        for (int j = 0; j < kKeysPerThread; ++j) {
+            const uint32_t local = (uint32_t)j * kThreads + threadIdx.x;
+            k[j] = local < ext.count ? (KeyT)src.hist_raw(ext.first + local, shift) : KeyT(0);
+        }
+#pragma unroll
+        for (int j = 0; j < kKeysPerThread; ++j) {
+            const uint32_t local = (uint32_t)j * kThreads + threadIdx.x;
+            if (local < ext.count) atomicAdd(&hist[src.hist_digit(k[j], shift) * kCopies + copy], 1u);
+        }
     }
     __syncthreads();
     const uint4 c4 = reinterpret_cast<const uint4 *>(hist)[threadIdx.x];
