@@ -232,6 +232,11 @@ int nolzss_debug_sort_pairs(uint64_t *keys, uint32_t *vals, size_t n, int device
 int nolzss_debug_scan(uint32_t *data, size_t n, int mode, int device);
 /* Capacity and high-water mark (bytes) of the device arena of `device` (lane 0). */
 int nolzss_debug_arena(int device, size_t *capacity, size_t *peak);
+/* The FASTA reader behind the nolzss_*fasta* entry points (host only, no device needed): records and
+ * ids as NUL-terminated strings back to back; sanitize_mode 0 = remove ambiguous, 1 = strict.
+ * reference: parse_fasta_sequences_and_ids, fasta_processor.cpp:28-128.  Free both with nolzss_free(). */
+int nolzss_debug_parse_fasta(const char *path, int sanitize_mode, char **ids, size_t *ids_bytes,
+                             char **sequences, size_t *sequences_bytes, size_t *count);
 /* Gives the device arenas that no call is using back to the driver (they are otherwise kept between
  * calls and only grow; the library does this by itself when a reservation fails). */
 int nolzss_debug_trim_arenas(int device, size_t *released_bytes);

@@ -95,6 +95,8 @@ def _load():
     lib.nolzss_debug_scan.argtypes = [vp, sz, C.c_int, C.c_int]
     lib.nolzss_debug_arena.argtypes = [C.c_int, szp, szp]
     lib.nolzss_debug_trim_arenas.argtypes = [C.c_int, szp]
+    lib.nolzss_debug_parse_fasta.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p), szp, C.POINTER(C.c_void_p),
+                                             szp, szp]
     lib.nolzss_debug_batch_counters.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.nolzss_debug_batch_counters.restype = None
     return lib
@@ -118,7 +120,7 @@ EXPORTED_SYMBOLS = [
     "nolzss_free_batch", "nolzss_profile_enable", "nolzss_profile_reset", "nolzss_profile_report",
     "nolzss_debug_arrays", "nolzss_debug_sort_pairs", "nolzss_debug_scan", "nolzss_debug_arena",
     "nolzss_debug_batch_counters", "nolzss_factorize_batch_dna_w_rc",
-    "nolzss_debug_trim_arenas",
+    "nolzss_debug_trim_arenas", "nolzss_debug_parse_fasta",
 ]
 
 

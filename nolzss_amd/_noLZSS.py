@@ -664,6 +664,22 @@ def debug_arena():
     return cap.value, peak.value
 
 
+def debug_parse_fasta(path, sanitize_mode: str = "remove_ambiguous"):
+    """[(id, sequence bytes)] as the native FASTA reader sees the file (host only)."""
+    ids, seqs = C.c_void_p(), C.c_void_p()
+    nb_ids, nb_seqs, count = C.c_size_t(), C.c_size_t(), C.c_size_t()
+    check(lib.nolzss_debug_parse_fasta(os.fsencode(str(path)), _sanitize_mode(sanitize_mode), C.byref(ids),
+                                       C.byref(nb_ids), C.byref(seqs), C.byref(nb_seqs), C.byref(count)))
+    try:
+        a = C.string_at(ids, nb_ids.value).split(b"\0")[:-1] if nb_ids.value else []
+        b = C.string_at(seqs, nb_seqs.value).split(b"\0")[:-1] if nb_seqs.value else []
+    finally:
+        lib.nolzss_free(ids)
+        lib.nolzss_free(seqs)
+    assert len(a) == len(b) == count.value
+    return list(zip(a, b))
+
+
 def debug_trim_arenas() -> int:
     """Releases the idle device arenas of the default device; returns the bytes given back."""
     r = C.c_size_t()

@@ -12,6 +12,7 @@
 #include <chrono>
 #include <sys/mman.h>
 #include <fstream>
+#include <iterator>
 #include <memory>
 #include <mutex>
 #include <numeric>
@@ -701,8 +702,20 @@ int nolzss_factorize_dna_w_reference_seq_file(const char *reference_seq, size_t 
 namespace nolzss {
 namespace {
 
+void *alloc_factor_block(size_t bytes);  // (huge pages for large blocks; defined with the batch worker)
+
+// The records of a FASTA file: views into the buffer the file was read into (the bases are compacted
+// in place, in front of the read position; nothing is copied or allocated per record).
+struct SeqView {
+    const char *ptr = nullptr;
+    size_t len = 0;
+    const char *data() const { return ptr; }
+    size_t size() const { return len; }
+};
 struct FastaParse {
-    std::vector<std::string> sequences, ids;
+    std::vector<SeqView> sequences;
+    std::vector<std::string> ids;
+    std::vector<std::shared_ptr<char>> buffers;  // what the views point into
 };
 
 inline bool is_canonical_dna(char c) {
@@ -710,46 +723,101 @@ inline bool is_canonical_dna(char c) {
 }
 
 // restates parse_fasta_sequences_and_ids, /root/reference/src/cpp/fasta_processor.cpp:28-128
+// (same records, ids, warnings and errors).  The reference reads line by line and appends base by
+// base (0.2 GB/s); the device side takes 3-7 Gbases/s, so the file is read in one piece and every
+// line goes through a 256-entry table: upper-case base, white space to skip, or anything else.
 FastaParse parse_fasta(const char *path, bool strict) {
     if (!path) throw std::invalid_argument("path is null");
-    std::ifstream file(path);
+    std::ifstream file(path, std::ios::binary);
     if (!file.is_open()) throw std::runtime_error(std::string("Cannot open FASTA file: ") + path);
+    std::shared_ptr<char> data;  // (no zero fill in front of the read; large files on huge pages)
+    size_t data_size = 0;
+    {
+        file.seekg(0, std::ios::end);
+        const std::streamoff len = file.tellg();
+        file.seekg(0, std::ios::beg);
+        if (len > 0) {
+            char *raw = static_cast<char *>(alloc_factor_block((size_t)len));
+            if (!raw) throw std::bad_alloc();
+            data.reset(raw, [](char *q) { std::free(q); });
+            file.read(raw, len);
+            data_size = (size_t)file.gcount();
+        } else {  // not seekable: take what comes
+            const std::string all((std::istreambuf_iterator<char>(file)), std::istreambuf_iterator<char>());
+            char *raw = static_cast<char *>(std::malloc(all.size() + 1));
+            if (!raw) throw std::bad_alloc();
+            data.reset(raw, [](char *q) { std::free(q); });
+            std::memcpy(raw, all.data(), all.size());
+            data_size = all.size();
+        }
+    }
+    constexpr uint8_t kSpace = 0, kOther = 0xff;
+    uint8_t kind[256];
+    for (int c = 0; c < 256; ++c) kind[c] = kOther;
+    for (unsigned char c : {' ', '\t', '\n', '\v', '\f', '\r'}) kind[c] = kSpace;  // std::isspace, "C" locale
+    for (unsigned char c : {'A', 'C', 'G', 'T'}) kind[c] = kind[c - 'A' + 'a'] = c;
+    uint8_t plain[256];  // 0 for an upper-case base: a line of those is copied as it is
+    for (int c = 0; c < 256; ++c) plain[c] = 1;
+    for (unsigned char c : {'A', 'C', 'G', 'T'}) plain[c] = 0;
+
     FastaParse res;
-    std::string line, cur_seq, cur_id;
+    res.buffers.push_back(data);
+    std::string cur_id;
+    // the bases of the current record are compacted to [rec, rec + cur_len): never beyond the read
+    // position, since a byte of the file yields at most one base
+    char *rec = data.get();
+    size_t cur_len = 0;
     size_t empty_count = 0, removed = 0;
     auto finish = [&] {
-        if (cur_id.empty()) return;
-        if (!cur_seq.empty()) {
-            res.sequences.push_back(cur_seq);
+        if (cur_id.empty()) return;  // (bases in front of the first header go on into the first record, as in the reference)
+        if (cur_len) {
+            res.sequences.push_back(SeqView{rec, cur_len});
             res.ids.push_back(cur_id);
         } else {
             fprintf(stderr, "Warning: Skipping empty sequence with ID: %s\n", cur_id.c_str());
             ++empty_count;
         }
-        cur_seq.clear();
+        rec += cur_len;
+        cur_len = 0;
     };
-    while (std::getline(file, line)) {
-        while (!line.empty() && std::isspace((unsigned char)line.back())) line.pop_back();
-        if (line.empty()) continue;
+    const char *p = data.get(), *const end = p + data_size;
+    while (p < end) {
+        const char *nl = static_cast<const char *>(std::memchr(p, '\n', (size_t)(end - p)));
+        const char *line = p;
+        size_t len = (size_t)((nl ? nl : end) - p);
+        p = nl ? nl + 1 : end;
+        while (len && kind[(unsigned char)line[len - 1]] == kSpace) --len;  // trailing white space
+        if (!len) continue;
         if (line[0] == '>') {
             finish();
             size_t start = 1;
-            while (start < line.size() && std::isspace((unsigned char)line[start])) ++start;
-            size_t end = start;
-            while (end < line.size() && !std::isspace((unsigned char)line[end])) ++end;
-            if (start >= line.size()) throw std::runtime_error("Empty sequence header in FASTA file");
-            cur_id = line.substr(start, end - start);
+            while (start < len && kind[(unsigned char)line[start]] == kSpace) ++start;
+            size_t stop = start;
+            while (stop < len && kind[(unsigned char)line[stop]] != kSpace) ++stop;
+            if (start >= len) throw std::runtime_error("Empty sequence header in FASTA file");
+            cur_id.assign(line + start, stop - start);
         } else {
-            for (char c : line) {
-                if (std::isspace((unsigned char)c)) continue;
-                if (is_canonical_dna(c))
-                    cur_seq += (char)upper_base((uint8_t)c);
-                else if (strict)
-                    throw std::runtime_error("Invalid nucleotide '" + std::string(1, c) +
-                                             "' found in sequence with ID: " + cur_id);
-                else
-                    ++removed;
+            char *out = rec + cur_len;  // <= line
+            uint8_t mixed = 0;
+            for (size_t i = 0; i < len; ++i) mixed |= plain[(unsigned char)line[i]];
+            if (!mixed) {  // the usual line
+                if (out != line) std::memmove(out, line, len);
+                cur_len += len;
+                continue;
             }
+            size_t k = 0;
+            for (size_t i = 0; i < len; ++i) {
+                const uint8_t t = kind[(unsigned char)line[i]];
+                if (t == kOther) {
+                    if (strict)
+                        throw std::runtime_error("Invalid nucleotide '" + std::string(1, line[i]) +
+                                                 "' found in sequence with ID: " + cur_id);
+                    ++removed;
+                } else if (t != kSpace) {
+                    out[k++] = (char)t;
+                }
+            }
+            cur_len += k;
         }
     }
     finish();
@@ -856,6 +924,8 @@ void factorize_ref_target_fasta(const char *ref_path, const char *tgt_path, bool
     for (const auto &q : ref.sequences) target_start += q.size() + 1;  // +1 for each sentinel (:249-252)
     out.parse.sequences = ref.sequences;
     out.parse.ids = ref.ids;
+    out.parse.buffers = ref.buffers;
+    out.parse.buffers.insert(out.parse.buffers.end(), tgt.buffers.begin(), tgt.buffers.end());
     out.parse.sequences.insert(out.parse.sequences.end(), tgt.sequences.begin(), tgt.sequences.end());
     out.parse.ids.insert(out.parse.ids.end(), tgt.ids.begin(), tgt.ids.end());
     std::vector<const char *> ptrs;
@@ -1527,6 +1597,33 @@ void nolzss_free_batch(nolzss_factor **out, size_t *z, size_t m) {
         std::free(out);
     }
     std::free(z);
+}
+
+int nolzss_debug_parse_fasta(const char *path, int sanitize_mode, char **ids, size_t *ids_bytes, char **sequences,
+                             size_t *sequences_bytes, size_t *count) {
+    return guarded([&] {
+        if (!ids || !ids_bytes || !sequences || !sequences_bytes || !count)
+            throw std::invalid_argument("output pointer is null");
+        *ids = *sequences = nullptr;
+        *ids_bytes = *sequences_bytes = *count = 0;
+        const FastaParse parse = parse_fasta(path, sanitize_mode == 1);
+        std::string a, b;
+        for (const auto &id : parse.ids) a.append(id).push_back('\0');
+        for (const auto &seq : parse.sequences) b.append(seq.data(), seq.size()).push_back('\0');
+        char *pa = static_cast<char *>(std::malloc(a.size() + 1)), *pb = static_cast<char *>(std::malloc(b.size() + 1));
+        if (!pa || !pb) {
+            std::free(pa);
+            std::free(pb);
+            throw std::bad_alloc();
+        }
+        std::memcpy(pa, a.data(), a.size());
+        std::memcpy(pb, b.data(), b.size());
+        *ids = pa;
+        *ids_bytes = a.size();
+        *sequences = pb;
+        *sequences_bytes = b.size();
+        *count = parse.sequences.size();
+    });
 }
 
 int nolzss_debug_trim_arenas(int device, size_t *released) {
