@@ -81,15 +81,27 @@ def _as_buffer(data):
     return arr.ctypes.data, arr.size, arr
 
 
+class _Owned:
+    """Frees a library-owned block when the last array that views it is gone."""
+
+    def __init__(self, ptr):
+        self.ptr = C.c_void_p(ptr.value)
+
+    def __del__(self):
+        lib.nolzss_free(self.ptr)
+
+
 def _take(ptr, z):
-    """library-owned factor array -> numpy structured array (copied), then free."""
+    """library-owned factor array -> numpy structured array: a view of the block (a 2^30-base text has
+    1.2 GB of factor records; copying them costs as much as downloading them), freed with the array."""
     if not ptr.value:
         return np.zeros(0, dtype=FACTOR_DTYPE)
-    try:
-        raw = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint64)), shape=(z * 3,)).copy()
-    finally:
-        lib.nolzss_free(ptr)
-    return raw.view(FACTOR_DTYPE)
+    owner = _Owned(ptr)
+    if z == 0:
+        return np.zeros(0, dtype=FACTOR_DTYPE)
+    raw = (C.c_uint64 * (3 * z)).from_address(ptr.value)
+    raw._owner = owner
+    return np.frombuffer(raw, dtype=FACTOR_DTYPE)
 
 
 def _tuples3(f):

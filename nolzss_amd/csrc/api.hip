@@ -29,6 +29,8 @@ namespace {
 
 thread_local std::string g_error;
 
+void *alloc_factor_block(size_t bytes);  // host memory for results: huge pages for large blocks (defined with the batch worker)
+
 int set_error(int code, const std::string &msg) {
     g_error = msg;
     return code;
@@ -155,7 +157,7 @@ size_t run_plain(Context &ctx, const uint8_t *d_text, size_t n, size_t start_pos
     const uint32_t z = resolve_chain(ctx, (uint32_t)n, (uint32_t)start_pos, lstar, sa, isa, lcp, Psa, Plcp,
                                      (out_host || records_on_device_only) ? &d_recs : nullptr);
     if (out_host && z) {
-        nolzss_factor *h = static_cast<nolzss_factor *>(std::malloc(sizeof(nolzss_factor) * (size_t)z));
+        nolzss_factor *h = static_cast<nolzss_factor *>(alloc_factor_block(sizeof(nolzss_factor) * (size_t)z));
         if (!h) throw std::bad_alloc();
         ProfScope ps(ctx.profiler(), "factors_d2h", s);
         hipError_t e = hipMemcpyAsync(h, d_recs, sizeof(nolzss_factor) * (size_t)z, hipMemcpyDeviceToHost, s);
@@ -325,7 +327,7 @@ size_t run_rc_host(Context &ctx, const uint8_t *S, size_t m, size_t start_pos, n
         void *d_recs = nullptr;
         z = run_rc_pipeline(ctx, d_S, m, start_pos, out ? &d_recs : nullptr);
         if (out && z) {
-            nolzss_factor *h = static_cast<nolzss_factor *>(std::malloc(sizeof(nolzss_factor) * z));
+            nolzss_factor *h = static_cast<nolzss_factor *>(alloc_factor_block(sizeof(nolzss_factor) * z));
             if (!h) throw std::bad_alloc();
             hipError_t e = hipMemcpyAsync(h, d_recs, sizeof(nolzss_factor) * z, hipMemcpyDeviceToHost, ctx.stream);
             if (e != hipSuccess) {
@@ -507,7 +509,7 @@ static void dna_w_rc_common(const uint8_t *text, size_t n, int device, nolzss_fa
     void *d_recs = nullptr;
     const size_t count = run_rc_pipeline(ctx, d_S, m, 0, out ? &d_recs : nullptr);
     if (out && count) {
-        nolzss_factor *h = static_cast<nolzss_factor *>(std::malloc(sizeof(nolzss_factor) * count));
+        nolzss_factor *h = static_cast<nolzss_factor *>(alloc_factor_block(sizeof(nolzss_factor) * count));
         if (!h) throw std::bad_alloc();
         hipError_t e = hipMemcpyAsync(h, d_recs, sizeof(nolzss_factor) * count, hipMemcpyDeviceToHost, ctx.stream);
         if (e != hipSuccess) {
@@ -701,8 +703,6 @@ int nolzss_factorize_dna_w_reference_seq_file(const char *reference_seq, size_t 
 // ---- concatenated multi-sequence FASTA -----------------------------------------
 namespace nolzss {
 namespace {
-
-void *alloc_factor_block(size_t bytes);  // (huge pages for large blocks; defined with the batch worker)
 
 // The records of a FASTA file: views into the buffer the file was read into (the bases are compacted
 // in place, in front of the read position; nothing is copied or allocated per record).
