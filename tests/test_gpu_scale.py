@@ -246,3 +246,15 @@ def test_differential_fuzz_short():
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz.py"), "8", seed], cwd=root,
                            env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and "no mismatch" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_file_entry_points_read_large_files_in_pieces(native, tmp_path):
+    """files beyond 16 MiB are read by several threads in 16 MiB pieces: same result as the buffer"""
+    text = gen.repeat_dna((40 << 20) + 12345, seed=77)
+    path = tmp_path / "big.txt"
+    path.write_bytes(text.tobytes())
+    z = native.count_factors(text)
+    assert native.count_factors_file(str(path)) == z
+    f = native.factorize_file(str(path))
+    assert len(f) == z and f[0] == (0, 1, 0)
+    assert sum(l for _, l, _ in f) == len(text)

@@ -17,3 +17,11 @@ for name, fn in (("count_factors (host buffer in)", lambda: native.count_factors
 native.profile_enable(True); native.profile_reset(); native.count_factors(text)
 st = native.profile_report()
 print({k: round(v[1], 2) for k, v in st.items() if k in ("text_h2d", "factors_d2h")})
+import tempfile, os
+path = os.path.join(tempfile.mkdtemp(), "text.bin")
+text.tofile(path)
+best = 1e9
+for rep in range(3):
+    t0 = time.time(); z = native.count_factors_file(path); best = min(best, time.time() - t0)
+print(f"2^{lg} bases, count_factors_file (cached file in): {best*1e3:.1f} ms = {(1<<lg)/best/1e9:.2f} Gbases/s (z={z})", flush=True)
+os.remove(path)
