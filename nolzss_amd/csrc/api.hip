@@ -323,6 +323,49 @@ inline uint8_t complement_base(uint8_t c) {  // factorizer.cpp:17-27
     }
 }
 
+// Bulk helpers of the two prepare functions (the strings they build are as long as the texts the device
+// factorizes at several Gbases/s: no per-byte push_back, no per-byte chain of comparisons).
+struct DnaTables {
+    uint8_t invalid[256], comp[256];  // invalid: 1 unless [ACGTacgt]; comp: complement of the upper-cased base
+    DnaTables() {
+        for (int c = 0; c < 256; ++c) {
+            invalid[c] = 1;
+            comp[c] = 0;
+        }
+        const char *b = "ACGT", *r = "TGCA";
+        for (int i = 0; i < 4; ++i) {
+            invalid[(unsigned char)b[i]] = invalid[(unsigned char)(b[i] + 32)] = 0;
+            comp[(unsigned char)b[i]] = comp[(unsigned char)(b[i] + 32)] = (uint8_t)r[i];
+        }
+    }
+};
+const DnaTables &dna_tables() {
+    static const DnaTables t;
+    return t;
+}
+// index of the first byte that is not a nucleotide, n if there is none
+size_t first_invalid_nucleotide(const char *s, size_t n) {
+    const DnaTables &t = dna_tables();
+    constexpr size_t kBlock = 4096;
+    for (size_t at = 0; at < n; at += kBlock) {
+        const size_t stop = std::min(n, at + kBlock);
+        uint8_t bad = 0;
+        for (size_t j = at; j < stop; ++j) bad |= t.invalid[(unsigned char)s[j]];
+        if (bad)
+            for (size_t j = at; j < stop; ++j)
+                if (t.invalid[(unsigned char)s[j]]) return j;
+    }
+    return n;
+}
+// dst = upper(src) for validated nucleotides (clearing bit 5 turns acgt into ACGT)
+void copy_upper(uint8_t *dst, const char *src, size_t n) {
+    for (size_t j = 0; j < n; ++j) dst[j] = (uint8_t)src[j] & 0xdfu;
+}
+void copy_reverse_complement(uint8_t *dst, const char *src, size_t n) {
+    const DnaTables &t = dna_tables();
+    for (size_t j = 0; j < n; ++j) dst[j] = t.comp[(unsigned char)src[n - 1 - j]];
+}
+
 void prepare_w_rc(const char *const *seqs, const size_t *lens, size_t k, std::vector<uint8_t> &S,
                   size_t &original_length, std::vector<uint64_t> &sentinels) {
     S.clear();
@@ -337,30 +380,30 @@ void prepare_w_rc(const char *const *seqs, const size_t *lens, size_t k, std::ve
     if (non_empty > 125)
         throw std::invalid_argument(
             "Too many sequences: maximum 125 sequences supported (due to sentinel character limitations)");
-    for (size_t i = 0; i < k; ++i)
-        for (size_t j = 0; j < lens[i]; ++j) {
-            const char c = seqs[i][j];
-            if (c != 'A' && c != 'C' && c != 'G' && c != 'T' && c != 'a' && c != 'c' && c != 'g' && c != 't')
-                throw std::runtime_error("Invalid nucleotide '" + std::string(1, c) + "' found in sequence " +
-                                         std::to_string(i));
-        }
+    for (size_t i = 0; i < k; ++i) {
+        const size_t j = first_invalid_nucleotide(seqs[i], lens[i]);
+        if (j < lens[i])
+            throw std::runtime_error("Invalid nucleotide '" + std::string(1, seqs[i][j]) + "' found in sequence " +
+                                     std::to_string(i));
+    }
     for (size_t i = 0; i < k; ++i) total += 2 * lens[i];
     total += 2 * non_empty;
-    S.reserve(total);
-    size_t sidx = 0;
+    S.resize(total);
+    size_t sidx = 0, at = 0;
     for (size_t i = 0; i < k; ++i) {  // :128-147
         if (!lens[i]) continue;
-        for (size_t j = 0; j < lens[i]; ++j) S.push_back(upper_base((uint8_t)seqs[i][j]));
-        sentinels.push_back(S.size());
-        S.push_back(rc_sentinel(sidx++));
+        copy_upper(S.data() + at, seqs[i], lens[i]);
+        at += lens[i];
+        sentinels.push_back(at);
+        S[at++] = rc_sentinel(sidx++);
     }
-    original_length = S.size();
+    original_length = at;
     for (size_t i = k; i-- > 0;) {  // :150-169
         if (!lens[i]) continue;
-        for (size_t j = 0; j < lens[i]; ++j)
-            S.push_back(complement_base(upper_base((uint8_t)seqs[i][lens[i] - 1 - j])));
-        sentinels.push_back(S.size());
-        S.push_back(rc_sentinel(sidx++));
+        copy_reverse_complement(S.data() + at, seqs[i], lens[i]);
+        at += lens[i];
+        sentinels.push_back(at);
+        S[at++] = rc_sentinel(sidx++);
     }
 }
 
@@ -910,23 +953,25 @@ void prepare_no_rc(const char *const *seqs, const size_t *lens, size_t k, std::v
     if (non_empty > 250)
         throw std::invalid_argument(
             "Too many sequences: maximum 250 sequences supported (due to sentinel character limitations)");
-    for (size_t i = 0; i < k; ++i)
-        for (size_t j = 0; j < lens[i]; ++j)
-            if (!is_canonical_dna(seqs[i][j]))
-                throw std::runtime_error("Invalid nucleotide '" + std::string(1, seqs[i][j]) +
-                                         "' found in sequence " + std::to_string(i));
+    for (size_t i = 0; i < k; ++i) {
+        const size_t j = first_invalid_nucleotide(seqs[i], lens[i]);
+        if (j < lens[i])
+            throw std::runtime_error("Invalid nucleotide '" + std::string(1, seqs[i][j]) + "' found in sequence " +
+                                     std::to_string(i));
+    }
     for (size_t i = 0; i < k; ++i) total += lens[i];
-    S.reserve(total + non_empty);
-    size_t sidx = 0, done = 0;
+    S.resize(total + non_empty - 1);
+    size_t sidx = 0, done = 0, at = 0;
     for (size_t i = 0; i < k; ++i) {
         if (!lens[i]) continue;
-        for (size_t j = 0; j < lens[i]; ++j) S.push_back(upper_base((uint8_t)seqs[i][j]));
+        copy_upper(S.data() + at, seqs[i], lens[i]);
+        at += lens[i];
         if (++done < non_empty) {  // sentinels only BETWEEN sequences (:280-288)
-            sentinels.push_back(S.size());
-            S.push_back(rc_sentinel(sidx++));
+            sentinels.push_back(at);
+            S[at++] = rc_sentinel(sidx++);
         }
     }
-    original_length = S.size();
+    original_length = at;
 }
 
 // restates identify_sentinel_factors, fasta_processor.cpp:131-163
