@@ -308,7 +308,9 @@ struct RegroupArgs {
     const uint32_t *act_slot; // later rounds: slot per list element
     uint32_t m;
     uint32_t *sa;
-    uint32_t *rank_val;       // rank per list element (when rank_by_slot == nullptr)
+    uint32_t *rank_val;       // (when rank_by_slot == nullptr) new rank of the elements whose rank changes ...
+    uint32_t *chg_idx;        // ... and their suffix starts, appended in any order; chg_count counts them
+    uint32_t *chg_count;
     uint32_t *rank_by_slot;   // rank per slot
     uint32_t *lcp;
     int sym_bits, tag_bits, bits, low_bits;  // round 0 key layout
@@ -376,11 +378,13 @@ __global__ __launch_bounds__(kFuseThreads) void regroup_kernel(RegroupArgs A) {
         if (lane == 63 && in && a + 1 < m) edge[k] = load_view(a + 1);
     }
     uint64_t hmask[kFuseItems], kmask[kFuseItems];  // wave-uniform: heads / kept elements of my segment
+    uint32_t old_head[kFuseItems];                  // later rounds: head slot of the group I come from
 #pragma unroll
     for (int k = 0; k < kFuseItems; ++k) {
         const size_t a = tile_base + (size_t)k * kFuseThreads + threadIdx.x;
         const bool in = (uint32_t)k * kFuseThreads + threadIdx.x < ext.count;
         const uint64_t v = view[k];
+        old_head[k] = (uint32_t)(v >> 32);
         // the element in front: the previous lane's, except for lane 0
         const uint64_t pv = ((uint64_t)lane_prev((uint32_t)(v >> 32), (uint32_t)(edge[k] >> 32)) << 32) |
                             lane_prev((uint32_t)v, (uint32_t)edge[k]);
@@ -474,11 +478,8 @@ __global__ __launch_bounds__(kFuseThreads) void regroup_kernel(RegroupArgs A) {
     __syncthreads();
     const uint32_t xmax = s_excl[0], xsum = s_excl[1];
 
-#pragma unroll
-    for (int k = 0; k < kFuseItems; ++k) {
-        const size_t a = tile_base + (size_t)k * kFuseThreads + threadIdx.x;
-        const bool in = (uint32_t)k * kFuseThreads + threadIdx.x < ext.count;
-        // slot of my group head: the last head at or in front of me
+    // slot of my group head: the last head at or in front of me
+    auto head_slot = [&](int k, size_t a) -> uint32_t {
         const uint64_t mine = hmask[k] & ((2ull << lane) - 1ull);
         const int hl = mine ? 63 - __builtin_clzll(mine) : lane;
         uint32_t head_of = kRound0 ? (uint32_t)(a - (size_t)(lane - hl)) : (uint32_t)__shfl((int)slot[k], hl, 64);
@@ -486,13 +487,58 @@ __global__ __launch_bounds__(kFuseThreads) void regroup_kernel(RegroupArgs A) {
             const uint32_t pm = s_seg_max[k * kWaves + w];
             head_of = pm > xmax ? pm : xmax;
         }
+        return head_of;
+    };
+    // Doubling rounds: rank[i] changes only for the members of groups that split off their old group
+    // (on long exact repeats a round moves a few hundred of 10^8 tied suffixes).  Those go, in any
+    // order, to the list that bucketed_scatter writes into rank[]: the tile counts them, takes its part
+    // of the list with ONE atomic, and every wavefront appends its own.
+    const bool list_changes = !kRound0 && !A.rank_by_slot;  // (uniform)
+    uint64_t cmask[kFuseItems];
+    uint32_t chg_base = 0;
+    if (list_changes) {
+        __shared__ uint32_t s_chg[kWaves + 1];
+        uint32_t mine_total = 0;
+#pragma unroll
+        for (int k = 0; k < kFuseItems; ++k) {
+            const size_t a = tile_base + (size_t)k * kFuseThreads + threadIdx.x;
+            const bool in = (uint32_t)k * kFuseThreads + threadIdx.x < ext.count;
+            cmask[k] = __ballot(in && head_slot(k, a) != old_head[k]);
+            mine_total += (uint32_t)__popcll(cmask[k]);
+        }
+        if (lane == 0) s_chg[w] = mine_total;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t all = 0;
+#pragma unroll
+            for (int k = 0; k < kWaves; ++k) {
+                const uint32_t c = s_chg[k];
+                s_chg[k] = all;
+                all += c;
+            }
+            s_chg[kWaves] = all ? atomicAdd(A.chg_count, all) : 0u;
+        }
+        __syncthreads();
+        chg_base = s_chg[kWaves] + s_chg[w];
+    }
+
+#pragma unroll
+    for (int k = 0; k < kFuseItems; ++k) {
+        const size_t a = tile_base + (size_t)k * kFuseThreads + threadIdx.x;
+        const bool in = (uint32_t)k * kFuseThreads + threadIdx.x < ext.count;
+        const uint32_t head_of = head_slot(k, a);
+        if (list_changes) {
+            if ((cmask[k] >> lane) & 1ull) {
+                const uint32_t q = chg_base + (uint32_t)__popcll(cmask[k] & lt);
+                A.chg_idx[q] = A.vals[a];
+                A.rank_val[q] = head_of + 1u;
+            }
+            chg_base += (uint32_t)__popcll(cmask[k]);
+        }
         if (!in) continue;
         // (round 0: the key sort left the suffixes in sa itself; direct round: group_refine_kernel did)
         if (!kRound0 && !A.sa_is_current) A.sa[slot[k]] = A.vals[a];
-        if (A.rank_by_slot)
-            A.rank_by_slot[slot[k]] = head_of + 1u;  // rank[] itself is written later, in one pass
-        else
-            A.rank_val[a] = head_of + 1u;  // goes to rank[i] through bucketed_scatter
+        if (A.rank_by_slot) A.rank_by_slot[slot[k]] = head_of + 1u;  // rank[] itself is written later, in one pass
         if ((kmask[k] >> lane) & 1ull) {  // surviving elements keep their slot, learn their group head
             const uint32_t kk = xsum + s_seg_sum[k * kWaves + w] + (uint32_t)__popcll(kmask[k] & lt);
             A.new_slot[kk] = slot[k];
@@ -520,6 +566,12 @@ __global__ __launch_bounds__(kThreads) void round_keys_kernel(const uint32_t *__
 // counting the smaller members of its own group -- one pass, no radix passes.  Members of
 // groups larger than kSmallGroup are flagged for the radix fallback instead.
 constexpr uint32_t kSmallGroup = 64;
+
+// *p = min(*p, v) for a value that millions of wavefronts report and that soon stops changing: look
+// first, the atomic only if it would lower the value (5 M atomics on one address cost 20 ms)
+__device__ __forceinline__ void lower_min(uint32_t *p, uint32_t v) {
+    if (*reinterpret_cast<volatile uint32_t *>(p) > v) atomicMin(p, v);
+}
 
 __global__ __launch_bounds__(kThreads) void small_sort_kernel(const uint32_t *__restrict__ act_slot,
                                                               const uint32_t *__restrict__ act_grp,
@@ -587,7 +639,7 @@ template <int BITS>
 __global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void group_refine_kernel(
     const uint32_t *__restrict__ act_slot, const uint32_t *__restrict__ act_grp, uint32_t *sa,
     const uint64_t *__restrict__ words, TermTable terms, uint32_t m, uint32_t h0, uint32_t cap,
-    uint32_t *__restrict__ out_lo, uint32_t *__restrict__ lcp_list) {
+    uint32_t *__restrict__ out_lo, uint32_t *__restrict__ lcp_list, uint32_t *__restrict__ min_depth) {
     constexpr int kW32 = 2 * kRefineWords;  // window in 32-bit words, text order
     constexpr int kChunks = kW32 / 4;
     constexpr uint32_t kPer32 = 32 / BITS;
@@ -638,6 +690,9 @@ __global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(
         // too large for this round: stays one group, in place.  Its first kSmallGroup members are
         // written by the tile it starts in, the others by the tile that owns their list position.
         if ((large && j < kSmallGroup) || (a < a1 && j >= kSmallGroup)) out_lo[a] = 0;  // (sa keeps its order)
+        // the symbols every group that stays tied is known to agree on: h0 for the groups this round does
+        // not touch, the depth reached for the others (the doubling rounds start from the minimum)
+        if (large && j == 0) lower_min(min_depth, h0);
         if (starts_here && !large) {
             my_gs = (int)sz;
             my_j = (int)j;
@@ -674,6 +729,7 @@ __global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(
             handled = gend <= (uint32_t)kPairCap;
             if (handled && my_j == my_gs - 1) atomicMax(&s_npairs, gend);
             if (!handled) out_lo[a] = 0;  // no room for its pairs: the group stays as it is
+            if (!handled && my_j == 0) lower_min(min_depth, h0);
         }
         __syncthreads();
         npairs = s_npairs;
@@ -689,6 +745,7 @@ __global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(
     const uint64_t lt = lanemask_lt();
 
     int cur = 0;
+    uint32_t depth = h0;
     if (npairs > 0) {
         for (uint32_t h = h0; h < cap; h += kPerRound) {
             if (s_tied[cur][t]) {  // the next kRefineWords words of my suffix, from symbol h
@@ -774,6 +831,7 @@ __global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(
             }
             cnt = kept;
             cur ^= 1;
+            depth = h + kPerRound;  // pairs that are still tied agree on a whole window more
             // A workgroup that is still mostly tied after two windows sits on a long exact repeat:
             // comparing on to the cap would cost a window fetch per member per round for nothing.
             // Leave those ties to the doubling rounds, which need only log2(LCP) steps.
@@ -782,6 +840,7 @@ __global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(
         }
     }
 
+    if (cnt > 0 && lane == 0) lower_min(min_depth, depth);
     // ---- members still tied keep their list order: count the tied partners in front of me --------
     // (s_goff is free now)
     s_goff[t] = 0;
@@ -865,6 +924,8 @@ uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *grp, const 
         A.sa_is_current = sa_is_current ? 1 : 0;
         A.keys = keys; A.keys32 = keys32; A.seg = seg ? *seg : SegView{}; A.num_tiles = (uint32_t)tiles; A.grp = grp; A.lo = lo; A.vals = vals; A.act_slot = act_slot; A.m = m;
         A.sa = sa; A.rank_val = rank_val; A.rank_by_slot = rank_by_slot; A.lcp = lcp;
+        A.chg_idx = scratch_idx; A.chg_count = d_total + 2;
+        HIP_CHECK(hipMemsetAsync(d_total + 2, 0, sizeof(uint32_t), s));
         A.sym_bits = sym_bits; A.tag_bits = tag_bits; A.bits = bits; A.low_bits = low_bits;
         A.lcp_list = lcp_list; A.dbl_h = dbl_h; A.Plcp = Plcp;
         A.new_slot = new_slot; A.new_grp = new_grp;
@@ -877,15 +938,18 @@ uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *grp, const 
         HIP_CHECK(hipMemcpyAsync(d_total + 1, A.ticket + 1, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
     }
     ctx.arena.rewind(pmark);
-    if (!rank_by_slot) {
-        // rank[vals[a]] = rank_val[a]: the one truly random write of the round
-        ProfScope ps(ctx.profiler(), "sa_rank_scatter", s);
-        uint32_t *idx[2] = {vals, scratch_idx};
-        uint32_t *val[2] = {rank_val, scratch_val};
-        bucketed_scatter(idx, val, m, rank, n, ctx.arena, s, ctx.profiler(), false);
-    }
-    ctx.read_back(d_total, total, 2);
+    uint32_t total3[3] = {0, 0, 0};
+    ctx.read_back(d_total, total3, 3);
+    total[0] = total3[0];
+    total[1] = total3[1];
     if (total[1]) throw HipError("suffix array: look-back scan timed out");
+    if (!rank_by_slot && total3[2] > 0) {
+        // rank[start] = new rank for the elements whose rank changed: the one truly random write of the round
+        ProfScope ps(ctx.profiler(), "sa_rank_scatter", s);
+        uint32_t *idx[2] = {scratch_idx, vals};
+        uint32_t *val[2] = {rank_val, scratch_val};
+        bucketed_scatter(idx, val, total3[2], rank, n, ctx.arena, s, ctx.profiler(), false);
+    }
     return total[0];
 }
 
@@ -1102,7 +1166,7 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     uint32_t *rank_by_slot = arena.alloc<uint32_t>(n);
     uint32_t *scratch_idx = arena.alloc<uint32_t>(n);
     uint32_t *scratch_val = arena.alloc<uint32_t>(n);
-    uint32_t *d_total = arena.alloc<uint32_t>(2);
+    uint32_t *d_total = arena.alloc<uint32_t>(4);  // survivors, look-back error flag, elements whose rank changed
     uint32_t *seg_mem = arena.alloc<uint32_t>((size_t)kSegDescWords * (div_up(n, kSortTile) + 257));  // 16-byte aligned
     uint32_t *rank = isa;
 
@@ -1201,21 +1265,23 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         // at most 32 words (1024 bases of DNA) deep; longer ties are cheaper in the doubling rounds
         static const uint32_t cap_words = getenv("NOLZSS_REFINE_WORDS") ? (uint32_t)atoi(getenv("NOLZSS_REFINE_WORDS")) : 32u;
         const uint32_t cap = (uint32_t)k_syms + cap_words * (64u / (uint32_t)text.bits);
+        uint32_t *d_min_depth = arena.alloc<uint32_t>(1);
+        HIP_CHECK(hipMemsetAsync(d_min_depth, 0xff, sizeof(uint32_t), s));
         {
             ProfScope ps(ctx.profiler(), "sa_direct_sort", s);
             const unsigned g = (unsigned)div_up(m, kRefineTile);
             switch (text.bits) {
             case 2:
                 group_refine_kernel<2><<<g, kRefineThreads, 0, s>>>(slot, grp, sa, text.words, text.terms, m, (uint32_t)h, cap,
-                                                              out_lo, lcp_list);
+                                                              out_lo, lcp_list, d_min_depth);
                 break;
             case 4:
                 group_refine_kernel<4><<<g, kRefineThreads, 0, s>>>(slot, grp, sa, text.words, text.terms, m, (uint32_t)h, cap,
-                                                              out_lo, lcp_list);
+                                                              out_lo, lcp_list, d_min_depth);
                 break;
             default:
                 group_refine_kernel<8><<<g, kRefineThreads, 0, s>>>(slot, grp, sa, text.words, text.terms, m, (uint32_t)h, cap,
-                                                              out_lo, lcp_list);
+                                                              out_lo, lcp_list, d_min_depth);
                 break;
             }
             KERNEL_CHECK();
@@ -1225,8 +1291,15 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
                            0, 0, 0, lcp_list, 0, (uint32_t)h, rank_by_slot, nullptr, nullptr, nullptr, 0u,
                            /*sa_is_current=*/true);
         a_cur ^= 1;
-        if (trace) fprintf(stderr, "[nolzss]   direct round (cap %u symbols): %u still tied\n", cap, m);
-        // h stays K: the large groups are only K-sorted
+        // every group that is still tied agrees on at least min_depth symbols (K if a group was too large
+        // for the round, more if the round left all its ties at the cap or at a bail-out depth): the
+        // doubling rounds start there instead of repeating the steps K, 2K, 4K, ...
+        if (m > 0) {
+            uint32_t depth = 0;
+            ctx.read_back(d_min_depth, &depth, 1);
+            if (depth != 0xffffffffu && depth > h) h = depth;
+        }
+        if (trace) fprintf(stderr, "[nolzss]   direct round (cap %u symbols): %u still tied, on at least %llu symbols\n", cap, m, (unsigned long long)h);
     }
     write_all_ranks();
 

@@ -1,0 +1,32 @@
+"""Wall time on degenerate texts (one run, short periods, Fibonacci words, two copies of a random text)."""
+import sys, time
+from pathlib import Path
+R = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(R)); sys.path.insert(0, str(R / 'tests'))
+import numpy as np
+import gen
+from nolzss_amd import _noLZSS as native
+lg = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+n = 1 << lg
+
+
+def fib(n):
+    a, b = b"A", b"AC"
+    while len(b) < n:
+        a, b = b, b + a
+    return np.frombuffer(b[:n], dtype=np.uint8)
+
+
+half = gen.random_dna(n // 2, 3)
+cases = {
+    "one run A^n": np.full(n, ord("A"), dtype=np.uint8),
+    "(AC)^(n/2)": np.tile(np.frombuffer(b"AC", dtype=np.uint8), n // 2),
+    "period 1000": np.tile(gen.random_dna(1000, 1), n // 1000 + 1)[:n],
+    "Fibonacci word": fib(n),
+    "two copies of a random text": np.concatenate([half, half]),
+    "random": gen.random_dna(n, 2),
+}
+native.count_factors(cases["random"][:1 << 16])
+for name, t in cases.items():
+    t0 = time.time(); z = native.count_factors(t); dt = time.time() - t0
+    print(f"2^{lg} {name}: {dt*1e3:.1f} ms, z={z}", flush=True)
