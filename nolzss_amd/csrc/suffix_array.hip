@@ -547,6 +547,123 @@ __global__ __launch_bounds__(kFuseThreads) void regroup_kernel(RegroupArgs A) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Long exact repeats.  After the direct round a text with long repeats (two similar genomes, a duplicated
+// region) is left with millions of groups of exactly TWO suffixes, i and j = i + d, that agree on more
+// than the cap.  Doubling would need log2(repeat length) rounds over all of them although the answer
+// is arithmetic: LCP(i, j) = 1 + LCP(i + 1, j + 1) and the order of (i, j) is the order of (i + 1, j + 1).
+// Along a RUN of text positions i, i + 1, ... whose partners keep the same distance d, everything follows
+// from the pair behind the end of the run, and that pair is already separated (different groups: order and
+// LCP come from the rank codes and the range minimum of the LCP values decided so far, the same rule a
+// doubling step uses with h = 1).  Runs are contiguous in TEXT order, so "the end of my run" is one
+// prefix scan, not pointer jumping.  Runs whose end pair is itself undecided (three or more copies) are
+// left to the doubling rounds.
+// ---------------------------------------------------------------------------------------
+// delta[i] = partner - i if suffix i is in an undecided group of exactly two, else 0
+__global__ __launch_bounds__(kThreads) void pair_delta_kernel(const uint32_t *__restrict__ rank,
+                                                              const uint32_t *__restrict__ sa,
+                                                              const uint32_t *__restrict__ lcp, uint32_t n,
+                                                              int32_t *__restrict__ delta) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t g = rank[i] - 1u;  // head slot of my group
+        int32_t d = 0;
+        if (g + 1u < n && lcp[g + 1] >= kLcpPendingMin && (g + 2u >= n || lcp[g + 2] < kLcpPendingMin)) {
+            const uint32_t a = sa[g], b = sa[g + 1];
+            d = (int32_t)((a == (uint32_t)i ? b : a) - (uint32_t)i);
+        }
+        delta[i] = d;
+    }
+}
+
+// does the run go on behind position t?
+__device__ __forceinline__ bool run_goes_on(const int32_t *__restrict__ delta, uint32_t n, size_t t) {
+    const int32_t d = delta[t];
+    return d != 0 && t + 1 < n && delta[t + 1] == d;
+}
+
+// rev[n - 1 - t] = (n - 1 - t) + 1 where a run ends at t (or t is in no run), else 0: an inclusive
+// max-scan over rev then names, for every t, the nearest end at or behind it
+__global__ __launch_bounds__(kThreads) void run_breaks_kernel(const int32_t *__restrict__ delta, uint32_t n,
+                                                              uint32_t *__restrict__ rev) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride)
+        rev[n - 1 - t] = run_goes_on(delta, n, t) ? 0u : (uint32_t)(n - 1 - t) + 1u;
+}
+
+constexpr uint32_t kRunDeferred = 0xffffffffu;
+
+// at the end t of a run (smaller member of the pair): LCP and order of the pair from the pair behind it
+__global__ __launch_bounds__(kThreads) void run_ends_kernel(const int32_t *__restrict__ delta,
+                                                            const uint32_t *__restrict__ rank, uint32_t n,
+                                                            Pyramid Plcp, uint32_t *__restrict__ end_lcp,
+                                                            uint32_t *__restrict__ end_first) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
+        const int32_t d = delta[t];
+        if (d <= 0 || run_goes_on(delta, n, t)) continue;
+        const size_t u = t + 1, v = t + 1 + (size_t)d;
+        uint32_t l = kRunDeferred, first = 0;
+        if (v < n) {
+            const uint32_t ru = rank[u], rv = rank[v];  // rank codes: head slot + 1
+            if (ru != rv) {
+                const uint32_t lo = ru < rv ? ru : rv, hi = ru < rv ? rv : ru;
+                l = 1u + pyr_range<false>(Plcp, lo, hi - 1u);
+                first = ru < rv ? 1u : 0u;  // 1: suffix t sorts in front of its partner
+            }
+        }
+        end_lcp[t] = l;
+        end_first[t] = first;
+    }
+}
+
+// every pair of a run whose end is decided: final order, LCP and ranks
+__global__ __launch_bounds__(kThreads) void run_members_kernel(const int32_t *__restrict__ delta,
+                                                               const uint32_t *__restrict__ end_of, uint32_t n,
+                                                               const uint32_t *__restrict__ end_lcp,
+                                                               const uint32_t *__restrict__ end_first,
+                                                               uint32_t *__restrict__ rank, uint32_t *__restrict__ sa,
+                                                               uint32_t *__restrict__ lcp) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int32_t d = delta[i];
+        if (d <= 0) continue;
+        const uint32_t e = (uint32_t)(n - 1) - (end_of[n - 1 - i] - 1u);  // end of my run (>= i)
+        const uint32_t le = end_lcp[e];
+        if (le == kRunDeferred) continue;
+        const uint32_t g = rank[i] - 1u;
+        const uint32_t j = (uint32_t)i + (uint32_t)d;
+        const bool i_first = end_first[e] != 0;
+        sa[g] = i_first ? (uint32_t)i : j;
+        sa[g + 1] = i_first ? j : (uint32_t)i;
+        lcp[g + 1] = le + (e - (uint32_t)i);
+        rank[i_first ? j : (uint32_t)i] = g + 2u;  // the second one is a group of its own now
+    }
+}
+
+// 1 for the active elements whose group is still undecided
+__global__ __launch_bounds__(kThreads) void still_tied_kernel(const uint32_t *__restrict__ act_grp, uint32_t m,
+                                                              const uint32_t *__restrict__ lcp,
+                                                              uint32_t *__restrict__ keep) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x; a < m; a += stride)
+        keep[a] = lcp[act_grp[a] + 1] >= kLcpPendingMin ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(kThreads) void compact_active_kernel(const uint32_t *__restrict__ act_slot,
+                                                                  const uint32_t *__restrict__ act_grp,
+                                                                  const uint32_t *__restrict__ keep,
+                                                                  const uint32_t *__restrict__ pos, uint32_t m,
+                                                                  uint32_t *__restrict__ new_slot,
+                                                                  uint32_t *__restrict__ new_grp) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x; a < m; a += stride)
+        if (keep[a]) {
+            new_slot[pos[a]] = act_slot[a];
+            new_grp[pos[a]] = act_grp[a];
+        }
+}
+
 // secondary key of a doubling round: rank of the suffix h symbols further on (0 past the end)
 __global__ __launch_bounds__(kThreads) void round_keys_kernel(const uint32_t *__restrict__ act_slot,
                                                               uint32_t m, const uint32_t *__restrict__ sa,
@@ -1305,9 +1422,47 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
 
     // one range-minimum pyramid over the LCP values known so far; the regroup kernel keeps it current
     Pyramid Plcp{};
+    const size_t pyr_mark = arena.mark();
     if (m > 0) {
         ProfScope ps(ctx.profiler(), "sa_lcp_pyramid", s);
         Plcp = build_pyramid(lcp, n + 1, false, arena, s);
+    }
+
+    // ---- long exact repeats: pairs along runs of text positions are finished arithmetically -------
+    // (worth its five passes over the text only when a large part of it is still tied;
+    // NOLZSS_PAIR_RUNS_MIN: smallest number of tied suffixes for which it runs, the tests set 1)
+    static const long long pair_runs_min = getenv("NOLZSS_PAIR_RUNS_MIN") ? atoll(getenv("NOLZSS_PAIR_RUNS_MIN")) : -1;
+    if (m > 0 && (pair_runs_min >= 0 ? (long long)m >= pair_runs_min : m >= n / 16)) {
+        ProfScope ps(ctx.profiler(), "sa_pair_runs", s);
+        int32_t *delta = reinterpret_cast<int32_t *>(tmp_a);
+        uint32_t *rev = tmp_b, *end_of = tmp_c, *end_lcp = scratch_idx, *end_first = scratch_val;
+        const unsigned g = grid_for(n, kThreads, 256u * 64u);
+        pair_delta_kernel<<<g, kThreads, 0, s>>>(rank, sa, lcp, n, delta);
+        KERNEL_CHECK();
+        run_breaks_kernel<<<g, kThreads, 0, s>>>(delta, n, rev);
+        KERNEL_CHECK();
+        scan_inclusive_max_u32(rev, end_of, n, arena, s);
+        run_ends_kernel<<<g, kThreads, 0, s>>>(delta, rank, n, Plcp, end_lcp, end_first);
+        KERNEL_CHECK();
+        run_members_kernel<<<g, kThreads, 0, s>>>(delta, end_of, n, end_lcp, end_first, rank, sa, lcp);
+        KERNEL_CHECK();
+        // the active list without the pairs that are done, and the pyramid over the new LCP values
+        uint32_t *keep = tmp_a, *pos = tmp_b;
+        still_tied_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(act_grp[a_cur], m, lcp, keep);
+        KERNEL_CHECK();
+        scan_exclusive_add_u32(keep, pos, m, d_total, arena, s);
+        compact_active_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(act_slot[a_cur], act_grp[a_cur], keep, pos, m,
+                                                                       act_slot[a_cur ^ 1], act_grp[a_cur ^ 1]);
+        KERNEL_CHECK();
+        uint32_t left = 0;
+        ctx.read_back(d_total, &left, 1);
+        if (trace) fprintf(stderr, "[nolzss]   pair runs: %u of %u tied suffixes finished\n", m - left, m);
+        m = left;
+        a_cur ^= 1;
+        if (m > 0) {
+            arena.rewind(pyr_mark);
+            Plcp = build_pyramid(lcp, n + 1, false, arena, s);
+        }
     }
 
     while (m > 0) {

@@ -192,3 +192,75 @@ print("ok", len(cases))
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_pair_runs_on_long_exact_repeats():
+    """Long exact repeats leave pairs of suffixes tied beyond the cap of the direct round; along runs of
+    text positions they are finished arithmetically (suffix_array.hip, pair_delta_kernel ...).  One child
+    process with a tiny cap (NOLZSS_REFINE_WORDS=1: 49 symbols) and NOLZSS_PAIR_RUNS_MIN=1 sends every
+    repeat longer than that through this path: two and three copies, copies with substitutions, nested and
+    overlapping repeats, repeats that end at the end of the text, other alphabets, reverse complement."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys
+sys.path.insert(0, "tests")
+import numpy as np
+import gen, oracle_lib as oracle
+from nolzss_amd import _noLZSS as native
+rng = np.random.default_rng(5)
+def rnd(n, seed): return gen.random_dna(n, seed)
+def mutate(x, k, seed):
+    y = x.copy(); r = np.random.default_rng(seed)
+    idx = r.integers(0, len(y), size=k); y[idx] = np.frombuffer(b"ACGT", dtype=np.uint8)[r.integers(0, 4, size=k)]
+    return y
+a, b, c = rnd(5000, 1), rnd(3000, 2), rnd(777, 3)
+cases = [
+    np.concatenate([a, a]),                                  # two copies, the repeat ends with the text
+    np.concatenate([a, b, a]),                               # two copies apart
+    np.concatenate([a, a, a]),                               # three copies: groups of three (left to doubling)
+    np.concatenate([a, b, a, c, a[:2000], b]),               # nested / partial copies
+    np.concatenate([a, mutate(a, 5, 9)]),                    # a copy with substitutions: several runs
+    np.concatenate([a, mutate(a, 60, 10), mutate(a, 3, 11)]),
+    np.concatenate([a[:100], a[:100]]),                      # repeats barely longer than the cap
+    np.concatenate([a[:60], c, a[:60], c[:50], a[:60]]),
+    np.concatenate([c, c, b, b, c]),
+    np.tile(a[:300], 7),                                     # period 300
+    gen.repeat_dna(200000, 77, lo=64, hi=20000),
+    np.concatenate([rnd(100000, 4), rnd(100000, 4)]),
+    np.concatenate([rnd(70000, 5), mutate(rnd(70000, 5), 40, 6), rnd(1000, 7)]),
+]
+texts = [bytes(x) for x in cases]
+texts += [b"abracadabra, " * 300 + b"simsalabim" * 100 + b"abracadabra, " * 300,   # 8-bit alphabet
+          bytes(np.concatenate([rnd(4000, 8), rnd(4000, 8)]) + 1)]               # other symbols, sigma = 4
+for t in texts:
+    got = native.factorize_array(t)
+    exp = oracle.factors_array(t)
+    assert len(got) == len(exp), (len(t), len(got), len(exp))
+    for k in ("start", "length", "ref"):
+        assert np.array_equal(got[k], exp[k]), (len(t), k)
+    d = native.debug_arrays(t)
+    sa = oracle.suffix_array(t)
+    assert np.array_equal(d["sa"].astype(np.int64), sa.astype(np.int64)), len(t)
+    assert np.array_equal(d["lcp"][:len(t)].astype(np.int64), oracle.lcp_array(t, sa).astype(np.int64)), len(t)
+    isa = np.empty(len(t), dtype=np.int64); isa[sa] = np.arange(len(t))
+    assert np.array_equal(d["isa"].astype(np.int64), isa), len(t)
+# reverse complement: the prepared string holds every sequence twice
+for seqs in ([bytes(a)], [bytes(a), bytes(a)], [bytes(a[:3000]), bytes(b), bytes(a[:3000])]):
+    S, orig, sent = native.prepare_multiple_dna_sequences_w_rc_bytes(seqs)
+    assert native.factorize_multiple_dna_w_rc(S) == oracle.factorize_multiple_dna_w_rc(S), len(seqs)
+# the merged batch: independent records that are copies of each other or hold repeats
+recs = [a, a.copy(), np.concatenate([b, b]), np.concatenate([c, a[:1000], c]), b]
+counts, arrays = native.factorize_batch(recs, want_factors=True)
+for r, f in zip(recs, arrays):
+    e = oracle.factors_array(r)
+    assert len(f) == len(e) and all(np.array_equal(f[k], e[k]) for k in ("start", "length", "ref"))
+print("ok", len(texts))
+'''
+    env = dict(os.environ, NOLZSS_REFINE_WORDS="1", NOLZSS_PAIR_RUNS_MIN="1", NOLZSS_TRACE="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    done = [int(line.split("pair runs:")[1].split()[0]) for line in r.stderr.splitlines() if "pair runs:" in line]
+    assert len(done) >= 15 and sum(done) > 100000, done  # the path ran and finished pairs
