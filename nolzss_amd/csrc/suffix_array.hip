@@ -548,96 +548,184 @@ __global__ __launch_bounds__(kFuseThreads) void regroup_kernel(RegroupArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Long exact repeats.  After the direct round a text with long repeats (two similar genomes, a duplicated
-// region) is left with millions of groups of exactly TWO suffixes, i and j = i + d, that agree on more
-// than the cap.  Doubling would need log2(repeat length) rounds over all of them although the answer
-// is arithmetic: LCP(i, j) = 1 + LCP(i + 1, j + 1) and the order of (i, j) is the order of (i + 1, j + 1).
-// Along a RUN of text positions i, i + 1, ... whose partners keep the same distance d, everything follows
-// from the pair behind the end of the run, and that pair is already separated (different groups: order and
-// LCP come from the rank codes and the range minimum of the LCP values decided so far, the same rule a
-// doubling step uses with h = 1).  Runs are contiguous in TEXT order, so "the end of my run" is one
-// prefix scan, not pointer jumping.  Runs whose end pair is itself undecided (three or more copies) are
-// left to the doubling rounds.
+// Long exact repeats.  After the direct round a text with long repeats (similar genomes, a duplicated
+// region) is left with millions of small groups of suffixes -- i and i + d for two copies -- that agree
+// on more than the cap.  Doubling would need log2(repeat length) rounds over all of them although the
+// answer is arithmetic: LCP(i, j) = 1 + LCP(i + 1, j + 1), and the order of (i, j) is the order of
+// (i + 1, j + 1).  Along a RUN of text positions i, i + 1, ... whose groups keep the same shape (the same
+// distances between the members), everything follows from the group behind the end of the run, and that
+// one is already separated (its members carry different rank codes): the order is the order of the codes,
+// the LCP of neighbours 1 + the range minimum of the LCP values decided so far -- the rule a doubling step
+// applies, with h = 1.  Runs are contiguous in TEXT order, so "where does my run end" is one prefix scan,
+// not pointer jumping.  Groups of up to kRunGroupMax members are handled; runs whose end group is only
+// partly separated are left to the doubling rounds.
 // ---------------------------------------------------------------------------------------
-// delta[i] = partner - i if suffix i is in an undecided group of exactly two, else 0
-__global__ __launch_bounds__(kThreads) void pair_delta_kernel(const uint32_t *__restrict__ rank,
+constexpr uint32_t kRunGroupMax = 8;
+
+// members of the undecided group with head slot g: k = its size (0: decided or too large)
+__device__ __forceinline__ uint32_t run_group_size(const uint32_t *__restrict__ lcp, uint32_t n, uint32_t g) {
+    uint32_t k = 1;
+    while (k <= kRunGroupMax && g + k < n && lcp[g + k] >= kLcpPendingMin) ++k;
+    return (k >= 2 && k <= kRunGroupMax) ? k : 0u;
+}
+
+// link[i] = (next member of my group in text order, cyclically) - i, gsz[i] = size of my group; 0 / 0 if
+// suffix i is decided or its group is too large
+__global__ __launch_bounds__(kThreads) void group_link_kernel(const uint32_t *__restrict__ rank,
                                                               const uint32_t *__restrict__ sa,
                                                               const uint32_t *__restrict__ lcp, uint32_t n,
-                                                              int32_t *__restrict__ delta) {
+                                                              uint32_t *__restrict__ link, uint32_t *__restrict__ gsz) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const uint32_t g = rank[i] - 1u;  // head slot of my group
-        int32_t d = 0;
-        if (g + 1u < n && lcp[g + 1] >= kLcpPendingMin && (g + 2u >= n || lcp[g + 2] < kLcpPendingMin)) {
-            const uint32_t a = sa[g], b = sa[g + 1];
-            d = (int32_t)((a == (uint32_t)i ? b : a) - (uint32_t)i);
+        const uint32_t k = run_group_size(lcp, n, g);
+        uint32_t d = 0;
+        if (k) {
+            uint32_t above = 0xffffffffu, lowest = 0xffffffffu;
+            for (uint32_t x = 0; x < k; ++x) {
+                const uint32_t m = sa[g + x];
+                lowest = m < lowest ? m : lowest;
+                if (m > (uint32_t)i && m < above) above = m;
+            }
+            d = (above != 0xffffffffu ? above : lowest) - (uint32_t)i;
         }
-        delta[i] = d;
+        link[i] = d;
+        gsz[i] = d ? k : 0u;
     }
 }
 
-// does the run go on behind position t?
-__device__ __forceinline__ bool run_goes_on(const int32_t *__restrict__ delta, uint32_t n, size_t t) {
-    const int32_t d = delta[t];
-    return d != 0 && t + 1 < n && delta[t + 1] == d;
+// does the chain of position t go on at t + 1?
+__device__ __forceinline__ bool run_goes_on(const uint32_t *__restrict__ link, const uint32_t *__restrict__ gsz,
+                                            uint32_t n, size_t t) {
+    const uint32_t d = link[t];
+    return d != 0 && t + 1 < n && link[t + 1] == d && gsz[t + 1] == gsz[t];
 }
 
-// rev[n - 1 - t] = (n - 1 - t) + 1 where a run ends at t (or t is in no run), else 0: an inclusive
-// max-scan over rev then names, for every t, the nearest end at or behind it
-__global__ __launch_bounds__(kThreads) void run_breaks_kernel(const int32_t *__restrict__ delta, uint32_t n,
+// rev[n - 1 - t] = (n - 1 - t) + 1 where the chain of t ends at t (or t is in no group), else 0: an
+// inclusive max-scan over rev then names, for every t, the nearest such end at or behind it
+__global__ __launch_bounds__(kThreads) void run_breaks_kernel(const uint32_t *__restrict__ link,
+                                                              const uint32_t *__restrict__ gsz, uint32_t n,
                                                               uint32_t *__restrict__ rev) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride)
-        rev[n - 1 - t] = run_goes_on(delta, n, t) ? 0u : (uint32_t)(n - 1 - t) + 1u;
+        rev[n - 1 - t] = run_goes_on(link, gsz, n, t) ? 0u : (uint32_t)(n - 1 - t) + 1u;
+}
+
+// togo[i] = steps until the run of my GROUP ends: the shortest chain of its members (the group one
+// step further on is my group shifted by one only while every member's chain goes on)
+__global__ __launch_bounds__(kThreads) void group_run_kernel(const uint32_t *__restrict__ gsz,
+                                                             const uint32_t *__restrict__ rank,
+                                                             const uint32_t *__restrict__ sa,
+                                                             const uint32_t *__restrict__ end_of, uint32_t n,
+                                                             uint32_t *__restrict__ togo) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t k = gsz[i];
+        if (k <= 2) continue;  // (a pair's two chains are equally long: run_steps takes its own)
+        const uint32_t g = rank[i] - 1u;
+        uint32_t best = 0xffffffffu;
+        for (uint32_t x = 0; x < k; ++x) {
+            const uint32_t m = sa[g + x];
+            const uint32_t e = (uint32_t)(n - 1) - (end_of[n - 1 - m] - 1u);  // where the chain of m ends (>= m)
+            best = e - m < best ? e - m : best;
+        }
+        togo[i] = best;
+    }
+}
+
+// steps from position i to the end of its group's run
+__device__ __forceinline__ uint32_t run_steps(uint32_t k, size_t i, uint32_t n, const uint32_t *__restrict__ end_of,
+                                              const uint32_t *__restrict__ togo) {
+    if (k > 2) return togo[i];
+    return ((uint32_t)(n - 1) - (end_of[n - 1 - i] - 1u)) - (uint32_t)i;
 }
 
 constexpr uint32_t kRunDeferred = 0xffffffffu;
 
-// at the end t of a run (smaller member of the pair): LCP and order of the pair from the pair behind it
-__global__ __launch_bounds__(kThreads) void run_ends_kernel(const int32_t *__restrict__ delta,
-                                                            const uint32_t *__restrict__ rank, uint32_t n,
-                                                            Pyramid Plcp, uint32_t *__restrict__ end_lcp,
-                                                            uint32_t *__restrict__ end_first) {
+// members of a group at the end of its run: place inside the group and LCP to the predecessor there,
+// from the rank codes of the suffixes one symbol further on
+__global__ __launch_bounds__(kThreads) void group_end_kernel(const uint32_t *__restrict__ gsz,
+                                                             const uint32_t *__restrict__ togo,
+                                                             const uint32_t *__restrict__ end_of,
+                                                             const uint32_t *__restrict__ rank,
+                                                             const uint32_t *__restrict__ sa, uint32_t n, Pyramid Plcp,
+                                                             uint32_t *__restrict__ end_place,
+                                                             uint32_t *__restrict__ end_lcp,
+                                                             uint32_t *__restrict__ deferred) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
-        const int32_t d = delta[t];
-        if (d <= 0 || run_goes_on(delta, n, t)) continue;
-        const size_t u = t + 1, v = t + 1 + (size_t)d;
-        uint32_t l = kRunDeferred, first = 0;
-        if (v < n) {
-            const uint32_t ru = rank[u], rv = rank[v];  // rank codes: head slot + 1
-            if (ru != rv) {
-                const uint32_t lo = ru < rv ? ru : rv, hi = ru < rv ? rv : ru;
-                l = 1u + pyr_range<false>(Plcp, lo, hi - 1u);
-                first = ru < rv ? 1u : 0u;  // 1: suffix t sorts in front of its partner
+        const uint32_t k = gsz[t];
+        if (!k || run_steps(k, t, n, end_of, togo) != 0) continue;
+        const uint32_t g = rank[t] - 1u;
+        uint32_t place = 0, l = 0;
+        if (t + 1 >= n) {
+            place = kRunDeferred;
+        } else {
+            const uint32_t mine = rank[t + 1];  // rank code (head slot + 1) of my suffix one symbol further on
+            uint32_t pred = 0;                  // largest code below mine
+            for (uint32_t x = 0; x < k && place != kRunDeferred; ++x) {
+                const uint32_t m = sa[g + x];
+                if (m == (uint32_t)t) continue;
+                if ((size_t)m + 1 >= n) {
+                    place = kRunDeferred;
+                    break;
+                }
+                const uint32_t c = rank[m + 1];
+                if (c == mine) {  // not separated from that member: the doubling rounds take the group
+                    place = kRunDeferred;
+                } else if (c < mine) {
+                    ++place;
+                    pred = c > pred ? c : pred;
+                }
             }
+            if (place != kRunDeferred && place > 0) l = 1u + pyr_range<false>(Plcp, pred, mine - 1u);
         }
+        end_place[t] = place;
         end_lcp[t] = l;
-        end_first[t] = first;
+        if (k == 2) deferred[t] = place == kRunDeferred ? 1u : 0u;  // (the two members of a pair see each other)
     }
 }
 
-// every pair of a run whose end is decided: final order, LCP and ranks
-__global__ __launch_bounds__(kThreads) void run_members_kernel(const int32_t *__restrict__ delta,
-                                                               const uint32_t *__restrict__ end_of, uint32_t n,
-                                                               const uint32_t *__restrict__ end_lcp,
-                                                               const uint32_t *__restrict__ end_first,
-                                                               uint32_t *__restrict__ rank, uint32_t *__restrict__ sa,
-                                                               uint32_t *__restrict__ lcp) {
+// every member of every group of a run whose end group is separated: final slot, LCP and rank.
+// (A group is deferred as a whole: two members that tie at the end see each other.  A member that is
+// separated from all others while two OTHERS tie must not be placed either, hence the second pass over the
+// end group's verdicts through `deferred`.)
+__global__ __launch_bounds__(kThreads) void group_verdict_kernel(const uint32_t *__restrict__ gsz,
+                                                                 const uint32_t *__restrict__ togo,
+                                                                 const uint32_t *__restrict__ rank,
+                                                                 const uint32_t *__restrict__ sa, uint32_t n,
+                                                                 const uint32_t *__restrict__ end_place,
+                                                                 uint32_t *__restrict__ deferred) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
+        const uint32_t k = gsz[t];
+        if (k <= 2 || togo[t] != 0) continue;
+        const uint32_t g = rank[t] - 1u;
+        uint32_t bad = 0;
+        for (uint32_t x = 0; x < k; ++x) bad |= end_place[sa[g + x]] == kRunDeferred ? 1u : 0u;
+        deferred[t] = bad;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void group_members_kernel(const uint32_t *__restrict__ gsz,
+                                                                 const uint32_t *__restrict__ togo,
+                                                                 const uint32_t *__restrict__ end_of, uint32_t n,
+                                                                 const uint32_t *__restrict__ end_place,
+                                                                 const uint32_t *__restrict__ end_lcp,
+                                                                 const uint32_t *__restrict__ deferred,
+                                                                 uint32_t *__restrict__ rank, uint32_t *__restrict__ sa,
+                                                                 uint32_t *__restrict__ lcp) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const int32_t d = delta[i];
-        if (d <= 0) continue;
-        const uint32_t e = (uint32_t)(n - 1) - (end_of[n - 1 - i] - 1u);  // end of my run (>= i)
-        const uint32_t le = end_lcp[e];
-        if (le == kRunDeferred) continue;
-        const uint32_t g = rank[i] - 1u;
-        const uint32_t j = (uint32_t)i + (uint32_t)d;
-        const bool i_first = end_first[e] != 0;
-        sa[g] = i_first ? (uint32_t)i : j;
-        sa[g + 1] = i_first ? j : (uint32_t)i;
-        lcp[g + 1] = le + (e - (uint32_t)i);
-        rank[i_first ? j : (uint32_t)i] = g + 2u;  // the second one is a group of its own now
+        const uint32_t k = gsz[i];
+        if (!k) continue;
+        const uint32_t steps = run_steps(k, i, n, end_of, togo);
+        const size_t e = i + steps;  // my position in the end group of the run
+        if (deferred[e]) continue;
+        const uint32_t g = rank[i] - 1u, place = end_place[e];
+        sa[g + place] = (uint32_t)i;
+        if (place) lcp[g + place] = end_lcp[e] + steps;
+        rank[i] = g + place + 1u;
     }
 }
 
@@ -1434,17 +1522,22 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     static const long long pair_runs_min = getenv("NOLZSS_PAIR_RUNS_MIN") ? atoll(getenv("NOLZSS_PAIR_RUNS_MIN")) : -1;
     if (m > 0 && (pair_runs_min >= 0 ? (long long)m >= pair_runs_min : m >= n / 16)) {
         ProfScope ps(ctx.profiler(), "sa_pair_runs", s);
-        int32_t *delta = reinterpret_cast<int32_t *>(tmp_a);
-        uint32_t *rev = tmp_b, *end_of = tmp_c, *end_lcp = scratch_idx, *end_first = scratch_val;
+        uint32_t *link = tmp_a, *gsz = rank_val, *rev = tmp_b, *end_of = tmp_c, *togo = scratch_idx;
+        uint32_t *end_place = scratch_val, *end_lcp = reinterpret_cast<uint32_t *>(keys[0]);
+        uint32_t *deferred = reinterpret_cast<uint32_t *>(keys[0]) + n;
         const unsigned g = grid_for(n, kThreads, 256u * 64u);
-        pair_delta_kernel<<<g, kThreads, 0, s>>>(rank, sa, lcp, n, delta);
+        group_link_kernel<<<g, kThreads, 0, s>>>(rank, sa, lcp, n, link, gsz);
         KERNEL_CHECK();
-        run_breaks_kernel<<<g, kThreads, 0, s>>>(delta, n, rev);
+        run_breaks_kernel<<<g, kThreads, 0, s>>>(link, gsz, n, rev);
         KERNEL_CHECK();
         scan_inclusive_max_u32(rev, end_of, n, arena, s);
-        run_ends_kernel<<<g, kThreads, 0, s>>>(delta, rank, n, Plcp, end_lcp, end_first);
+        group_run_kernel<<<g, kThreads, 0, s>>>(gsz, rank, sa, end_of, n, togo);
         KERNEL_CHECK();
-        run_members_kernel<<<g, kThreads, 0, s>>>(delta, end_of, n, end_lcp, end_first, rank, sa, lcp);
+        group_end_kernel<<<g, kThreads, 0, s>>>(gsz, togo, end_of, rank, sa, n, Plcp, end_place, end_lcp, deferred);
+        KERNEL_CHECK();
+        group_verdict_kernel<<<g, kThreads, 0, s>>>(gsz, togo, rank, sa, n, end_place, deferred);
+        KERNEL_CHECK();
+        group_members_kernel<<<g, kThreads, 0, s>>>(gsz, togo, end_of, n, end_place, end_lcp, deferred, rank, sa, lcp);
         KERNEL_CHECK();
         // the active list without the pairs that are done, and the pyramid over the new LCP values
         uint32_t *keep = tmp_a, *pos = tmp_b;

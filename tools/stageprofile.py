@@ -16,6 +16,12 @@ elif kind == "mutated":   # second copy with 0.1 % substitutions
     rng = np.random.default_rng(1); idx = rng.integers(0, n // 2, size=n // 2000)
     c[idx] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=len(idx))]
     t = np.concatenate([half, c])
+elif kind == "copies3":   # three genomes, the second and third 0.1 % away from the first
+    third = gen.random_dna(n // 3, 3); rng = np.random.default_rng(1); parts = [third]
+    for _ in range(2):
+        c = third.copy(); idx = rng.integers(0, len(c), size=len(c) // 1000)
+        c[idx] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=len(idx))]; parts.append(c)
+    t = np.concatenate(parts)
 elif kind == "run":
     t = np.full(n, ord("A"), dtype=np.uint8)
 else:
