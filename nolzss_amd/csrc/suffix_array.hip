@@ -642,77 +642,55 @@ __device__ __forceinline__ uint32_t run_steps(uint32_t k, size_t i, uint32_t n, 
 
 constexpr uint32_t kRunDeferred = 0xffffffffu;
 
-// members of a group at the end of its run: place inside the group and LCP to the predecessor there,
-// from the rank codes of the suffixes one symbol further on
+// Members of a group at the end of its run.  One symbol further on the members carry rank codes; equal
+// codes mean "still tied".  The group splits into classes of equal code, in code order: my slot inside
+// the group, the first slot of my class (my new group head), and -- if I am the first of a class that is
+// not the first -- the LCP to the class in front (decided now).  A class of one is a finished suffix.
 __global__ __launch_bounds__(kThreads) void group_end_kernel(const uint32_t *__restrict__ gsz,
                                                              const uint32_t *__restrict__ togo,
                                                              const uint32_t *__restrict__ end_of,
                                                              const uint32_t *__restrict__ rank,
                                                              const uint32_t *__restrict__ sa, uint32_t n, Pyramid Plcp,
                                                              uint32_t *__restrict__ end_place,
-                                                             uint32_t *__restrict__ end_lcp,
-                                                             uint32_t *__restrict__ deferred) {
+                                                             uint32_t *__restrict__ end_head,
+                                                             uint32_t *__restrict__ end_lcp) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
         const uint32_t k = gsz[t];
         if (!k || run_steps(k, t, n, end_of, togo) != 0) continue;
         const uint32_t g = rank[t] - 1u;
-        uint32_t place = 0, l = 0;
-        if (t + 1 >= n) {
-            place = kRunDeferred;
-        } else {
-            const uint32_t mine = rank[t + 1];  // rank code (head slot + 1) of my suffix one symbol further on
-            uint32_t pred = 0;                  // largest code below mine
-            for (uint32_t x = 0; x < k && place != kRunDeferred; ++x) {
-                const uint32_t m = sa[g + x];
-                if (m == (uint32_t)t) continue;
-                if ((size_t)m + 1 >= n) {
-                    place = kRunDeferred;
-                    break;
-                }
-                const uint32_t c = rank[m + 1];
-                if (c == mine) {  // not separated from that member: the doubling rounds take the group
-                    place = kRunDeferred;
-                } else if (c < mine) {
-                    ++place;
-                    pred = c > pred ? c : pred;
-                }
+        uint32_t below = 0, same_before = 0, pred = 0, l = kRunDeferred;
+        bool off_end = t + 1 >= n;
+        const uint32_t mine = off_end ? 0u : rank[t + 1];  // rank code (head slot + 1) one symbol further on
+        for (uint32_t x = 0; x < k; ++x) {
+            const uint32_t m = sa[g + x];
+            if (m == (uint32_t)t) continue;
+            if ((size_t)m + 1 >= n) {  // (every member sees this: the group is left alone as a whole)
+                off_end = true;
+                continue;
             }
-            if (place != kRunDeferred && place > 0) l = 1u + pyr_range<false>(Plcp, pred, mine - 1u);
+            const uint32_t c = rank[m + 1];
+            if (c < mine) {
+                ++below;
+                pred = c > pred ? c : pred;
+            } else if (c == mine && m < (uint32_t)t) {
+                ++same_before;
+            }
         }
-        end_place[t] = place;
+        if (!off_end && same_before == 0 && below > 0) l = 1u + pyr_range<false>(Plcp, pred, mine - 1u);
+        end_place[t] = off_end ? kRunDeferred : below + same_before;
+        end_head[t] = below;
         end_lcp[t] = l;
-        if (k == 2) deferred[t] = place == kRunDeferred ? 1u : 0u;  // (the two members of a pair see each other)
     }
 }
 
-// every member of every group of a run whose end group is separated: final slot, LCP and rank.
-// (A group is deferred as a whole: two members that tie at the end see each other.  A member that is
-// separated from all others while two OTHERS tie must not be placed either, hence the second pass over the
-// end group's verdicts through `deferred`.)
-__global__ __launch_bounds__(kThreads) void group_verdict_kernel(const uint32_t *__restrict__ gsz,
-                                                                 const uint32_t *__restrict__ togo,
-                                                                 const uint32_t *__restrict__ rank,
-                                                                 const uint32_t *__restrict__ sa, uint32_t n,
-                                                                 const uint32_t *__restrict__ end_place,
-                                                                 uint32_t *__restrict__ deferred) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
-        const uint32_t k = gsz[t];
-        if (k <= 2 || togo[t] != 0) continue;
-        const uint32_t g = rank[t] - 1u;
-        uint32_t bad = 0;
-        for (uint32_t x = 0; x < k; ++x) bad |= end_place[sa[g + x]] == kRunDeferred ? 1u : 0u;
-        deferred[t] = bad;
-    }
-}
-
+// every member of every group of a run does what its counterpart in the end group does
 __global__ __launch_bounds__(kThreads) void group_members_kernel(const uint32_t *__restrict__ gsz,
                                                                  const uint32_t *__restrict__ togo,
                                                                  const uint32_t *__restrict__ end_of, uint32_t n,
                                                                  const uint32_t *__restrict__ end_place,
+                                                                 const uint32_t *__restrict__ end_head,
                                                                  const uint32_t *__restrict__ end_lcp,
-                                                                 const uint32_t *__restrict__ deferred,
                                                                  uint32_t *__restrict__ rank, uint32_t *__restrict__ sa,
                                                                  uint32_t *__restrict__ lcp) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -721,25 +699,32 @@ __global__ __launch_bounds__(kThreads) void group_members_kernel(const uint32_t 
         if (!k) continue;
         const uint32_t steps = run_steps(k, i, n, end_of, togo);
         const size_t e = i + steps;  // my position in the end group of the run
-        if (deferred[e]) continue;
-        const uint32_t g = rank[i] - 1u, place = end_place[e];
+        const uint32_t place = end_place[e];
+        if (place == kRunDeferred) continue;
+        const uint32_t g = rank[i] - 1u;
         sa[g + place] = (uint32_t)i;
-        if (place) lcp[g + place] = end_lcp[e] + steps;
-        rank[i] = g + place + 1u;
+        const uint32_t le = end_lcp[e];
+        if (le != kRunDeferred) lcp[g + place] = le + steps;
+        rank[i] = g + end_head[e] + 1u;
     }
 }
 
-// 1 for the active elements whose group is still undecided
-__global__ __launch_bounds__(kThreads) void still_tied_kernel(const uint32_t *__restrict__ act_grp, uint32_t m,
-                                                              const uint32_t *__restrict__ lcp,
-                                                              uint32_t *__restrict__ keep) {
+// the active list after a pass: head slot of every element's (new) group, 1 if that group is still undecided
+__global__ __launch_bounds__(kThreads) void still_tied_kernel(const uint32_t *__restrict__ act_slot, uint32_t m,
+                                                              const uint32_t *__restrict__ sa,
+                                                              const uint32_t *__restrict__ rank,
+                                                              const uint32_t *__restrict__ lcp, uint32_t n,
+                                                              uint32_t *__restrict__ head, uint32_t *__restrict__ keep) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x; a < m; a += stride)
-        keep[a] = lcp[act_grp[a] + 1] >= kLcpPendingMin ? 1u : 0u;
+    for (size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x; a < m; a += stride) {
+        const uint32_t h = rank[sa[act_slot[a]]] - 1u;
+        head[a] = h;
+        keep[a] = (h + 1u < n && lcp[h + 1] >= kLcpPendingMin) ? 1u : 0u;
+    }
 }
 
 __global__ __launch_bounds__(kThreads) void compact_active_kernel(const uint32_t *__restrict__ act_slot,
-                                                                  const uint32_t *__restrict__ act_grp,
+                                                                  const uint32_t *__restrict__ head,
                                                                   const uint32_t *__restrict__ keep,
                                                                   const uint32_t *__restrict__ pos, uint32_t m,
                                                                   uint32_t *__restrict__ new_slot,
@@ -748,7 +733,7 @@ __global__ __launch_bounds__(kThreads) void compact_active_kernel(const uint32_t
     for (size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x; a < m; a += stride)
         if (keep[a]) {
             new_slot[pos[a]] = act_slot[a];
-            new_grp[pos[a]] = act_grp[a];
+            new_grp[pos[a]] = head[a];
         }
 }
 
@@ -1516,15 +1501,17 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         Plcp = build_pyramid(lcp, n + 1, false, arena, s);
     }
 
-    // ---- long exact repeats: pairs along runs of text positions are finished arithmetically -------
-    // (worth its five passes over the text only when a large part of it is still tied;
-    // NOLZSS_PAIR_RUNS_MIN: smallest number of tied suffixes for which it runs, the tests set 1)
+    // ---- long exact repeats: small groups along runs of text positions are finished arithmetically ---
+    // (worth its passes over the text only when a large part of it is still tied; a pass that splits
+    // groups without finishing them -- three copies, one of which differs behind the run -- is followed by
+    // another one over the smaller groups.  NOLZSS_PAIR_RUNS_MIN: smallest number of tied suffixes for
+    // which it runs, the tests set 1)
     static const long long pair_runs_min = getenv("NOLZSS_PAIR_RUNS_MIN") ? atoll(getenv("NOLZSS_PAIR_RUNS_MIN")) : -1;
-    if (m > 0 && (pair_runs_min >= 0 ? (long long)m >= pair_runs_min : m >= n / 16)) {
+    for (int pass = 0; pass < 6 && m > 0 && (pair_runs_min >= 0 ? (long long)m >= pair_runs_min : m >= n / 16); ++pass) {
         ProfScope ps(ctx.profiler(), "sa_pair_runs", s);
         uint32_t *link = tmp_a, *gsz = rank_val, *rev = tmp_b, *end_of = tmp_c, *togo = scratch_idx;
         uint32_t *end_place = scratch_val, *end_lcp = reinterpret_cast<uint32_t *>(keys[0]);
-        uint32_t *deferred = reinterpret_cast<uint32_t *>(keys[0]) + n;
+        uint32_t *end_head = reinterpret_cast<uint32_t *>(keys[0]) + n;
         const unsigned g = grid_for(n, kThreads, 256u * 64u);
         group_link_kernel<<<g, kThreads, 0, s>>>(rank, sa, lcp, n, link, gsz);
         KERNEL_CHECK();
@@ -1533,29 +1520,29 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         scan_inclusive_max_u32(rev, end_of, n, arena, s);
         group_run_kernel<<<g, kThreads, 0, s>>>(gsz, rank, sa, end_of, n, togo);
         KERNEL_CHECK();
-        group_end_kernel<<<g, kThreads, 0, s>>>(gsz, togo, end_of, rank, sa, n, Plcp, end_place, end_lcp, deferred);
+        group_end_kernel<<<g, kThreads, 0, s>>>(gsz, togo, end_of, rank, sa, n, Plcp, end_place, end_head, end_lcp);
         KERNEL_CHECK();
-        group_verdict_kernel<<<g, kThreads, 0, s>>>(gsz, togo, rank, sa, n, end_place, deferred);
+        group_members_kernel<<<g, kThreads, 0, s>>>(gsz, togo, end_of, n, end_place, end_head, end_lcp, rank, sa, lcp);
         KERNEL_CHECK();
-        group_members_kernel<<<g, kThreads, 0, s>>>(gsz, togo, end_of, n, end_place, end_lcp, deferred, rank, sa, lcp);
-        KERNEL_CHECK();
-        // the active list without the pairs that are done, and the pyramid over the new LCP values
-        uint32_t *keep = tmp_a, *pos = tmp_b;
-        still_tied_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(act_grp[a_cur], m, lcp, keep);
+        // the active list without the suffixes that are done, with the new group heads of the others
+        uint32_t *keep = tmp_a, *pos = tmp_b, *head = tmp_c;
+        still_tied_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(act_slot[a_cur], m, sa, rank, lcp, n, head, keep);
         KERNEL_CHECK();
         scan_exclusive_add_u32(keep, pos, m, d_total, arena, s);
-        compact_active_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(act_slot[a_cur], act_grp[a_cur], keep, pos, m,
+        compact_active_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(act_slot[a_cur], head, keep, pos, m,
                                                                        act_slot[a_cur ^ 1], act_grp[a_cur ^ 1]);
         KERNEL_CHECK();
         uint32_t left = 0;
         ctx.read_back(d_total, &left, 1);
         if (trace) fprintf(stderr, "[nolzss]   pair runs: %u of %u tied suffixes finished\n", m - left, m);
+        const bool progress = left < m - m / 8;
         m = left;
         a_cur ^= 1;
         if (m > 0) {
             arena.rewind(pyr_mark);
             Plcp = build_pyramid(lcp, n + 1, false, arena, s);
         }
+        if (!progress) break;
     }
 
     while (m > 0) {
