@@ -18,12 +18,26 @@ def fib(n):
 
 
 half = gen.random_dna(n // 2, 3)
+
+
+def mutated(x, seed, rate=1000):
+    y = x.copy(); r = np.random.default_rng(seed)
+    idx = r.integers(0, len(y), size=len(y) // rate)
+    y[idx] = np.frombuffer(b"ACGT", dtype=np.uint8)[r.integers(0, 4, size=len(idx))]
+    return y
+
+
+third = gen.random_dna(n // 3, 4)
+fifth = gen.random_dna(n // 5, 5)
 cases = {
     "one run A^n": np.full(n, ord("A"), dtype=np.uint8),
     "(AC)^(n/2)": np.tile(np.frombuffer(b"AC", dtype=np.uint8), n // 2),
     "period 1000": np.tile(gen.random_dna(1000, 1), n // 1000 + 1)[:n],
     "Fibonacci word": fib(n),
     "two copies of a random text": np.concatenate([half, half]),
+    "two genomes 0.1 % apart": np.concatenate([half, mutated(half, 1)]),
+    "three genomes 0.1 % apart": np.concatenate([third, mutated(third, 2), mutated(third, 3)]),
+    "five genomes 0.1 % apart": np.concatenate([fifth] + [mutated(fifth, 10 + k) for k in range(4)]),
     "random": gen.random_dna(n, 2),
 }
 native.count_factors(cases["random"][:1 << 16])
