@@ -560,7 +560,7 @@ __global__ __launch_bounds__(kFuseThreads) void regroup_kernel(RegroupArgs A) {
 // not pointer jumping.  Groups of up to kRunGroupMax members are handled; runs whose end group is only
 // partly separated are left to the doubling rounds.
 // ---------------------------------------------------------------------------------------
-constexpr uint32_t kRunGroupMax = 8;
+constexpr uint32_t kRunGroupMax = 16;
 
 // members of the undecided group with head slot g: k = its size (0: decided or too large)
 __device__ __forceinline__ uint32_t run_group_size(const uint32_t *__restrict__ lcp, uint32_t n, uint32_t g) {
@@ -1507,7 +1507,7 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     // another one over the smaller groups.  NOLZSS_PAIR_RUNS_MIN: smallest number of tied suffixes for
     // which it runs, the tests set 1)
     static const long long pair_runs_min = getenv("NOLZSS_PAIR_RUNS_MIN") ? atoll(getenv("NOLZSS_PAIR_RUNS_MIN")) : -1;
-    for (int pass = 0; pass < 6 && m > 0 && (pair_runs_min >= 0 ? (long long)m >= pair_runs_min : m >= n / 16); ++pass) {
+    for (int pass = 0; pass < 10 && m > 0 && (pair_runs_min >= 0 ? (long long)m >= pair_runs_min : m >= n / 16); ++pass) {
         ProfScope ps(ctx.profiler(), "sa_pair_runs", s);
         uint32_t *link = tmp_a, *gsz = rank_val, *rev = tmp_b, *end_of = tmp_c, *togo = scratch_idx;
         uint32_t *end_place = scratch_val, *end_lcp = reinterpret_cast<uint32_t *>(keys[0]);

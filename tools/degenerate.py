@@ -38,6 +38,7 @@ cases = {
     "two genomes 0.1 % apart": np.concatenate([half, mutated(half, 1)]),
     "three genomes 0.1 % apart": np.concatenate([third, mutated(third, 2), mutated(third, 3)]),
     "five genomes 0.1 % apart": np.concatenate([fifth] + [mutated(fifth, 10 + k) for k in range(4)]),
+    "twelve genomes 0.1 % apart": np.concatenate([gen.random_dna(n // 12, 6)] + [mutated(gen.random_dna(n // 12, 6), 30 + k) for k in range(11)]),
     "random": gen.random_dna(n, 2),
 }
 native.count_factors(cases["random"][:1 << 16])
