@@ -1513,17 +1513,30 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         uint32_t *end_place = scratch_val, *end_lcp = reinterpret_cast<uint32_t *>(keys[0]);
         uint32_t *end_head = reinterpret_cast<uint32_t *>(keys[0]) + n;
         const unsigned g = grid_for(n, kThreads, 256u * 64u);
-        group_link_kernel<<<g, kThreads, 0, s>>>(rank, sa, lcp, n, link, gsz);
-        KERNEL_CHECK();
-        run_breaks_kernel<<<g, kThreads, 0, s>>>(link, gsz, n, rev);
-        KERNEL_CHECK();
-        scan_inclusive_max_u32(rev, end_of, n, arena, s);
-        group_run_kernel<<<g, kThreads, 0, s>>>(gsz, rank, sa, end_of, n, togo);
-        KERNEL_CHECK();
-        group_end_kernel<<<g, kThreads, 0, s>>>(gsz, togo, end_of, rank, sa, n, Plcp, end_place, end_head, end_lcp);
-        KERNEL_CHECK();
-        group_members_kernel<<<g, kThreads, 0, s>>>(gsz, togo, end_of, n, end_place, end_head, end_lcp, rank, sa, lcp);
-        KERNEL_CHECK();
+        {
+            ProfScope p1(ctx.profiler(), "runs_link", s);
+            group_link_kernel<<<g, kThreads, 0, s>>>(rank, sa, lcp, n, link, gsz);
+            KERNEL_CHECK();
+        }
+        {
+            ProfScope p2(ctx.profiler(), "runs_scan", s);
+            run_breaks_kernel<<<g, kThreads, 0, s>>>(link, gsz, n, rev);
+            KERNEL_CHECK();
+            scan_inclusive_max_u32(rev, end_of, n, arena, s);
+            group_run_kernel<<<g, kThreads, 0, s>>>(gsz, rank, sa, end_of, n, togo);
+            KERNEL_CHECK();
+        }
+        {
+            ProfScope p3(ctx.profiler(), "runs_end", s);
+            group_end_kernel<<<g, kThreads, 0, s>>>(gsz, togo, end_of, rank, sa, n, Plcp, end_place, end_head, end_lcp);
+            KERNEL_CHECK();
+        }
+        {
+            ProfScope p4(ctx.profiler(), "runs_members", s);
+            group_members_kernel<<<g, kThreads, 0, s>>>(gsz, togo, end_of, n, end_place, end_head, end_lcp, rank, sa, lcp);
+            KERNEL_CHECK();
+        }
+        ProfScope p5(ctx.profiler(), "runs_compact", s);
         // the active list without the suffixes that are done, with the new group heads of the others
         uint32_t *keep = tmp_a, *pos = tmp_b, *head = tmp_c;
         still_tied_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(act_slot[a_cur], m, sa, rank, lcp, n, head, keep);

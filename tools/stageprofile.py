@@ -30,7 +30,10 @@ native.count_factors(t[:1 << 16])
 native.profile_enable(True); native.profile_reset()
 t0 = time.time(); z = native.count_factors(t); dt = time.time() - t0
 st = native.profile_report()
-nested = ("rs_", "bucket_scatter", "window_scatter")
+nested = ("rs_", "bucket_scatter", "window_scatter", "runs_")
+for k, v in sorted(st.items()):
+    if k.startswith("runs_"):
+        print(f"      {k:20s} {v[0]:4d} x {v[1]:8.1f} ms")
 print(f"{kind} 2^{lg}: {dt*1e3:.1f} ms, z={z}")
 for k, v in sorted(st.items(), key=lambda kv: -kv[1][1]):
     if not k.startswith(nested) and v[1] > 0.5:
