@@ -710,14 +710,21 @@ __global__ __launch_bounds__(kThreads) void group_members_kernel(const uint32_t 
 }
 
 // the active list after a pass: head slot of every element's (new) group, 1 if that group is still undecided
-__global__ __launch_bounds__(kThreads) void still_tied_kernel(const uint32_t *__restrict__ act_slot, uint32_t m,
-                                                              const uint32_t *__restrict__ sa,
-                                                              const uint32_t *__restrict__ rank,
+// (the head is the nearest slot at or in front of mine whose boundary is decided; only groups of up to
+// kRunGroupMax members were touched, so the walk back is that short -- the list is in slot order, the
+// LCP entries it reads are neighbours in memory)
+__global__ __launch_bounds__(kThreads) void still_tied_kernel(const uint32_t *__restrict__ act_slot,
+                                                              const uint32_t *__restrict__ act_grp, uint32_t m,
                                                               const uint32_t *__restrict__ lcp, uint32_t n,
                                                               uint32_t *__restrict__ head, uint32_t *__restrict__ keep) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x; a < m; a += stride) {
-        const uint32_t h = rank[sa[act_slot[a]]] - 1u;
+        const uint32_t s = act_slot[a], g0 = act_grp[a];
+        uint32_t h = g0;
+        if (s - g0 < kRunGroupMax) {
+            h = s;
+            while (h > g0 && lcp[h] >= kLcpPendingMin) --h;
+        }
         head[a] = h;
         keep[a] = (h + 1u < n && lcp[h + 1] >= kLcpPendingMin) ? 1u : 0u;
     }
@@ -1539,7 +1546,7 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         ProfScope p5(ctx.profiler(), "runs_compact", s);
         // the active list without the suffixes that are done, with the new group heads of the others
         uint32_t *keep = tmp_a, *pos = tmp_b, *head = tmp_c;
-        still_tied_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(act_slot[a_cur], m, sa, rank, lcp, n, head, keep);
+        still_tied_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(act_slot[a_cur], act_grp[a_cur], m, lcp, n, head, keep);
         KERNEL_CHECK();
         scan_exclusive_add_u32(keep, pos, m, d_total, arena, s);
         compact_active_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(act_slot[a_cur], head, keep, pos, m,
