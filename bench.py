@@ -4,21 +4,31 @@
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json config 3, the configuration the metric is quoted on): one 2^30-base
+Headline workload (BASELINE.json config 3, the configuration the metric is quoted on): one 2^30-base
 synthetic DNA string (sigma = 4, 40 % copied blocks with 1 % substitutions, generator and seed in
-tests/gen.py) PER GPU -- the multi-sequence shard of north_star with one sequence per rank, so
-per-GPU work is fixed as N grows (weak scaling).  Rank r factorizes its own sequence (seed + r);
-the only collective is the all-gather of the per-sequence factor counts (RCCL over xGMI).
+tests/gen.py) PER GPU -- the multi-sequence shard of north_star with one sequence per rank, so per-GPU
+work is fixed as N grows (weak scaling).  Rank r factorizes its own sequence (seed + r); the only
+collective is the all-gather of the per-sequence factor counts (RCCL over xGMI).
 
 A step = one complete factorization of the rank's sequence with the text already resident in HBM:
-pack -> suffix array -> LCP -> L* -> chain -> all z factor records (start, length, ref) built in
-HBM.  The PCIe download of the records is outside `value` (reported as pcie_inclusive_*).
+pack -> suffix array -> LCP -> L* -> chain -> all z factor records (start, length, ref) built in HBM.
+
+Beside `value` the same JSON line carries
+  * "stopwatches" (N = 1): the three clocks of SURVEY.md 8d -- C ABI host buffer -> host factor array,
+    count_factors from a host buffer, and the Python-visible noLZSS.factorize() (tuple list) on a prefix;
+  * "fasta512": BASELINE config 4, the multi-sequence FASTA shard (512 records x 4 Mi bases, generator of
+    config 2 with seeds 0x4000 + k) dealt over the N ranks by the longest-processing-time-first plan, one
+    all-gather of the 512 factor counts -- STRONG scaling (total work fixed), records resident in HBM when
+    its clock starts.  `--workload fasta512` makes this the headline instead and also times the
+    file -> reader -> batch -> counts path through genomics.shard_nucleotide_fasta.
 """
 import argparse
 import json
 import os
 import sys
+import tempfile
 import time
+from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 
 import numpy as np
@@ -33,22 +43,26 @@ import gen  # noqa: E402
 from nolzss_amd import _noLZSS as native  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured copy
+ALG_BYTES_PER_BASE = 50.0  # SURVEY.md 8d, plain mode: compulsory traffic of the whole pipeline
 # rs_scatter_kernel: 2 * (sizeof(key) + 4) algorithmic bytes per (key, value) pair per launch
 # (24 B for the u64-key sorts, 16 B for the u32-key partition passes); the library sums them.
 DOMINANT = "rs_scatter"
+PMC_FILES = ["r02_pmc_radix_traffic.json", "r01_pmc_radix_traffic.json"]
 
 
 def measured_traffic_ratio():
     """HBM bytes / algorithmic bytes of rs_scatter_kernel from the committed rocprofv3 PMC passes
     (FETCH_SIZE and WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 correction);
-    None if the profile summary is not there."""
-    try:
-        with open(ROOT / "profiles" / "r01_pmc_radix_traffic.json") as f:
-            d = json.load(f)
+    (ratio, file) or (None, None) if no profile summary is there."""
+    for name in PMC_FILES:
+        try:
+            with open(ROOT / "profiles" / name) as f:
+                d = json.load(f)
             cur = d.get("rs_scatter_kernel<u32,u32> at 2^30 pairs (current pipeline)")  # the dominant instantiation
-            return float((cur or d["rs_scatter_kernel<u64>"])["traffic_over_algorithmic"])
-    except Exception:
-        return None
+            return float((cur or d["rs_scatter_kernel<u64>"])["traffic_over_algorithmic"]), name
+        except Exception:
+            continue
+    return None, None
 
 
 def make_text(workload: str, n: int, rank: int) -> np.ndarray:
@@ -71,50 +85,49 @@ def cpu_baseline(text: np.ndarray, sample: int):
             "sample": f"first {sample} bases of the rank-0 sequence, count_factors, {dt:.1f} s, z={z}"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="dna1g", choices=["dna1g", "random"])
-    ap.add_argument("--log2n", type=int, default=30, help="bases per GPU = 2^log2n (default 2^30)")
-    ap.add_argument("--cpu-sample-log2", type=int, default=26)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="collective backend for N > 1 (nccl = RCCL over xGMI; gloo only for rehearsals)")
-    ap.add_argument("--same-device", action="store_true",
-                    help="rehearsal on a one-GPU box: every rank uses cuda:0 (needs --backend gloo)")
-    a = ap.parse_args()
+class Job:
+    """rank / world / collectives of this process"""
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = 0 if a.same_device else int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("gloo")
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
-    dev = torch.device("cuda", local_rank)
-    native.set_device(local_rank)
+    def __init__(self, a):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = 0 if a.same_device else int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(self.local_rank)
+        self.backend = a.backend
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if a.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+            else:
+                dist.init_process_group("gloo")
+        assert self.world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={self.world}"
+        self.dev = torch.device("cuda", self.local_rank)
+        self.cdev = self.dev if a.backend == "nccl" else torch.device("cpu")
+        native.set_device(self.local_rank)
 
-    n = 1 << a.log2n
-    text = make_text(a.workload, n, rank)
-    d_text = torch.from_numpy(text).to(dev)
-    cdev = dev if a.backend == "nccl" else torch.device("cpu")
-    counts = torch.zeros(world, dtype=torch.int64, device=cdev)
-    mine = torch.zeros(1, dtype=torch.int64, device=cdev)
-
-    def barrier():
-        if world > 1:
+    def barrier(self):
+        if self.world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(self, seconds: float) -> float:
+        t = torch.tensor([seconds], dtype=torch.float64, device=self.cdev)
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+
+def run_single_sequence(job: Job, a):
+    """headline: one sequence per GPU, text resident in HBM, records built in HBM"""
+    n = 1 << a.log2n
+    text = make_text(a.workload, n, job.rank)
+    d_text = torch.from_numpy(text).to(job.dev)
+    counts = torch.zeros(job.world, dtype=torch.int64, device=job.cdev)
+    mine = torch.zeros(1, dtype=torch.int64, device=job.cdev)
+
     def step():
         z, _ = native.factorize_device(d_text.data_ptr(), n, emit=1)
-        if world > 1:  # the only collective: per-sequence factor counts
+        if job.world > 1:  # the only collective: per-sequence factor counts
             mine[0] = z
             dist.all_gather_into_tensor(counts, mine)
         return z
@@ -123,19 +136,15 @@ def main():
         step()
     native.profile_enable(True)
     native.profile_reset()
-    barrier()
+    job.barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         z = step()
-    barrier()
+    job.barrier()
     elapsed = time.perf_counter() - t0
     stats = native.profile_report()
     native.profile_enable(False)
-
-    t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed = job.max_over_ranks(elapsed)
 
     # PCIe-inclusive variant (records downloaded into host memory), rank-local, one run
     t1 = time.perf_counter()
@@ -143,57 +152,224 @@ def main():
     pcie_dt = time.perf_counter() - t1
     assert z2 == z
     del f
+    del d_text
+    torch.cuda.empty_cache()
+    if job.rank != 0:
+        return None, text, z
 
-    if rank == 0:
-        total_bases = float(n) * world * a.steps
-        # every launch of the kernel, whatever the instantiation (the library reports them by class:
-        # rs_scatter.text = first pass computing the keys, .u32 / .u64 = key width, .small = < 2^24 pairs)
-        family = {k: v for k, v in stats.items() if k.startswith(DOMINANT)}
-        cnt = sum(v[0] for v in family.values())
-        ms = sum(v[1] for v in family.values())
-        nbytes = sum(v[2] for v in family.values())
-        achieved = (nbytes / (ms * 1e-3)) / 1e9 if ms > 0 else 0.0
-        by_class = {k: {"launches": v[0], "ms_per_step": v[1] / a.steps,
-                        "achieved_GBps": (v[2] / (v[1] * 1e-3)) / 1e9 if v[1] > 0 else 0.0}
-                    for k, v in sorted(family.items())}
-        nested = {"rs_hist", "rs_scan", "bucket_scatter", "window_scatter"} | set(family)
-        ratio = measured_traffic_ratio()
-        out = {
-            "metric": "bases/sec factorized (1 GB sigma=4 DNA) + HBM GB/s fraction",
-            "value": total_bases / elapsed,
-            "unit": "bases/s",
-            "n_gpus": world,
-            "steps": a.steps,
-            "warmup": a.warmup,
-            "ms_per_step": elapsed / a.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u32",
-            "data": "synthetic",
-            "config": {"workload": f"{a.workload}: one 2^{a.log2n}-base synthetic DNA sequence per GPU "
-                                   "(sigma=4, 40% copied blocks, 1% substitutions), full factorization "
-                                   "to (start,length,ref) records in HBM",
-                       "bases_per_gpu": n, "factors_per_sequence": int(z),
-                       "parallelism": f"{world} independent sequence shard(s), all-gather of counts"},
-            "roofline": {"bound": "hbm", "kernel": "rs_scatter_kernel", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": (ratio * nbytes / cnt) if (ratio and cnt) else None,
-                         "traffic_source": "profiles/r01_pmc_radix_traffic.json (rocprofv3 --pmc FETCH_SIZE / "
-                                           "WRITE_SIZE, separate passes): HBM bytes = 1.02 x algorithmic bytes, u32 passes at 2^30 pairs",
-                         "launches": cnt,
-                         "avg_launch_ms": (ms / cnt) if cnt else None,
-                         "algorithmic_bytes_per_launch": (nbytes / cnt) if cnt else None,
-                         "by_class": by_class},
-            "pcie_inclusive_bases_per_s": n / pcie_dt,
-            "stages_ms_per_step": {k: v[1] / a.steps for k, v in sorted(stats.items(), key=lambda kv: -kv[1][1])
-                                   if k not in nested},
-            "kernels_ms_per_step": {k: stats[k][1] / a.steps for k in sorted(nested) if k in stats},
-        }
-        if not a.no_cpu_baseline and world == 1:  # the CPU leg runs on rank 0 of the one-GPU run only
-            out["cpu_baseline"] = cpu_baseline(text, 1 << a.cpu_sample_log2)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+    total_bases = float(n) * job.world * a.steps
+    # every launch of the kernel, whatever the instantiation (the library reports them by class:
+    # rs_scatter.text = first pass computing the keys, .u32 / .u64 = key width, .small = < 2^24 pairs)
+    family = {k: v for k, v in stats.items() if k.startswith(DOMINANT)}
+    cnt = sum(v[0] for v in family.values())
+    ms = sum(v[1] for v in family.values())
+    nbytes = sum(v[2] for v in family.values())
+    achieved = (nbytes / (ms * 1e-3)) / 1e9 if ms > 0 else 0.0
+    by_class = {k: {"launches": v[0], "ms_per_step": v[1] / a.steps,
+                    "achieved_GBps": (v[2] / (v[1] * 1e-3)) / 1e9 if v[1] > 0 else 0.0}
+                for k, v in sorted(family.items())}
+    nested = {"rs_hist", "rs_scan", "bucket_scatter", "window_scatter"} | set(family)
+    ratio, ratio_file = measured_traffic_ratio()
+    step_s = elapsed / a.steps
+    out = {
+        "metric": "bases/sec factorized (1 GB sigma=4 DNA) + HBM GB/s fraction",
+        "value": total_bases / elapsed,
+        "unit": "bases/s",
+        "n_gpus": job.world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": step_s * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u32",
+        "data": "synthetic",
+        "config": {"workload": f"{a.workload}: one 2^{a.log2n}-base synthetic DNA sequence per GPU "
+                               "(sigma=4, 40% copied blocks, 1% substitutions), full factorization "
+                               "to (start,length,ref) records in HBM",
+                   "bases_per_gpu": n, "factors_per_sequence": int(z),
+                   "parallelism": f"{job.world} independent sequence shard(s), all-gather of counts"},
+        "roofline": {"bound": "hbm", "kernel": "rs_scatter_kernel", "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": (ratio * nbytes / cnt) if (ratio and cnt) else None,
+                     "traffic_source": (f"profiles/{ratio_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
+                                        "passes): HBM bytes over algorithmic bytes of the u32 passes at 2^30 pairs")
+                     if ratio_file else None,
+                     "launches": cnt,
+                     "avg_launch_ms": (ms / cnt) if cnt else None,
+                     "algorithmic_bytes_per_launch": (nbytes / cnt) if cnt else None,
+                     "by_class": by_class},
+        # SURVEY.md 8d end-to-end figure: 50 B per base of compulsory traffic over the whole pipeline
+        "pipeline_hbm": {"algorithmic_bytes_per_base": ALG_BYTES_PER_BASE,
+                         "achieved_GBps_per_gpu": ALG_BYTES_PER_BASE * n / step_s / 1e9,
+                         "frac_of_peak_per_gpu": ALG_BYTES_PER_BASE * n / step_s / 1e9 / HBM_PEAK_GBS},
+        "pcie_inclusive_bases_per_s": n / pcie_dt,
+        "stages_ms_per_step": {k: v[1] / a.steps for k, v in sorted(stats.items(), key=lambda kv: -kv[1][1])
+                               if k not in nested},
+        "kernels_ms_per_step": {k: stats[k][1] / a.steps for k in sorted(nested) if k in stats},
+    }
+    return out, text, z
+
+
+def stopwatches(text: np.ndarray, z: int, py_log2: int):
+    """SURVEY.md 8d: (i) C ABI host-in / host-out, (i') count_factors, (iii) Python-visible tuples;
+    (ii) kernel-only is `value`.  One warm call each (the arena is already reserved)."""
+    import noLZSS  # the reference's import path: pybind11 module -> C ABI
+    n = len(text)
+    buf = text.tobytes()
+    t0 = time.perf_counter()
+    zc = native.count_factors(buf)
+    t_count = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    f = native.factorize_array(buf)
+    t_fact = time.perf_counter() - t0
+    assert zc == z == len(f)
+    del f
+    m = min(n, 1 << py_log2)
+    prefix = buf[:m]
+    t0 = time.perf_counter()
+    tuples = noLZSS.factorize(prefix)
+    t_py = time.perf_counter() - t0
+    zt = len(tuples)
+    del tuples
+    return {"c_abi_host_ms": t_fact * 1e3, "c_abi_host_bases_per_s": n / t_fact,
+            "count_factors_host_ms": t_count * 1e3, "count_factors_host_bases_per_s": n / t_count,
+            "python_visible_ms": t_py * 1e3, "python_visible_bases": m, "python_visible_factors": zt,
+            "python_visible_bases_per_s": m / t_py,
+            "note": "c_abi_host: nolzss_factorize, host bytes in -> nolzss_factor[] on the host (upload + kernels + "
+                    "download); count_factors_host: nolzss_count_factors from host bytes; python_visible: "
+                    f"noLZSS.factorize(bytes) -> list of int tuples on the first {m} bases (the full text would "
+                    "build 5*10^7 tuples)"}
+
+
+def run_fasta_shard(job: Job, a, with_file: bool):
+    """BASELINE config 4: `records` FASTA records of 2^rec_log2 bases, dealt over the ranks by the LPT
+    plan of the library; per step every rank factorizes its records (resident in HBM) to factor records
+    in HBM and the 512 counts are all-gathered.  Strong scaling."""
+    m, L = a.fasta_records, 1 << a.fasta_record_log2
+    owners = native.debug_lpt_plan([L] * m, job.world)
+    mine = [j for j, o in enumerate(owners) if o == job.rank]
+    with ThreadPoolExecutor(max_workers=min(8, max(1, (os.cpu_count() or 8) // max(1, job.world)))) as pool:
+        recs = list(pool.map(lambda j: gen.random_dna(L, 0x4000 + j), mine))
+    d_recs = [torch.from_numpy(r).to(job.dev) for r in recs]
+    ptrs = [t.data_ptr() for t in d_recs]
+    lens = [L] * len(mine)
+    vec = torch.zeros(m, dtype=torch.int64, device=job.cdev)
+    gathered = torch.zeros(job.world * m, dtype=torch.int64, device=job.cdev)
+    idx = torch.tensor(mine, dtype=torch.int64, device=job.cdev)
+
+    def step():
+        zs = native.factorize_batch_device(ptrs, lens, emit=1)
+        vec.zero_()
+        if mine:
+            vec[idx] = torch.tensor(zs, dtype=torch.int64, device=job.cdev)
+        if job.world > 1:
+            dist.all_gather_into_tensor(gathered, vec)
+            return gathered.view(job.world, m).sum(dim=0)
+        return vec.clone()
+
+    for _ in range(a.fasta_warmup):
+        step()
+    job.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.fasta_steps):
+        counts = step()
+    job.barrier()
+    elapsed = job.max_over_ranks(time.perf_counter() - t0)
+    counts = counts.cpu().tolist()
+    step_s = elapsed / a.fasta_steps
+    total = float(m) * L
+    out = {"workload": f"fasta512: {m} records x 2^{a.fasta_record_log2} random ACGT bases (seeds 0x4000+k), LPT shard "
+                       f"over {job.world} rank(s), records resident in HBM, factor records built in HBM, one all-gather "
+                       f"of {m} counts",
+           "scaling": "strong", "n_gpus": job.world, "steps": a.fasta_steps, "warmup": a.fasta_warmup,
+           "value": total / step_s, "unit": "bases/s", "ms_per_step": step_s * 1e3,
+           "records_per_rank": [owners.count(r) for r in range(job.world)],
+           "total_factors": int(sum(counts)),
+           "pipeline_hbm_frac_per_gpu": ALG_BYTES_PER_BASE * (total / job.world) / step_s / 1e9 / HBM_PEAK_GBS}
+    # PCIe-inclusive: the host-buffer batch entry point (nolzss_factorize_batch), counts only
+    job.barrier()
+    t0 = time.perf_counter()
+    zs_host, _ = native.factorize_batch(recs, want_factors=False)
+    job.barrier()
+    dt = job.max_over_ranks(time.perf_counter() - t0)
+    assert zs_host == [counts[j] for j in mine]
+    out["host_buffers_to_counts_bases_per_s"] = total / dt
+    del d_recs
+    torch.cuda.empty_cache()
+    if with_file:
+        # file -> native reader -> batch -> all-gather, through the reference's caller
+        from nolzss_amd.genomics.fasta import shard_nucleotide_fasta
+        tmp = Path("/dev/shm") if Path("/dev/shm").is_dir() else Path(tempfile.gettempdir())
+        path = tmp / f"nolzss_bench_fasta_{os.environ.get('MASTER_PORT', 'single')}.fa"
+        if job.rank == 0:
+            with ThreadPoolExecutor(max_workers=8) as pool:
+                allrecs = list(pool.map(lambda j: gen.random_dna(L, 0x4000 + j), range(m)))
+            gen.write_fasta_fast(path, [(f"seq{j}", r) for j, r in enumerate(allrecs)])
+            del allrecs
+        job.barrier()
+        try:
+            t0 = time.perf_counter()
+            ids, fcounts, local = shard_nucleotide_fasta(path, want_factors=False)
+            job.barrier()
+            dt = job.max_over_ranks(time.perf_counter() - t0)
+            assert fcounts == counts and ids[0] == "seq0" and len(ids) == m
+            out["file_to_counts_s"] = dt
+            out["file_to_counts_bases_per_s"] = total / dt
+            out["file_bytes"] = path.stat().st_size
+        finally:
+            job.barrier()
+            if job.rank == 0:
+                path.unlink(missing_ok=True)
+    return out if job.rank == 0 else None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="dna1g", choices=["dna1g", "random", "fasta512"])
+    ap.add_argument("--log2n", type=int, default=30, help="bases per GPU = 2^log2n (default 2^30)")
+    ap.add_argument("--cpu-sample-log2", type=int, default=26)
+    ap.add_argument("--python-sample-log2", type=int, default=26)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stopwatches", action="store_true")
+    ap.add_argument("--no-fasta", action="store_true", help="skip the fasta512 side measurement")
+    ap.add_argument("--fasta-records", type=int, default=512)
+    ap.add_argument("--fasta-record-log2", type=int, default=22)
+    ap.add_argument("--fasta-steps", type=int, default=2)
+    ap.add_argument("--fasta-warmup", type=int, default=1)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for N > 1 (nccl = RCCL over xGMI; gloo only for rehearsals)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="rehearsal on a one-GPU box: every rank uses cuda:0 (needs --backend gloo)")
+    a = ap.parse_args()
+    job = Job(a)
+
+    if a.workload == "fasta512":
+        a.fasta_steps, a.fasta_warmup = a.steps, a.warmup
+        fa = run_fasta_shard(job, a, with_file=True)
+        if job.rank == 0:
+            out = {"metric": "bases/sec factorized (multi-sequence FASTA shard, 512 x 4 Mi bases) + HBM GB/s fraction",
+                   "value": fa["value"], "unit": "bases/s", "n_gpus": job.world, "steps": a.steps, "warmup": a.warmup,
+                   "ms_per_step": fa["ms_per_step"], "higher_is_better": True, "scaling": "strong",
+                   "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+                   "config": {"workload": fa["workload"], "parallelism": f"{job.world} rank(s), LPT plan, all-gather of counts"},
+                   "fasta512": fa}
+            print(json.dumps(out), flush=True)
+    else:
+        out, text, z = run_single_sequence(job, a)
+        fa = None if a.no_fasta else run_fasta_shard(job, a, with_file=False)
+        if job.rank == 0:
+            if fa is not None:
+                out["fasta512"] = fa
+            if job.world == 1 and not a.no_stopwatches:  # the host-side clocks run on the one-GPU run only
+                out["stopwatches"] = stopwatches(text, z, a.python_sample_log2)
+            if job.world == 1 and not a.no_cpu_baseline:  # the CPU leg runs on rank 0 of the one-GPU run only
+                out["cpu_baseline"] = cpu_baseline(text, 1 << a.cpu_sample_log2)
+            print(json.dumps(out), flush=True)
+    if job.world > 1:
         dist.barrier()
         dist.destroy_process_group()
 

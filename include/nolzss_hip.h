@@ -47,7 +47,8 @@ enum {
     NOLZSS_ERR_RUNTIME = 2,
     NOLZSS_ERR_NOMEM = 3,
     NOLZSS_ERR_DEVICE = 4,
-    NOLZSS_ERR_IO = 5
+    NOLZSS_ERR_IO = 5,
+    NOLZSS_ERR_UNSUPPORTED = 6 /* the caller's own (host) path must handle this input */
 };
 
 const char *nolzss_last_error(void);
@@ -70,7 +71,10 @@ int nolzss_factorize_file(const char *path, size_t start_pos, int device, nolzss
 int nolzss_count_factors_file(const char *path, size_t start_pos, int device, size_t *z);
 
 /* Same computation with the text already resident in device memory (d_text is a device
- * pointer on `device`); `stream` is a hipStream_t or NULL for the context's own stream.
+ * pointer on `device`); `stream` is a hipStream_t or NULL for the context's own stream.  With NULL the
+ * call is ordered behind everything already queued on the legacy default stream (torch's default
+ * stream); a producer of d_text on another non-blocking stream must be synchronised by the caller or
+ * hand in its stream.
  * emit = 0: count only (the count_factors path);
  * emit = 1: build all z factor records in HBM and stop there (no PCIe transfer);
  * emit = 2: also copy them into a malloc'ed host array returned through out_host.
@@ -213,6 +217,38 @@ int nolzss_factorize_batch(const uint8_t *const *texts, const size_t *lens, size
 int nolzss_factorize_batch_dna_w_rc(const uint8_t *const *texts, const size_t *lens, size_t m,
                                     const int *devices, size_t n_dev, nolzss_factor ***out, size_t **z);
 void nolzss_free_batch(nolzss_factor **out, size_t *z, size_t m);
+/* The plain per-sequence batch with the records already in the memory of `device` (d_texts[j] = device
+ * pointer to lens[j] bytes): no PCIe leg.  emit = 0 counts, emit = 1 also builds the factor records of
+ * every record in HBM and stops there.  z[j] (caller-allocated, m entries) = factors of record j.  Used by
+ * bench.py for the FASTA shard workload (inputs resident in HBM when the clock starts). */
+int nolzss_factorize_batch_device(const void *const *d_texts, const size_t *lens, size_t m, int device, int emit,
+                                  size_t *z);
+
+/* ---- genomics.read_nucleotide_fasta: FASTA file in, per-record factors out ---------------------- */
+/* reference: read_nucleotide_fasta + _parse_fasta_content, src/noLZSS/genomics/fasta.py:28-126: parse
+ * (id = first header word, bases upper-cased, white space dropped, a repeated id keeps its place and
+ * takes the last record), check ^[ACGT]+$, then factorize() every record on its own (:110-122) -- here
+ * as ONE per-sequence batch over the listed devices, the records read in one piece and handed to the
+ * device as views of the read buffer.  Errors carry the reference's FASTAError texts ("Empty sequence
+ * header at line N", "Sequence data before header at line N", "No valid sequences found in FASTA file",
+ * "Sequence 'id' contains invalid nucleotides: {...}") with NOLZSS_ERR_RUNTIME; a file with non-ASCII
+ * bytes returns NOLZSS_ERR_UNSUPPORTED (the Python layer then parses it itself).
+ * Sharding (one process per GPU): with shard_count > 1 only the records that the longest-processing-
+ * time-first plan gives to shard_index are factorized (owners[j] = shard of record j, the same on every
+ * rank); counts[j] = 0 and factors[j] = NULL for the others, and the caller all-gathers the counts. */
+typedef struct nolzss_nucleotide_fasta {
+    char *sequence_ids;       /* num_sequences NUL-terminated ids, back to back, first-appearance order */
+    size_t sequence_ids_bytes;
+    size_t num_sequences;
+    size_t *lengths;          /* bases per record */
+    size_t *counts;           /* factors per record */
+    size_t *owners;           /* shard that factorized the record */
+    nolzss_factor **factors;  /* per record (NULL array when want_factors == 0) */
+    void *keep;               /* owns the factor blocks */
+} nolzss_nucleotide_fasta;
+int nolzss_read_nucleotide_fasta(const char *path, const int *devices, size_t n_dev, int want_factors,
+                                 size_t shard_index, size_t shard_count, nolzss_nucleotide_fasta *out);
+void nolzss_free_nucleotide_fasta(nolzss_nucleotide_fasta *r);
 
 /* ---- measurement hooks -------------------------------------------------------------------- */
 /* HIP-event timing of every pipeline stage on the context's stream (off by default). */
@@ -237,6 +273,12 @@ int nolzss_debug_arena(int device, size_t *capacity, size_t *peak);
  * reference: parse_fasta_sequences_and_ids, fasta_processor.cpp:28-128.  Free both with nolzss_free(). */
 int nolzss_debug_parse_fasta(const char *path, int sanitize_mode, char **ids, size_t *ids_bytes,
                              char **sequences, size_t *sequences_bytes, size_t *count);
+/* The reader behind nolzss_read_nucleotide_fasta alone (host only): the records after the nucleotide
+ * check, or the error the reference's Python reader raises.  reference: genomics/fasta.py:28-76, 110-115. */
+int nolzss_debug_parse_nucleotide_fasta(const char *path, char **ids, size_t *ids_bytes, char **sequences,
+                                        size_t *sequences_bytes, size_t *count);
+/* The shard plan of nolzss_read_nucleotide_fasta: owners[j] = shard of a record of lens[j] bases. */
+int nolzss_debug_lpt_plan(const size_t *lens, size_t m, size_t bins, size_t *owners);
 /* Gives the device arenas that no call is using back to the driver (they are otherwise kept between
  * calls and only grow; the library does this by itself when a reservation fails). */
 int nolzss_debug_trim_arenas(int device, size_t *released_bytes);

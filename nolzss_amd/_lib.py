@@ -10,7 +10,7 @@ from pathlib import Path
 _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "libnolzss_hip.so"
 
-OK, ERR_INVALID_ARGUMENT, ERR_RUNTIME, ERR_NOMEM, ERR_DEVICE, ERR_IO = range(6)
+OK, ERR_INVALID_ARGUMENT, ERR_RUNTIME, ERR_NOMEM, ERR_DEVICE, ERR_IO, ERR_UNSUPPORTED = range(7)
 
 
 class FastaResult(C.Structure):
@@ -25,6 +25,13 @@ class FastaPerSequenceResult(C.Structure):
     """Mirror of nolzss_fasta_per_sequence_result (include/nolzss_hip.h)."""
     _fields_ = [("factors", C.POINTER(C.c_void_p)), ("counts", C.POINTER(C.c_size_t)),
                 ("sequence_ids", C.c_void_p), ("sequence_ids_bytes", C.c_size_t), ("num_sequences", C.c_size_t)]
+
+
+class NucleotideFasta(C.Structure):
+    """Mirror of nolzss_nucleotide_fasta (include/nolzss_hip.h)."""
+    _fields_ = [("sequence_ids", C.c_void_p), ("sequence_ids_bytes", C.c_size_t), ("num_sequences", C.c_size_t),
+                ("lengths", C.POINTER(C.c_size_t)), ("counts", C.POINTER(C.c_size_t)),
+                ("owners", C.POINTER(C.c_size_t)), ("factors", C.POINTER(C.c_void_p)), ("keep", C.c_void_p)]
 
 
 class Factor(C.Structure):
@@ -85,8 +92,17 @@ def _load():
         C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), sz, C.POINTER(C.c_int), sz,
         C.POINTER(C.POINTER(C.c_void_p)), C.POINTER(C.POINTER(C.c_size_t))]
     lib.nolzss_factorize_batch_dna_w_rc.argtypes = lib.nolzss_factorize_batch.argtypes
+    lib.nolzss_factorize_batch_device.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), sz, C.c_int, C.c_int,
+                                                  C.POINTER(C.c_size_t)]
     lib.nolzss_free_batch.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), sz]
     lib.nolzss_free_batch.restype = None
+    lib.nolzss_read_nucleotide_fasta.argtypes = [C.c_char_p, C.POINTER(C.c_int), sz, C.c_int, sz, sz,
+                                                 C.POINTER(NucleotideFasta)]
+    lib.nolzss_free_nucleotide_fasta.argtypes = [C.POINTER(NucleotideFasta)]
+    lib.nolzss_free_nucleotide_fasta.restype = None
+    lib.nolzss_debug_parse_nucleotide_fasta.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), szp, C.POINTER(C.c_void_p),
+                                                        szp, szp]
+    lib.nolzss_debug_lpt_plan.argtypes = [szp, sz, sz, szp]
     lib.nolzss_profile_enable.argtypes = [C.c_int, C.c_int]
     lib.nolzss_profile_reset.argtypes = [C.c_int]
     lib.nolzss_profile_report.argtypes = [C.c_int, C.c_char_p, sz]
@@ -121,6 +137,7 @@ EXPORTED_SYMBOLS = [
     "nolzss_debug_arrays", "nolzss_debug_sort_pairs", "nolzss_debug_scan", "nolzss_debug_arena",
     "nolzss_debug_batch_counters", "nolzss_factorize_batch_dna_w_rc",
     "nolzss_debug_trim_arenas", "nolzss_debug_parse_fasta",
+    "nolzss_read_nucleotide_fasta", "nolzss_free_nucleotide_fasta", "nolzss_debug_parse_nucleotide_fasta", "nolzss_debug_lpt_plan", "nolzss_factorize_batch_device",
 ]
 
 

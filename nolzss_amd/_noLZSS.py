@@ -195,6 +195,68 @@ def factorize_batch(texts, devices=None, want_factors: bool = True, with_rc: boo
     return counts, arrays
 
 
+def factorize_batch_device(data_ptrs, lengths, emit: int = 0):
+    """Extension (measurement): per-sequence batch over records resident in device memory
+    (C ABI nolzss_factorize_batch_device); returns the factor count of every record."""
+    m = len(data_ptrs)
+    ptrs = (C.c_void_p * max(m, 1))(*data_ptrs)
+    lens = (C.c_size_t * max(m, 1))(*lengths)
+    zs = (C.c_size_t * max(m, 1))()
+    check(lib.nolzss_factorize_batch_device(ptrs, lens, m, _default_device, emit, zs))
+    return [zs[j] for j in range(m)]
+
+
+class UnsupportedInput(Exception):
+    """The native host-side reader does not take this input (NOLZSS_ERR_UNSUPPORTED): parse it in Python."""
+
+
+class _FastaResult:
+    """Frees a nolzss_nucleotide_fasta when the last array that views its blocks is gone."""
+
+    def __init__(self, res):
+        self.res = res
+
+    def __del__(self):
+        lib.nolzss_free_nucleotide_fasta(C.byref(self.res))
+
+
+def read_nucleotide_fasta_arrays(path, devices=None, want_factors: bool = True, shard_index: int = 0,
+                                 shard_count: int = 1):
+    """Extension: the native form of genomics.read_nucleotide_fasta (reference: genomics/fasta.py:79-126;
+    C ABI nolzss_read_nucleotide_fasta) -- the file is read, parsed and checked on the host by the
+    library, every record of this shard factorized as one per-sequence batch.  Returns
+    (ids, lengths, counts, owners, factor arrays or None); arrays of records this shard does not own are
+    None.  Raises RuntimeError with the reference's FASTAError text, UnsupportedInput for non-ASCII files."""
+    devices = list(devices) if devices is not None else [_default_device]
+    devs = (C.c_int * len(devices))(*devices)
+    res = _lib.NucleotideFasta()
+    rc = lib.nolzss_read_nucleotide_fasta(os.fsencode(str(path)), devs, len(devices), 1 if want_factors else 0,
+                                          shard_index, shard_count, C.byref(res))
+    if rc == _lib.ERR_UNSUPPORTED:
+        raise UnsupportedInput(lib.nolzss_last_error().decode("utf-8", "replace"))
+    check(rc)
+    owner = _FastaResult(res)
+    m = res.num_sequences
+    blob = C.string_at(res.sequence_ids, res.sequence_ids_bytes) if res.sequence_ids_bytes else b""
+    ids = [x.decode("utf-8") for x in blob.split(b"\x00")[:m]]
+    lengths = [res.lengths[j] for j in range(m)]
+    counts = [res.counts[j] for j in range(m)]
+    owners = [res.owners[j] for j in range(m)]
+    arrays = None
+    if want_factors:
+        arrays = []
+        for j in range(m):
+            if owners[j] != shard_index:
+                arrays.append(None)
+            elif counts[j] == 0 or not res.factors[j]:
+                arrays.append(np.zeros(0, dtype=FACTOR_DTYPE))
+            else:
+                raw = (C.c_uint64 * (3 * counts[j])).from_address(res.factors[j])
+                raw._owner = owner
+                arrays.append(np.frombuffer(raw, dtype=FACTOR_DTYPE))
+    return ids, lengths, counts, owners, arrays
+
+
 class _BatchResult:
     """Frees the result of nolzss_factorize_batch when the last array that views it is gone."""
 
@@ -690,6 +752,35 @@ def debug_parse_fasta(path, sanitize_mode: str = "remove_ambiguous"):
         lib.nolzss_free(seqs)
     assert len(a) == len(b) == count.value
     return list(zip(a, b))
+
+
+def debug_parse_nucleotide_fasta(path):
+    """[(id, sequence bytes)] as the reader behind read_nucleotide_fasta_arrays sees the file (host only);
+    raises what that entry point would."""
+    ids, seqs = C.c_void_p(), C.c_void_p()
+    nb_ids, nb_seqs, count = C.c_size_t(), C.c_size_t(), C.c_size_t()
+    rc = lib.nolzss_debug_parse_nucleotide_fasta(os.fsencode(str(path)), C.byref(ids), C.byref(nb_ids), C.byref(seqs),
+                                                 C.byref(nb_seqs), C.byref(count))
+    if rc == _lib.ERR_UNSUPPORTED:
+        raise UnsupportedInput(lib.nolzss_last_error().decode("utf-8", "replace"))
+    check(rc)
+    try:
+        a = C.string_at(ids, nb_ids.value).split(b"\0")[:-1] if nb_ids.value else []
+        b = C.string_at(seqs, nb_seqs.value).split(b"\0")[:-1] if nb_seqs.value else []
+    finally:
+        lib.nolzss_free(ids)
+        lib.nolzss_free(seqs)
+    assert len(a) == len(b) == count.value
+    return list(zip(a, b))
+
+
+def debug_lpt_plan(lengths, bins: int):
+    """owners of the records under the library's shard plan (host only)."""
+    m = len(lengths)
+    lens = (C.c_size_t * max(m, 1))(*lengths)
+    owners = (C.c_size_t * max(m, 1))()
+    check(lib.nolzss_debug_lpt_plan(lens, m, bins, owners))
+    return [owners[j] for j in range(m)]
 
 
 def debug_trim_arenas() -> int:

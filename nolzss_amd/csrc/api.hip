@@ -49,7 +49,8 @@ std::map<int, std::unique_ptr<DeviceContext>> g_ctx;
 
 constexpr size_t kMaxText = 0xffffffffull - (1ull << 16);  // 32-bit index pipeline
 
-size_t arena_bytes_for(size_t n) { return 108 * n + (size_t(64) << 20); }
+constexpr size_t kArenaBytesPerSymbol = 108;
+size_t arena_bytes_for(size_t n) { return kArenaBytesPerSymbol * n + (size_t(64) << 20); }
 
 constexpr int kMaxLanes = 16;  // concurrent pipelines (stream + arena each) per device
 
@@ -107,6 +108,20 @@ size_t trim_idle_arenas(int device, const Context *keep) {
 
 void reserve_arena(Context &ctx, size_t bytes) {
     if (bytes <= ctx.arena.capacity()) return;
+    {
+        // An input that cannot fit is refused up front, with the sizes, as an argument error (ValueError in
+        // Python) instead of failing late with a device out-of-memory error.
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && bytes > total_b) {
+            char buf[256];
+            snprintf(buf, sizeof buf,
+                     "input too large for this device: the pipeline needs %.1f GiB of device memory, the device has %.1f GiB "
+                     "(one MI355X takes about %.1f Gi symbols in plain mode, half of that with reverse complement)",
+                     (double)bytes / 1073741824.0, (double)total_b / 1073741824.0,
+                     (double)total_b / (double)kArenaBytesPerSymbol / 1073741824.0);
+            throw std::invalid_argument(buf);
+        }
+    }
     try {
         ctx.arena.reserve(bytes);
         return;
@@ -169,7 +184,16 @@ size_t run_plain(Context &ctx, const uint8_t *d_text, size_t n, size_t start_pos
         }
         *out_host = h;
     }
-    HIP_CHECK(hipStreamSynchronize(s));
+    {
+        const hipError_t e = hipStreamSynchronize(s);
+        if (e != hipSuccess) {  // a late device error: the caller gets an error status and no live pointer
+            if (out_host && *out_host) {
+                std::free(*out_host);
+                *out_host = nullptr;
+            }
+            HIP_CHECK(e);
+        }
+    }
     ctx.prof.collect();
     arena.rewind(mark);
     return z;
@@ -534,6 +558,18 @@ int nolzss_factorize_device(const void *d_text, size_t n, size_t start_pos, int 
         if (emit == 2 && !out_host) throw std::invalid_argument("emit = 2 needs out_host");
         check_text_args(d_text, n, start_pos);
         Session ses(device, stream);
+        if (!stream) {
+            // The library's own stream is non-blocking: order it behind the work already queued on the
+            // legacy default stream (where torch's default stream and plain hipMemcpyAsync(.., 0) producers
+            // of d_text run).  Producers on other non-blocking streams must be synchronised by the caller
+            // or pass their stream.
+            hipEvent_t ev = nullptr;
+            HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            hipError_t e = hipEventRecord(ev, nullptr);
+            if (e == hipSuccess) e = hipStreamWaitEvent(ses.ctx().stream, ev, 0);
+            (void)hipEventDestroy(ev);
+            HIP_CHECK(e);
+        }
         reserve_arena(ses.ctx(), arena_bytes_for(n));
         *z = run_plain(ses.ctx(), static_cast<const uint8_t *>(d_text), n, start_pos,
                        emit == 2 ? out_host : nullptr, nullptr, emit == 1);
@@ -1692,6 +1728,57 @@ int nolzss_factorize_batch_dna_w_rc(const uint8_t *const *texts, const size_t *l
     return factorize_batch_impl(texts, lens, m, devices, n_dev, true, out, z);
 }
 
+// The per-sequence batch with the records already resident in device memory (the measurement form: no
+// PCIe leg inside).  Every record takes its own pipeline run; `lanes` runs are in flight on the device,
+// each lane with its own stream and arena, as for the host-buffer batch.
+int nolzss_factorize_batch_device(const void *const *d_texts, const size_t *lens, size_t m, int device, int emit,
+                                  size_t *z) {
+    return guarded([&] {
+        if (m && (!d_texts || !lens || !z)) throw std::invalid_argument("sequence array is null");
+        if (emit != 0 && emit != 1) throw std::invalid_argument("emit must be 0 (count) or 1 (records built in HBM)");
+        for (size_t j = 0; j < m; ++j) check_text_args(d_texts[j], lens[j], 0);
+        std::vector<size_t> order(m);
+        std::iota(order.begin(), order.end(), (size_t)0);
+        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return lens[a] > lens[b]; });
+        static const size_t lanes_env = [] {
+            const char *e = getenv("NOLZSS_BATCH_LANES");
+            const long v = e ? atol(e) : 4;
+            return (size_t)(v < 1 ? 1 : (v > kMaxLanes ? kMaxLanes : v));
+        }();
+        size_t lanes = std::min(lanes_env, m ? m : (size_t)1);
+        if (m) {  // no more lanes than arenas for the longest record fit the device
+            size_t free_b = 0, total_b = 0;
+            HIP_CHECK(hipSetDevice(device));
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                const size_t fit = (size_t)((double)total_b * 0.85) / arena_bytes_for(lens[order[0]]);
+                lanes = std::max<size_t>(1, std::min(lanes, fit));
+            }
+        }
+        std::atomic<size_t> next{0};
+        std::vector<int> status(lanes, NOLZSS_OK);
+        std::vector<std::string> messages(lanes);
+        auto worker = [&](size_t lane) {
+            status[lane] = guarded([&] {
+                Session ses(device, nullptr, (int)lane);
+                for (;;) {
+                    const size_t k = next.fetch_add(1);
+                    if (k >= m) break;
+                    const size_t j = order[k];
+                    reserve_arena(ses.ctx(), arena_bytes_for(lens[j]));
+                    z[j] = run_plain(ses.ctx(), static_cast<const uint8_t *>(d_texts[j]), lens[j], 0, nullptr, nullptr,
+                                     emit == 1);
+                }
+            });
+            if (status[lane] != NOLZSS_OK) messages[lane] = g_error;
+        };
+        std::vector<std::thread> threads;
+        for (size_t lane = 0; lane < lanes; ++lane) threads.emplace_back(worker, lane);
+        for (auto &t : threads) t.join();
+        for (size_t lane = 0; lane < lanes; ++lane)
+            if (status[lane] != NOLZSS_OK) rethrow_worker_error(status[lane], messages[lane]);
+    });
+}
+
 // out[j] may point INTO a block shared by many records: only this function knows what to free
 void nolzss_free_batch(nolzss_factor **out, size_t *z, size_t m) {
     (void)m;
@@ -1709,6 +1796,239 @@ void nolzss_free_batch(nolzss_factor **out, size_t *z, size_t m) {
         std::free(out);
     }
     std::free(z);
+}
+
+}  // extern "C"
+
+// ---- genomics.read_nucleotide_fasta: the per-sequence FASTA batch, file in, per-record factors out ----
+namespace nolzss {
+namespace {
+
+struct NucleotideFasta {
+    FileBytes data;  // the records' bases are compacted in place in here
+    std::vector<std::string> ids;
+    std::vector<size_t> off, len;
+};
+
+[[noreturn]] void fasta_error(const std::string &msg) { throw std::runtime_error(msg); }
+
+// restates _parse_fasta_content and the nucleotide check of read_nucleotide_fasta,
+// /root/reference/src/noLZSS/genomics/fasta.py:28-76 and :110-115, for files of ASCII bytes (a file with
+// other bytes is handed back to the Python reader: false).  Python's rules, kept: lines end at \n, \r\n,
+// \r, \v, \f, \x1c, \x1d, \x1e (universal newlines + str.splitlines); white space (str.strip, re \s) is
+// \t \n \v \f \r \x1c-\x1f and the blank; the id is the first word of the header; bases are upper-cased;
+// a repeated id keeps its first place in the order and takes the LAST record's bases (dict semantics).
+bool parse_nucleotide_fasta(const char *path, NucleotideFasta &res) {
+    if (!path) throw std::invalid_argument("path is null");
+    res.data = read_file(path);
+    uint8_t *const base = const_cast<uint8_t *>(res.data.data());
+    const size_t size = res.data.size();
+    {
+        uint8_t any = 0;
+        for (size_t at = 0; at < size; ++at) any |= base[at];
+        if (any & 0x80) return false;
+    }
+    enum : uint8_t { kBase = 0, kLower = 1, kSpace = 2, kBreak = 3, kOther = 4 };
+    uint8_t kind[256];
+    for (int c = 0; c < 256; ++c) kind[c] = kOther;
+    for (unsigned char c : {'A', 'C', 'G', 'T'}) kind[c] = kBase;
+    for (int c = 'a'; c <= 'z'; ++c) kind[c] = kLower;
+    for (int c : {(int)'\t', (int)' ', 0x1f}) kind[c] = kSpace;
+    for (int c : {(int)'\r', (int)'\v', (int)'\f', 0x1c, 0x1d, 0x1e}) kind[c] = kBreak;  // (\n is what the scan splits at)
+    auto is_space = [&](uint8_t c) { return kind[c] == kSpace || kind[c] == kBreak || c == '\n'; };
+
+    std::map<std::string, size_t> index;  // id -> position in res.ids
+    bool have_id = false;
+    std::string cur_id;
+    uint8_t *rec = base;  // the bases of the current record go to [rec, rec + cur_len), never beyond the read position
+    size_t cur_len = 0, line_num = 0;
+    auto store = [&] {
+        auto it = index.find(cur_id);
+        if (it == index.end()) {
+            index.emplace(cur_id, res.ids.size());
+            res.ids.push_back(cur_id);
+            res.off.push_back((size_t)(rec - base));
+            res.len.push_back(cur_len);
+        } else {
+            res.off[it->second] = (size_t)(rec - base);
+            res.len[it->second] = cur_len;
+        }
+        rec += cur_len;
+        cur_len = 0;
+    };
+    auto one_line = [&](const uint8_t *line, size_t len) {  // a line without any line break inside
+        ++line_num;
+        while (len && is_space(line[len - 1])) --len;
+        while (len && is_space(line[0])) ++line, --len;
+        if (!len) return;
+        if (line[0] == '>') {
+            if (have_id) store();
+            size_t start = 1;
+            while (start < len && is_space(line[start])) ++start;
+            if (start >= len) fasta_error("Empty sequence header at line " + std::to_string(line_num));
+            size_t stop = start;
+            while (stop < len && !is_space(line[stop])) ++stop;
+            cur_id.assign(reinterpret_cast<const char *>(line) + start, stop - start);
+            have_id = true;
+            return;
+        }
+        if (!have_id) fasta_error("Sequence data before header at line " + std::to_string(line_num));
+        uint8_t *out = rec + cur_len;  // <= line
+        uint8_t mixed = 0;
+        for (size_t i = 0; i < len; ++i) mixed |= kind[line[i]];
+        if (!mixed) {  // the usual line: upper-case bases only
+            if (out != line) std::memmove(out, line, len);
+            cur_len += len;
+            return;
+        }
+        size_t k = 0;
+        for (size_t i = 0; i < len; ++i) {
+            const uint8_t c = line[i], t = kind[c];
+            if (t == kSpace) continue;
+            out[k++] = t == kLower ? (uint8_t)(c - 32) : c;  // (anything that is not a base fails the check below)
+        }
+        cur_len += k;
+    };
+    const uint8_t *p = base, *const end = base + size;
+    while (p < end) {
+        const uint8_t *nl = static_cast<const uint8_t *>(std::memchr(p, '\n', (size_t)(end - p)));
+        const uint8_t *line = p;
+        size_t len = (size_t)((nl ? nl : end) - p);
+        p = nl ? nl + 1 : end;
+        if (nl && len && line[len - 1] == '\r') --len;  // \r\n is one line end
+        uint8_t brk = 0;
+        for (size_t i = 0; i < len; ++i) brk |= (uint8_t)(kind[line[i]] == kBreak);
+        if (!brk) {
+            one_line(line, len);
+            continue;
+        }
+        size_t at = 0;  // (rare) other line ends inside: \r, \v, \f, \x1c-\x1e
+        for (size_t i = 0; i <= len; ++i)
+            if (i == len || kind[line[i]] == kBreak) {
+                // (a break that is the last byte of the FILE ends the last line; in front of a \n it is followed by an empty line)
+                if (i < len || i > at || nl) one_line(line + at, i - at);
+                at = i + 1;
+            }
+    }
+    if (have_id) store();
+    if (res.ids.empty()) fasta_error("No valid sequences found in FASTA file");
+    for (size_t j = 0; j < res.ids.size(); ++j) {  // ^[ACGT]+$ (fasta.py:112)
+        const uint8_t *q = base + res.off[j];
+        bool present[128] = {false};
+        uint8_t bad = 0;
+        for (size_t i = 0; i < res.len[j]; ++i) bad |= kind[q[i]];
+        if (!bad && res.len[j]) continue;
+        for (size_t i = 0; i < res.len[j]; ++i) present[q[i] & 127] = true;
+        std::string set;
+        for (int c = 0; c < 128; ++c)
+            if (present[c] && kind[c] != kBase) {
+                if (!set.empty()) set += ", ";
+                set += "'";
+                set += (char)c;
+                set += "'";
+            }
+        fasta_error("Sequence '" + res.ids[j] + "' contains invalid nucleotides: " + (set.empty() ? "set()" : "{" + set + "}"));
+    }
+    return true;
+}
+
+// Longest-processing-time-first bin packing, the plan every rank of a sharded job computes for itself:
+// records by (length descending, index), bins by (load, index).
+std::vector<size_t> lpt_owner(const std::vector<size_t> &lens, size_t bins) {
+    std::vector<size_t> order(lens.size()), owner(lens.size(), 0), load(bins, 0);
+    std::iota(order.begin(), order.end(), (size_t)0);
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return lens[a] > lens[b]; });
+    for (size_t j : order) {
+        const size_t b = (size_t)(std::min_element(load.begin(), load.end()) - load.begin());
+        owner[j] = b;
+        load[b] += lens[j];
+    }
+    return owner;
+}
+
+struct NucleotideFastaKeep {
+    NucleotideFasta parse;
+    std::vector<void *> blocks;
+    ~NucleotideFastaKeep() {
+        for (void *b : blocks) std::free(b);
+    }
+};
+
+}  // namespace
+}  // namespace nolzss
+
+extern "C" {
+
+int nolzss_read_nucleotide_fasta(const char *path, const int *devices, size_t n_dev, int want_factors,
+                                 size_t shard_index, size_t shard_count, nolzss_nucleotide_fasta *out) {
+    if (out) std::memset(out, 0, sizeof *out);
+    bool ascii = true;
+    const int rc = guarded([&] {
+        if (!out) throw std::invalid_argument("output pointer is null");
+        if (!devices || n_dev == 0) throw std::invalid_argument("device list is empty");
+        if (shard_count == 0 || shard_index >= shard_count) throw std::invalid_argument("shard index out of range");
+        std::unique_ptr<NucleotideFastaKeep> keep(new NucleotideFastaKeep);
+        NucleotideFasta &P = keep->parse;
+        ascii = parse_nucleotide_fasta(path, P);
+        if (!ascii) return;
+        const size_t m = P.ids.size();
+        const std::vector<size_t> owner = lpt_owner(P.len, shard_count);
+        std::vector<const uint8_t *> texts;
+        std::vector<size_t> lens, mine;
+        for (size_t j = 0; j < m; ++j)
+            if (owner[j] == shard_index) {
+                check_text_args(P.data.data() + P.off[j], P.len[j], 0);
+                mine.push_back(j);
+                texts.push_back(P.data.data() + P.off[j]);
+                lens.push_back(P.len[j]);
+            }
+        std::vector<size_t> zs(mine.size() ? mine.size() : 1, 0);
+        std::vector<nolzss_factor *> fs(mine.size() ? mine.size() : 1, nullptr);
+        try {
+            factorize_many(texts.data(), lens.data(), mine.size(), devices, n_dev, false, zs.data(),
+                           want_factors ? fs.data() : nullptr, keep->blocks);
+        } catch (const std::exception &e) {  // fasta.py:121-122
+            throw std::runtime_error(std::string("Failed to factorize sequences of '") + path + "': " + e.what());
+        }
+        std::string blob;
+        for (const auto &id : P.ids) blob.append(id).push_back('\0');
+        out->sequence_ids = static_cast<char *>(std::malloc(blob.size() + 1));
+        out->lengths = static_cast<size_t *>(std::calloc(m, sizeof(size_t)));
+        out->counts = static_cast<size_t *>(std::calloc(m, sizeof(size_t)));
+        out->owners = static_cast<size_t *>(std::calloc(m, sizeof(size_t)));
+        out->factors = want_factors ? static_cast<nolzss_factor **>(std::calloc(m, sizeof(nolzss_factor *))) : nullptr;
+        if (!out->sequence_ids || !out->lengths || !out->counts || !out->owners || (want_factors && !out->factors)) {
+            nolzss_free_nucleotide_fasta(out);
+            throw std::bad_alloc();
+        }
+        std::memcpy(out->sequence_ids, blob.data(), blob.size());
+        out->sequence_ids_bytes = blob.size();
+        out->num_sequences = m;
+        for (size_t j = 0; j < m; ++j) {
+            out->lengths[j] = P.len[j];
+            out->owners[j] = owner[j];
+        }
+        for (size_t k = 0; k < mine.size(); ++k) {
+            out->counts[mine[k]] = zs[k];
+            if (want_factors) out->factors[mine[k]] = fs[k];
+        }
+        P.data = FileBytes{};  // the text is not needed any more; the factor blocks are
+        out->keep = keep.release();
+    });
+    if (rc == NOLZSS_OK && !ascii)
+        return set_error(NOLZSS_ERR_UNSUPPORTED, "the file holds non-ASCII bytes: the native FASTA reader takes ASCII files only");
+    return rc;
+}
+
+void nolzss_free_nucleotide_fasta(nolzss_nucleotide_fasta *r) {
+    if (!r) return;
+    delete static_cast<NucleotideFastaKeep *>(r->keep);
+    std::free(r->sequence_ids);
+    std::free(r->lengths);
+    std::free(r->counts);
+    std::free(r->owners);
+    std::free(r->factors);
+    std::memset(r, 0, sizeof *r);
 }
 
 int nolzss_debug_parse_fasta(const char *path, int sanitize_mode, char **ids, size_t *ids_bytes, char **sequences,
@@ -1735,6 +2055,49 @@ int nolzss_debug_parse_fasta(const char *path, int sanitize_mode, char **ids, si
         *sequences = pb;
         *sequences_bytes = b.size();
         *count = parse.sequences.size();
+    });
+}
+
+int nolzss_debug_parse_nucleotide_fasta(const char *path, char **ids, size_t *ids_bytes, char **sequences,
+                                        size_t *sequences_bytes, size_t *count) {
+    bool ascii = true;
+    const int rc = guarded([&] {
+        if (!ids || !ids_bytes || !sequences || !sequences_bytes || !count)
+            throw std::invalid_argument("output pointer is null");
+        *ids = *sequences = nullptr;
+        *ids_bytes = *sequences_bytes = *count = 0;
+        NucleotideFasta P;
+        ascii = parse_nucleotide_fasta(path, P);
+        if (!ascii) return;
+        std::string a, b;
+        for (size_t j = 0; j < P.ids.size(); ++j) {
+            a.append(P.ids[j]).push_back('\0');
+            b.append(reinterpret_cast<const char *>(P.data.data()) + P.off[j], P.len[j]).push_back('\0');
+        }
+        char *pa = static_cast<char *>(std::malloc(a.size() + 1)), *pb = static_cast<char *>(std::malloc(b.size() + 1));
+        if (!pa || !pb) {
+            std::free(pa);
+            std::free(pb);
+            throw std::bad_alloc();
+        }
+        std::memcpy(pa, a.data(), a.size());
+        std::memcpy(pb, b.data(), b.size());
+        *ids = pa;
+        *ids_bytes = a.size();
+        *sequences = pb;
+        *sequences_bytes = b.size();
+        *count = P.ids.size();
+    });
+    if (rc == NOLZSS_OK && !ascii)
+        return set_error(NOLZSS_ERR_UNSUPPORTED, "the file holds non-ASCII bytes: the native FASTA reader takes ASCII files only");
+    return rc;
+}
+
+int nolzss_debug_lpt_plan(const size_t *lens, size_t m, size_t bins, size_t *owners) {
+    return guarded([&] {
+        if ((m && (!lens || !owners)) || bins == 0) throw std::invalid_argument("bad plan arguments");
+        const std::vector<size_t> o = lpt_owner(std::vector<size_t>(lens, lens + m), bins);
+        for (size_t j = 0; j < m; ++j) owners[j] = o[j];
     });
 }
 

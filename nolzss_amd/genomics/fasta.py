@@ -77,24 +77,57 @@ def lpt_assignment(lengths: Sequence[int], n_bins: int) -> List[int]:
     return owner
 
 
+def _factorize_file_records(filepath, devices, want_factors, shard_index=0, shard_count=1):
+    """(ids, lengths, counts, owners, arrays) for the records of a FASTA file: the native reader + batch
+    (C ABI nolzss_read_nucleotide_fasta) for ASCII files, else this module's parser with the same plan."""
+    filepath = Path(filepath)
+    if not filepath.exists():
+        raise FileNotFoundError(f"FASTA file not found: {filepath}")
+    try:
+        return _noLZSS.read_nucleotide_fasta_arrays(filepath, devices, want_factors, shard_index, shard_count)
+    except _noLZSS.UnsupportedInput:
+        pass  # non-ASCII bytes (a header in another script, or a broken file): Python's own decoding rules
+    except RuntimeError as e:  # the reader's errors are the reference's FASTAError texts
+        raise FASTAError(str(e))
+    records = _load_validated(filepath)
+    owners = lpt_assignment([len(s) for _, s in records], shard_count)
+    mine = [j for j, o in enumerate(owners) if o == shard_index]
+    try:
+        got_counts, got = _noLZSS.factorize_batch([records[j][1] for j in mine], devices=devices,
+                                                  want_factors=want_factors)
+    except Exception as e:
+        raise FASTAError(f"Failed to factorize sequences of '{filepath}': {e}")
+    counts = [0] * len(records)
+    arrays = [None] * len(records) if want_factors else None
+    for k, j in enumerate(mine):
+        counts[j] = got_counts[k]
+        if want_factors:
+            arrays[j] = got[k]
+    return [rid for rid, _ in records], [len(s) for _, s in records], counts, owners, arrays
+
+
 def read_nucleotide_fasta(filepath: Union[str, Path], devices: Optional[Sequence[int]] = None
                           ) -> List[Tuple[str, List[Tuple[int, int, int]]]]:
     """[(sequence_id, [(start, length, ref), ...]), ...] in first-appearance order
     (reference: fasta.py:79-126).  `devices` (extension) spreads the sequences over several
     GPUs of this process; default: the current device only."""
-    records = _load_validated(filepath)
-    try:
-        _, arrays = _noLZSS.factorize_batch([seq for _, seq in records], devices=devices, want_factors=True)
-    except Exception as e:
-        raise FASTAError(f"Failed to factorize sequences of '{filepath}': {e}")
-    return [(seq_id, _noLZSS._tuples3(f)) for (seq_id, _), f in zip(records, arrays)]
+    ids, _, _, _, arrays = _factorize_file_records(filepath, devices, True)
+    return [(rid, _noLZSS._tuples3(f)) for rid, f in zip(ids, arrays)]
+
+
+def read_nucleotide_fasta_arrays(filepath: Union[str, Path], devices: Optional[Sequence[int]] = None,
+                                 want_factors: bool = True):
+    """Extension: the same records as (ids, factor counts, NumPy arrays of (start, length, ref)) -- for
+    files whose tuple lists would not fit (config 4 of the benchmark: 2 * 10^8 tuples)."""
+    ids, _, counts, _, arrays = _factorize_file_records(filepath, devices, want_factors)
+    return ids, counts, arrays
 
 
 def shard_nucleotide_fasta(filepath: Union[str, Path], want_factors: bool = False):
     """Multi-GPU form of read_nucleotide_fasta for a torch.distributed job (one process per GPU,
     backend nccl = RCCL on ROCm, or gloo on CPU-only ranks for tests).
 
-    Every rank parses the file, takes the sequences the LPT plan assigns to it, factorizes them
+    Every rank reads the file, takes the sequences the LPT plan assigns to it, factorizes them
     on its own GPU and contributes its per-sequence factor counts to ONE all-gather (the only
     collective on this path).  Returns (ids, counts, local) where counts[j] is the factor count
     of sequence j on every rank and local maps the indices owned by this rank to their factor
@@ -102,25 +135,17 @@ def shard_nucleotide_fasta(filepath: Union[str, Path], want_factors: bool = Fals
     import torch
     import torch.distributed as dist
 
-    records = _load_validated(filepath)
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
-    owner = lpt_assignment([len(s) for _, s in records], world)
-    mine = [j for j, o in enumerate(owner) if o == rank]
-    counts_local, arrays = _noLZSS.factorize_batch([records[j][1] for j in mine], want_factors=want_factors)
-    m = len(records)
+    ids, _, counts_mine, owners, arrays = _factorize_file_records(filepath, None, want_factors, rank, world)
     if world > 1:
         use_cuda = dist.get_backend() == "nccl"
         dev = torch.device("cuda", torch.cuda.current_device()) if use_cuda else torch.device("cpu")
-        mine_vec = torch.zeros(m, dtype=torch.int64, device=dev)
-        if mine:
-            mine_vec[torch.tensor(mine, device=dev)] = torch.tensor(counts_local, dtype=torch.int64, device=dev)
+        mine_vec = torch.tensor(counts_mine, dtype=torch.int64, device=dev)  # zero for records of other ranks
         gathered = [torch.zeros_like(mine_vec) for _ in range(world)]
         dist.all_gather(gathered, mine_vec)
         counts = torch.stack(gathered).sum(dim=0).cpu().tolist()
     else:
-        counts = [0] * m
-        for j, c in zip(mine, counts_local):
-            counts[j] = c
-    local = {j: (arrays[k] if arrays is not None else None) for k, j in enumerate(mine)}
-    return [rid for rid, _ in records], counts, local
+        counts = list(counts_mine)
+    local = {j: (arrays[j] if arrays is not None else None) for j, o in enumerate(owners) if o == rank}
+    return ids, counts, local

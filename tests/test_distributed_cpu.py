@@ -1,5 +1,7 @@
-"""World-size-2 gloo test of the multi-GPU FASTA shard path (no GPU): the per-rank factorize call
-is replaced by the oracle so that the sharding plan and the all-gather of counts are exercised."""
+"""World-size-2 gloo tests of the multi-GPU FASTA shard path (no GPU): the per-rank device call is
+replaced by the oracle so that the reader, the sharding plan and the all-gather of counts are exercised.
+Two variants: the library's reader + plan (as on the GPU box), and the Python reader + plan that
+non-ASCII files fall back to."""
 import os
 import socket
 import sys
@@ -18,7 +20,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, fasta, outdir):
+def _worker(rank, world, port, fasta, outdir, variant):
     sys.path.insert(0, str(ROOT))
     sys.path.insert(0, str(ROOT / "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -31,7 +33,18 @@ def _worker(rank, world, port, fasta, outdir):
         arrays = [oracle.factors_array(bytes(t)) for t in texts]
         return [len(a) for a in arrays], (arrays if want_factors else None)
 
+    def fake_native(path, devices=None, want_factors=True, shard_index=0, shard_count=1):
+        if variant == "python":
+            raise _noLZSS.UnsupportedInput("forced")
+        recs = _noLZSS.debug_parse_nucleotide_fasta(path)                 # the library's reader (host only)
+        lens = [len(s) for _, s in recs]
+        owners = _noLZSS.debug_lpt_plan(lens, shard_count)                # the library's plan
+        arrays = [oracle.factors_array(s) if o == shard_index else None for (_, s), o in zip(recs, owners)]
+        counts = [len(a) if a is not None else 0 for a in arrays]
+        return [i.decode() for i, _ in recs], lens, counts, owners, (arrays if want_factors else None)
+
     _noLZSS.factorize_batch = fake_batch  # the CPU checker stands in for the GPU on this rank
+    _noLZSS.read_nucleotide_fasta_arrays = fake_native
     dist.init_process_group("gloo", rank=rank, world_size=world)
     ids, counts, local = F.shard_nucleotide_fasta(fasta, want_factors=True)
     np.save(Path(outdir) / f"counts{rank}.npy", np.array(counts, dtype=np.int64))
@@ -41,14 +54,15 @@ def _worker(rank, world, port, fasta, outdir):
 
 
 @pytest.mark.timeout(300)
-def test_shard_fasta_two_ranks_gloo(tmp_path):
+@pytest.mark.parametrize("variant", ["native", "python"])
+def test_shard_fasta_two_ranks_gloo(tmp_path, variant):
     import gen
     import oracle_lib as oracle
     recs = [(f"seq{k}", gen.random_dna(2000 + 531 * k, 100 + k)) for k in range(7)]
     fasta = tmp_path / "in.fa"
     gen.write_fasta(fasta, recs)
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(fasta), str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(fasta), str(tmp_path), variant), nprocs=2, join=True)
     c0 = np.load(tmp_path / "counts0.npy")
     c1 = np.load(tmp_path / "counts1.npy")
     expected = np.array([oracle.count_factors(seq) for _, seq in recs])

@@ -118,3 +118,82 @@ def test_reader_fuzz(tmp_path):
 def test_reader_missing_file():
     with pytest.raises(RuntimeError, match="Cannot open FASTA file"):
         native.debug_parse_fasta("/nonexistent/a.fasta")
+
+
+# ---- the reader behind read_nucleotide_fasta (reference: genomics/fasta.py:28-76, 110-115) -------------
+def _python_reader(path):
+    """the Python mirror of the reference's rules (nolzss_amd.genomics.fasta), as (records | error text)"""
+    from nolzss_amd.genomics import fasta as F
+    try:
+        return [(rid.encode(), seq) for rid, seq in F._load_validated(path)], None
+    except F.FASTAError as e:
+        return None, str(e)
+
+
+def _native_reader(path):
+    from nolzss_amd import _noLZSS
+    try:
+        return _noLZSS.debug_parse_nucleotide_fasta(path), None
+    except RuntimeError as e:
+        return None, str(e)
+
+
+def _same_error(a, b):
+    import re as _re
+    if a == b:
+        return True
+    # Python prints the set of invalid characters in arbitrary order
+    pa, pb = _re.match(r"(.*invalid nucleotides: )\{(.*)\}$", a or ""), _re.match(r"(.*invalid nucleotides: )\{(.*)\}$", b or "")
+    return bool(pa and pb and pa.group(1) == pb.group(1) and
+                set(pa.group(2).split(", ")) == set(pb.group(2).split(", ")))
+
+
+@pytest.mark.parametrize("content", [
+    b">a\nACGT\n", b">a desc here\nACGT\nacgt\n>b\nGG\n", b">a\r\nAC\r\nGT\r\n", b">a\rACGT\r>b\rTT",
+    b"\n\n>a\n\nAC GT\n\t\n", b">a\nAC\x0bGT\x0cAA\x1cCC\x1dGG\x1eTT\x1fA\n", b">  a  b\n  ACGT  \n",
+    b">a\nACGT\n>a\nTTTT\n>b\nGG\n", b">a\nACGT\n>b\n>c\nGG\n", b">a\nACGN\n", b">a\nAC-GT*\n", b"ACGT\n>a\nAC\n",
+    b">\nACGT\n", b"> \t\nACGT\n", b"", b"\n\n", b">a\n", b">a\nACGT", b">a\nacgtn\n", b">a\x1cACGT\n",
+    b">a\n\x1f\nACGT\n", b">a\nA>C\n", b" >a\nACGT\n", b">a\nACGT\n\r\n\r\n>b\r\nA\r\n",
+])
+def test_nucleotide_reader_cases(tmp_path, content):
+    p = tmp_path / "x.fa"
+    p.write_bytes(content)
+    exp, exp_err = _python_reader(p)
+    got, got_err = _native_reader(p)
+    assert got == exp and _same_error(got_err, exp_err), (content, got, exp, got_err, exp_err)
+
+
+def test_nucleotide_reader_fuzz(tmp_path):
+    import random
+    rng = random.Random(2024)
+    pieces = [b">", b">id", b">id2 words", b"ACGT", b"acgt", b"AACCGGTT" * 10, b"N", b" ", b"\t", b"\n", b"\n", b"\n",
+              b"\r\n", b"\r", b"\x0b", b"\x0c", b"\x1c", b"\x1e", b"\x1f", b"-", b"TTTT", b"\n>", b"\n>s", b"\n>t x\n"]
+    p = tmp_path / "f.fa"
+    for _ in range(3000):
+        content = b"".join(rng.choice(pieces) for _ in range(rng.randint(0, 14)))
+        if rng.random() < 0.7:
+            content = b">h\n" + content
+        p.write_bytes(content)
+        exp, exp_err = _python_reader(p)
+        got, got_err = _native_reader(p)
+        assert got == exp and _same_error(got_err, exp_err), (content, got, exp, got_err, exp_err)
+
+
+def test_nucleotide_reader_leaves_non_ascii_to_python(tmp_path):
+    from nolzss_amd import _noLZSS
+    p = tmp_path / "u.fa"
+    p.write_bytes(">séq désc\nACGT\n".encode("utf-8"))
+    with pytest.raises(_noLZSS.UnsupportedInput):
+        _noLZSS.debug_parse_nucleotide_fasta(p)
+    assert _python_reader(p)[0] == [("séq".encode(), b"ACGT")]
+
+
+def test_shard_plan_matches_python_plan():
+    import random
+    from nolzss_amd import _noLZSS
+    from nolzss_amd.genomics.fasta import lpt_assignment
+    rng = random.Random(5)
+    for _ in range(200):
+        lens = [rng.choice([0, 1, 5, 5, 100, rng.randint(1, 10**6)]) for _ in range(rng.randint(0, 40))]
+        bins = rng.randint(1, 9)
+        assert _noLZSS.debug_lpt_plan(lens, bins) == lpt_assignment(lens, bins)

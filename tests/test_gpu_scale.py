@@ -100,6 +100,55 @@ def test_config4_fasta_records_batch(native, tmp_path):
         assert factors == oracle.factorize(seq)
 
 
+@pytest.mark.timeout(1500)
+def test_config4_fasta_512_records_end_to_end(native, tmp_path):
+    """BASELINE config 4 at its stated size through its stated caller: a FASTA file of 512 records x 4 Mi
+    bases (generator of config 2, seeds 0x4000 + k, 80-column lines, 2.2 GB) through the
+    read_nucleotide_fasta path (file -> native reader -> per-sequence batch; reference:
+    genomics/fasta.py:79-126) on one GPU.  ALL 512 factor counts are checked against the oracle run per
+    record in a host thread pool, the complete factor lists of a sample of records bit by bit, every record
+    for tiling; the tuple-list form of the API on the first records of the same file."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    from pathlib import Path
+    from nolzss_amd.genomics import read_nucleotide_fasta
+    from nolzss_amd.genomics.fasta import read_nucleotide_fasta_arrays
+    m, L = 512, 1 << 22
+    workers = min(16, os.cpu_count() or 8)
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        seqs = list(pool.map(lambda k: gen.random_dna(L, 0x4000 + k), range(m)))
+    shm = Path("/dev/shm")
+    path = (shm if shm.is_dir() else tmp_path) / f"nolzss_config4_{os.getpid()}.fa"
+    try:
+        gen.write_fasta_fast(path, [(f"seq{k}", s) for k, s in enumerate(seqs)])
+        assert path.stat().st_size > 2_170_000_000
+        ids, counts, arrays = read_nucleotide_fasta_arrays(path)
+        ids2, counts2, none = read_nucleotide_fasta_arrays(path, want_factors=False)
+    finally:
+        path.unlink(missing_ok=True)
+    assert ids == ids2 == [f"seq{k}" for k in range(m)] and counts2 == counts and none is None
+    with ThreadPoolExecutor(max_workers=workers) as pool:  # (the oracle releases the GIL: ctypes)
+        expected = list(pool.map(oracle.count_factors, seqs))
+    assert counts == expected
+    for k in range(m):
+        assert len(arrays[k]) == counts[k]
+        _check_tiling(arrays[k], L)
+    for k in (0, 1, 100, 255, 256, 300, 510, 511):
+        exp = oracle.factors_array(seqs[k])
+        for key in ("start", "length", "ref"):
+            assert np.array_equal(arrays[k][key], exp[key]), (k, key)
+    # the reference's result shape (lists of int tuples) on the head of the same data
+    head = tmp_path / "head.fa"
+    gen.write_fasta_fast(head, [(f"seq{k}", seqs[k]) for k in range(3)])
+    res = read_nucleotide_fasta(head)
+    assert [rid for rid, _ in res] == ["seq0", "seq1", "seq2"]
+    for k, (_, tuples) in enumerate(res):
+        assert len(tuples) == counts[k] and tuples[:1000] == list(zip(arrays[k]["start"][:1000].tolist(),
+                                                                       arrays[k]["length"][:1000].tolist(),
+                                                                       arrays[k]["ref"][:1000].tolist()))
+        assert tuples[-1] == tuple(int(arrays[k][key][-1]) for key in ("start", "length", "ref"))
+
+
 @pytest.mark.timeout(900)
 def test_rc_4Mi_exact(native):
     text = gen.repeat_dna(1 << 22, seed=0x5EED0005, lo=16, hi=8192)
