@@ -114,8 +114,14 @@ __global__ __launch_bounds__(kThreads) void rs_hist_kernel(Src src, size_t n, in
     __shared__ __align__(16) uint32_t hist[kBins * kCopies];
 #pragma unroll
     for (int c = 0; c < kCopies; ++c) hist[c * kBins + threadIdx.x] = 0;
+    // XCD-contiguous tile ranges, as in the scatter kernel: the table is bin-major, so the 256 counts of a
+    // tile go to 256 different lines, each shared with the 15 neighbouring tiles -- written from one XCD
+    // those 4-byte writes merge in its L2; dealt round-robin over the XCDs every one of them reached HBM
+    // as a partial line (67 M of them per pass at 2^30 keys).
+    const uint32_t tile = xcd_tile(blockIdx.x, num_tiles);
+    if (tile == 0xffffffffu) return;
     __syncthreads();
-    const TileExtent ext = tile_extent(blockIdx.x, n, num_tiles, seg);
+    const TileExtent ext = tile_extent(tile, n, num_tiles, seg);
     const uint32_t copy = threadIdx.x & (kCopies - 1);
     if (src.digits_from_window(shift)) {
         static_assert(kKeysPerThread == 16, "16 two-bit symbols and an 8-bit digit fit one 64-bit window");
@@ -282,7 +288,7 @@ void radix_pass(Src src, OutT *keys_out, uint32_t *vals_out, size_t n, int shift
                 const SegView &seg = SegView{}) {
     {
         ProfScope ps(prof, "rs_hist", stream, hist_bytes);
-        rs_hist_kernel<KeyT, Src><<<num_tiles, kThreads, 0, stream>>>(src, n, shift, hist, num_tiles, seg);
+        rs_hist_kernel<KeyT, Src><<<(uint32_t)div_up(num_tiles, 8) * 8, kThreads, 0, stream>>>(src, n, shift, hist, num_tiles, seg);
         KERNEL_CHECK();
     }
     {
