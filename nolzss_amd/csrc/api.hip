@@ -47,7 +47,7 @@ struct DeviceContext {
 std::mutex g_ctx_mu;
 std::map<int, std::unique_ptr<DeviceContext>> g_ctx;
 
-constexpr size_t kMaxText = 0xffffffffull - (1ull << 16);  // 32-bit index pipeline
+constexpr size_t kMaxText = 0xffffffffull - (1ull << 19);  // 32-bit index pipeline (sharded queue slots stay below 2^32)
 
 constexpr size_t kArenaBytesPerSymbol = 108;
 size_t arena_bytes_for(size_t n) { return kArenaBytesPerSymbol * n + (size_t(64) << 20); }

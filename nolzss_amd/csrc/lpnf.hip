@@ -19,118 +19,156 @@
 
 #include <cstdlib>
 #include "nearest_lds.hpp"
+#include "queues.hpp"
 #include "radix_sort.hpp"
 
 namespace nolzss {
+
+__global__ void shard_totals_kernel(const uint32_t *const *counts, int nq, uint32_t *totals) {
+    const int q = blockIdx.x;
+    if (q >= nq) return;
+    uint32_t v = threadIdx.x < kQShards ? counts[q][threadIdx.x * kQPad] : 0u;
+    v = wave_reduce(v, OpAdd<uint32_t>());
+    __shared__ uint32_t s_part[kQShards / 64];
+    if (lane_id() == 0) s_part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (uint32_t k = 0; k < kQShards / 64; ++k) t += s_part[k];
+        totals[q] = t;
+    }
+}
+
 namespace {
 
 constexpr int kThreads = 256;
 constexpr uint32_t kFarBothUnknown = 0xfffffffeu;  // far_aux: neither direction ended inside the tile
 
-// turn the two neighbour candidates into L*[i], or queue i for the exact search
-// (*dst receives L*[i] or, for queued positions, a lower bound with P(bound) true)
-__device__ __forceinline__ void lpf_decide(uint32_t i, uint32_t lp, uint32_t jp, uint32_t ls, uint32_t js,
-                                           uint32_t *__restrict__ dst, uint32_t *__restrict__ queue,
-                                           uint32_t *__restrict__ queue_count) {
+// turn the two neighbour candidates into L*[i]; returns true if i needs the exact search
+// (*dst then receives a lower bound with P(bound) true)
+__device__ __forceinline__ bool lpf_decide(uint32_t i, uint32_t lp, uint32_t jp, uint32_t ls, uint32_t js,
+                                           uint32_t *__restrict__ dst) {
     const uint32_t M = lp > ls ? lp : ls;
     if (M == 0) {
         *dst = 0;
-        return;
+        return false;
     }
     const bool ok = (lp == M && i - jp >= M) || (ls == M && i - js >= M);
     if (ok) {
         *dst = M;
-        return;
+        return false;
     }
     // best earlier match overlaps position i: exact search needed; record a true lower bound
     uint32_t lo = 0;
     if (lp > 0) { const uint32_t c = lp < i - jp ? lp : i - jp; lo = c > lo ? c : lo; }
     if (ls > 0) { const uint32_t c = ls < i - js ? ls : i - js; lo = c > lo ? c : lo; }
     *dst = lo;
-    queue[atomicAdd(queue_count, 1u)] = i;
+    return true;
 }
 
+// kBlocks: block-table search (nearest_lds.hpp, lds_search_wave_blocks); false: the list / row scheme
+template <bool kBlocks, bool kTimed>
 __global__ __launch_bounds__(kLdsThreads) void lpf_tile_kernel(const uint32_t *__restrict__ sa,
                                                                const uint32_t *__restrict__ lcp, uint32_t n,
                                                                uint32_t *__restrict__ lstar_by_rank,
-                                                               uint32_t *__restrict__ queue,
-                                                               uint32_t *__restrict__ queue_count,
-                                                               uint32_t *__restrict__ far_queue,
-                                                               uint32_t *__restrict__ far_count,
-                                                               uint32_t *__restrict__ far_aux) {
+                                                               ShardQueue exact_q, ShardQueue far_q,
+                                                               uint32_t *__restrict__ far_aux,
+                                                               unsigned long long *__restrict__ phases) {
     constexpr int NS = 2;
-    __shared__ uint32_t s_sa[kLdsSpan];
-    __shared__ uint32_t s_lcp[kLdsSpan + 1];
+    // (diagnostics, NOLZSS_LPF_PHASES: cycles per phase summed over the wavefronts of every 16th workgroup)
+    const bool timed = kTimed && phases != nullptr && (blockIdx.x & 15) == 0;
+    unsigned long long clk[6] = {0, 0, 0, 0, 0, 0};
+    if (timed) clk[0] = __builtin_readcyclecounter();
+    __shared__ __align__(16) uint32_t s_sa[kLdsSpan];
+    __shared__ __align__(16) uint32_t s_lcp[kLdsSpan + 4];
     __shared__ uint32_t s_len[NS * kLdsTile];
     __shared__ uint32_t s_pos[NS * kLdsTile];
     __shared__ uint16_t s_list[kLdsWaves][2][NS * kLdsPerWave];
+    __shared__ uint32_t s_blk[kBlocks ? 3 * kNumBlk : 1];
     const uint32_t base = blockIdx.x * (uint32_t)kLdsTile;
+    const uint32_t shard = blockIdx.x % kQShards;
     stage_tile(sa, lcp, n, base, s_sa, s_lcp);
     __syncthreads();
+    const BlockTables T{s_blk, nullptr, s_blk + (kBlocks ? kNumBlk : 0), s_blk + (kBlocks ? 2 * kNumBlk : 0)};
+    if (kBlocks) {
+        build_block_tables<false>(s_sa, s_lcp, T);
+        __syncthreads();
+    }
+    if (timed) clk[1] = __builtin_readcyclecounter();
     const int w = threadIdx.x >> 6;
     const uint32_t far_bit = n <= 0x80000000u ? 0x80000000u : 0u;
-    lds_search_wave<NS, NS, 1>(s_sa, s_lcp, n, base, s_len, s_pos, s_list[w][0], s_list[w][1],
-                            [](uint32_t) { return true; }, [](uint32_t) { return 0u; }, far_bit);
-    // ranks with a search beyond the reach go to the far queue: one atomic per wavefront
-    uint64_t far_mask[kLdsPerWave / 64];
-    uint32_t far_total = 0;
+    if (kBlocks)
+        lds_search_wave_blocks<NS, NS>(s_sa, s_lcp, T, n, base, s_len, s_pos, s_list[w][0], s_list[w][1],
+                                       [](uint32_t) { return true; }, [](uint32_t) { return 0u; }, far_bit,
+                                       timed ? clk + 2 : nullptr);
+    else
+        lds_search_wave<NS, NS, 1, 0>(s_sa, s_lcp, n, base, s_len, s_pos, s_list[w][0], s_list[w][1],
+                                      [](uint32_t) { return true; }, [](uint32_t) { return 0u; }, far_bit,
+                                      timed ? clk + 2 : nullptr);
+    if (timed) clk[4] = __builtin_readcyclecounter();
+    // epilogue: every rank is decided, or goes to the far queue (a search beyond the reach whose bound can
+    // still beat the other direction) or to the exact-search queue -- ONE atomic per wavefront and queue
+    constexpr int kRows = kLdsPerWave / 64;
+    bool far[kRows], exact[kRows];
+    uint32_t aux[kRows], known[kRows], fslot[kRows], eslot[kRows];
 #pragma unroll
-    for (int row = 0; row < kLdsPerWave / 64; ++row) {
-        const int t = w * kLdsPerWave + row * 64 + lane_id();
-        // a search that left the reach matters only if its bound can beat the other direction
-        uint32_t up = s_len[t], down = s_len[kLdsTile + t];
-        const bool far = far_resolve(up, down, far_bit, 0u) && (uint64_t)base + t < n;
-        s_len[t] = up;
-        s_len[kLdsTile + t] = down;
-        far_mask[row] = __ballot(far);
-        far_total += (uint32_t)__popcll(far_mask[row]);
-    }
-    uint32_t far_base = 0;
-    if (far_total) {
-        if (lane_id() == 0) far_base = atomicAdd(far_count, far_total);
-        far_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)far_base);
-    }
-#pragma unroll
-    for (int row = 0; row < kLdsPerWave / 64; ++row) {
+    for (int row = 0; row < kRows; ++row) {
         const int t = w * kLdsPerWave + row * 64 + lane_id();
         const uint64_t rr = (uint64_t)base + t;
-        const bool far = (far_mask[row] >> lane_id()) & 1;
-        if (far) far_queue[far_base + (uint32_t)__popcll(far_mask[row] & lanemask_lt())] = (uint32_t)rr;
-        far_base += (uint32_t)__popcll(far_mask[row]);
-        if (rr >= n) continue;
-        if (far) {
+        const bool in = rr < n;
+        uint32_t up = s_len[t], down = s_len[kLdsTile + t];
+        const bool fu = far_is(up, far_bit), fd = far_is(down, far_bit);
+        far[row] = far_resolve(up, down, far_bit, 0u) && in;
+        exact[row] = false;
+        aux[row] = kFarBothUnknown;
+        known[row] = 0;
+        if (far[row]) {
             // finished from global memory by lpf_far_kernel; what the direction that did end inside
             // the tile found travels along (length in the by-rank slot, position + side in far_aux)
-            const uint32_t up = s_len[t], down = s_len[kLdsTile + t];
-            const bool fu = far_is(up, far_bit), fd = far_is(down, far_bit);
-            uint32_t known_len = 0, aux = kFarBothUnknown;
             if (far_bit && fu != fd) {
-                known_len = fu ? down : up;
+                known[row] = fu ? down : up;
                 const uint32_t p = fu ? s_pos[kLdsTile + t] : s_pos[t];
-                aux = (known_len ? (p & 0x7fffffffu) : 0x7fffffffu) | (fu ? 0x80000000u : 0u);
+                aux[row] = (known[row] ? (p & 0x7fffffffu) : 0x7fffffffu) | (fu ? 0x80000000u : 0u);
             }
-            lstar_by_rank[rr] = known_len;
-            far_aux[rr] = aux;
-            continue;
+        } else if (in) {
+            exact[row] = lpf_decide(s_sa[t + kLdsReach], up, s_pos[t], down, s_pos[kLdsTile + t], lstar_by_rank + rr);
         }
-        lpf_decide(s_sa[t + kLdsReach], s_len[t], s_pos[t], s_len[kLdsTile + t], s_pos[kLdsTile + t],
-                   lstar_by_rank + rr, queue, queue_count);
+    }
+    shard_slots<kRows>(far_q, shard, far, fslot);
+    shard_slots<kRows>(exact_q, shard, exact, eslot);
+#pragma unroll
+    for (int row = 0; row < kRows; ++row) {
+        const int t = w * kLdsPerWave + row * 64 + lane_id();
+        const uint64_t rr = (uint64_t)base + t;
+        if (far[row]) {
+            far_q.items[fslot[row]] = (uint32_t)rr;
+            lstar_by_rank[rr] = known[row];
+            far_aux[rr] = aux[row];
+        }
+        if (exact[row]) exact_q.items[eslot[row]] = s_sa[t + kLdsReach];
+    }
+    if (timed) {
+        __builtin_amdgcn_s_waitcnt(0);
+        clk[5] = __builtin_readcyclecounter();
+        if (lane_id() == 0) {
+            for (int k = 0; k < 5; ++k) atomicAdd(phases + k, clk[k + 1] - clk[k]);
+            atomicAdd(phases + 5, 1ull);
+        }
     }
 }
 
-// ranks whose nearest earlier suffix lies outside the LDS reach: pyramid search
-__global__ __launch_bounds__(kThreads) void lpf_far_kernel(const uint32_t *__restrict__ far_queue, uint32_t count,
-                                                           const uint32_t *__restrict__ sa,
+// ranks whose nearest earlier suffix lies outside the LDS reach: pyramid search.  Grid (kQShards, Y).
+__global__ __launch_bounds__(kThreads) void lpf_far_kernel(ShardQueue far_q, const uint32_t *__restrict__ sa,
                                                            const uint32_t *__restrict__ lcp, uint32_t n,
                                                            Pyramid Psa, Pyramid Plcp,
                                                            const uint32_t *__restrict__ by_rank,
                                                            const uint32_t *__restrict__ far_aux, bool bounded,
-                                                           uint32_t *__restrict__ lstar,
-                                                           uint32_t *__restrict__ queue,
-                                                           uint32_t *__restrict__ queue_count) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < count; k += stride) {
-        const uint32_t r = far_queue[k];
+                                                           uint32_t *__restrict__ lstar, ShardQueue exact_q) {
+    const uint32_t shard = blockIdx.x;
+    const uint32_t count = far_q.counts[shard * kQPad];
+    const uint32_t *items = far_q.items + (size_t)shard * far_q.cap;
+    for (uint32_t k = blockIdx.y * blockDim.x + threadIdx.x; k < count; k += gridDim.y * blockDim.x) {
+        const uint32_t r = items[k];
         const uint32_t i = sa[r];
         const uint32_t aux = far_aux[r];
         uint32_t lp, jp, ls, js;
@@ -149,18 +187,21 @@ __global__ __launch_bounds__(kThreads) void lpf_far_kernel(const uint32_t *__res
             jp = (aux & 0x7fffffffu) == 0x7fffffffu ? kNoPos : (aux & 0x7fffffffu);
             far_down<false>(sa, n, Psa, Plcp, r, i, lp, ls, js);
         }
-        lpf_decide(i, lp, jp, ls, js, lstar + i, queue, queue_count);
+        const bool exact = lpf_decide(i, lp, jp, ls, js, lstar + i);
+        const uint32_t eslot = shard_slot(exact_q, shard, exact);  // (a rank reaches the exact queue at most once)
+        if (exact) exact_q.items[eslot] = i;
     }
 }
 
-__global__ __launch_bounds__(kThreads) void lpnf_fallback_kernel(const uint32_t *__restrict__ queue,
-                                                                 uint32_t count, uint32_t n,
+__global__ __launch_bounds__(kThreads) void lpnf_fallback_kernel(ShardQueue exact_q, uint32_t n,
                                                                  const uint32_t *__restrict__ isa,
                                                                  Pyramid Psa, Pyramid Plcp,
                                                                  uint32_t *__restrict__ lstar) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < count; k += stride) {
-        const uint32_t i = queue[k];
+    const uint32_t shard = blockIdx.x;
+    const uint32_t count = exact_q.counts[shard * kQPad];
+    const uint32_t *items = exact_q.items + (size_t)shard * exact_q.cap;
+    for (uint32_t k = blockIdx.y * blockDim.x + threadIdx.x; k < count; k += gridDim.y * blockDim.x) {
+        const uint32_t i = items[k];
         const uint32_t cap = (n - i) < i ? (n - i) : i;  // L* <= i - j <= i and L* <= n - i
         lstar[i] = lpnf_search(Psa, Plcp, isa[i] - 1u, i, lstar[i], cap);  // P(lstar[i]) holds on entry
     }
@@ -172,19 +213,55 @@ uint32_t build_lstar(Context &ctx, uint32_t n, const uint32_t *sa, const uint32_
                      const Pyramid &Psa, const Pyramid &Plcp, uint32_t *lstar) {
     hipStream_t s = ctx.stream;
     const size_t mark = ctx.arena.mark();
-    uint32_t *queue = ctx.arena.alloc<uint32_t>(n);
-    uint32_t *far_queue = ctx.arena.alloc<uint32_t>(n);
-    uint32_t *counts = ctx.arena.alloc<uint32_t>(2);  // [0] exact-search queue, [1] far queue
+    const unsigned tiles = (unsigned)div_up(n, kLdsTile);
+    ShardQueue exact_q, far_q;
+    exact_q.cap = far_q.cap = (uint32_t)shard_queue_cap(tiles, kLdsTile);
+    exact_q.items = ctx.arena.alloc<uint32_t>((size_t)kQShards * exact_q.cap);
+    far_q.items = ctx.arena.alloc<uint32_t>((size_t)kQShards * far_q.cap);
+    uint32_t *qcounts = ctx.arena.alloc<uint32_t>(2 * kQShards * kQPad);
+    exact_q.counts = qcounts;
+    far_q.counts = qcounts + kQShards * kQPad;
+    const uint32_t **count_ptrs = ctx.arena.alloc<const uint32_t *>(2);
+    uint32_t *totals = ctx.arena.alloc<uint32_t>(2);  // [0] exact-search queue, [1] far queue
     uint32_t *by_rank = ctx.arena.alloc<uint32_t>(n);
     uint32_t *far_aux = ctx.arena.alloc<uint32_t>(n);
     uint32_t *scratch_idx = ctx.arena.alloc<uint32_t>(n);
     uint32_t *scratch_val = ctx.arena.alloc<uint32_t>(n);
-    HIP_CHECK(hipMemsetAsync(counts, 0, 2 * sizeof(uint32_t), s));
+    HIP_CHECK(hipMemsetAsync(qcounts, 0, 2 * kQShards * kQPad * sizeof(uint32_t), s));
+    const uint32_t *h_ptrs[2] = {exact_q.counts, far_q.counts};
+    HIP_CHECK(hipMemcpyAsync(count_ptrs, h_ptrs, sizeof h_ptrs, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipStreamSynchronize(s));  // h_ptrs is a local array
+    auto read_totals = [&](uint32_t h[2]) {
+        shard_totals_kernel<<<2, kQShards, 0, s>>>(count_ptrs, 2, totals);
+        KERNEL_CHECK();
+        ctx.read_back(totals, h, 2);
+    };
     {
         ProfScope ps(ctx.profiler(), "lpf", s, 12.0 * (double)n);
-        lpf_tile_kernel<<<(unsigned)div_up(n, kLdsTile), kLdsThreads, 0, s>>>(sa, lcp, n, by_rank, queue, counts,
-                                                                          far_queue, counts + 1, far_aux);
+        static const bool old_scheme = getenv("NOLZSS_LPF_LISTS") != nullptr;  // (A/B: the list / row scheme)
+        static const bool want_phases = getenv("NOLZSS_LPF_PHASES") != nullptr;
+        unsigned long long *phases = nullptr;
+        if (want_phases) {
+            phases = ctx.arena.alloc<unsigned long long>(8);
+            HIP_CHECK(hipMemsetAsync(phases, 0, 64, s));
+        }
+        if (phases && old_scheme)
+            lpf_tile_kernel<false, true><<<tiles, kLdsThreads, 0, s>>>(sa, lcp, n, by_rank, exact_q, far_q, far_aux, phases);
+        else if (phases)
+            lpf_tile_kernel<true, true><<<tiles, kLdsThreads, 0, s>>>(sa, lcp, n, by_rank, exact_q, far_q, far_aux, phases);
+        else if (old_scheme)
+            lpf_tile_kernel<false, false><<<tiles, kLdsThreads, 0, s>>>(sa, lcp, n, by_rank, exact_q, far_q, far_aux, nullptr);
+        else
+            lpf_tile_kernel<true, false><<<tiles, kLdsThreads, 0, s>>>(sa, lcp, n, by_rank, exact_q, far_q, far_aux, nullptr);
         KERNEL_CHECK();
+        if (phases) {
+            unsigned long long h[8];
+            HIP_CHECK(hipMemcpyAsync(h, phases, 64, hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+            const double w = h[5] ? (double)h[5] : 1.0;
+            fprintf(stderr, "[nolzss] lpf_tile phases (cycles per wavefront, %llu sampled): stage %.0f  round0 %.0f  %s %.0f  %s %.0f  epilogue %.0f\n",
+                    h[5], h[0] / w, h[1] / w, old_scheme ? "worklist" : "roundA", h[2] / w, old_scheme ? "tail" : "roundsBC", h[3] / w, h[4] / w);
+        }
     }
     {
         // lstar[sa[r]] = by_rank[r]: rank order -> text order (a permutation scatter)
@@ -194,23 +271,21 @@ uint32_t build_lstar(Context &ctx, uint32_t n, const uint32_t *sa, const uint32_
         bucketed_scatter(idx, val, n, lstar, n, ctx.arena, s, ctx.profiler(), true);
     }
     uint32_t h[2] = {0, 0};
-    ctx.read_back(counts, h, 2);
+    read_totals(h);
     static const bool trace = getenv("NOLZSS_TRACE") != nullptr;
     if (trace) fprintf(stderr, "[nolzss] lpf: %u ranks to the far queue, %u positions to the exact search so far\n", h[1], h[0]);
     if (h[1] > 0) {
         ProfScope ps(ctx.profiler(), "lpf_far", s);
-        size_t g = div_up(h[1], kThreads);
-        if (g > 256u * 32u) g = 256u * 32u;
-        lpf_far_kernel<<<(unsigned)g, kThreads, 0, s>>>(far_queue, h[1], sa, lcp, n, Psa, Plcp, by_rank, far_aux,
-                                                        n <= 0x80000000u, lstar, queue, counts);
+        const unsigned gy = (unsigned)std::min<size_t>(64, std::max<size_t>(1, div_up(h[1], (size_t)kQShards * kThreads)));
+        lpf_far_kernel<<<dim3(kQShards, gy), kThreads, 0, s>>>(far_q, sa, lcp, n, Psa, Plcp, by_rank, far_aux,
+                                                              n <= 0x80000000u, lstar, exact_q);
         KERNEL_CHECK();
-        ctx.read_back(counts, h, 1);
+        read_totals(h);
     }
     if (h[0] > 0) {
         ProfScope ps(ctx.profiler(), "lpnf_fallback", s);
-        size_t g = div_up(h[0], kThreads);
-        if (g > 256u * 32u) g = 256u * 32u;
-        lpnf_fallback_kernel<<<(unsigned)g, kThreads, 0, s>>>(queue, h[0], n, isa, Psa, Plcp, lstar);
+        const unsigned gy = (unsigned)std::min<size_t>(64, std::max<size_t>(1, div_up(h[0], (size_t)kQShards * kThreads)));
+        lpnf_fallback_kernel<<<dim3(kQShards, gy), kThreads, 0, s>>>(exact_q, n, isa, Psa, Plcp, lstar);
         KERNEL_CHECK();
     }
     ctx.arena.rewind(mark);

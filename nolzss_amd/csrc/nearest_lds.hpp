@@ -139,11 +139,12 @@ __device__ __forceinline__ int lds_scan_round(const uint32_t *s_sa, const uint32
 // Results: res_len[k * kLdsTile + t] (0: none, far_mark(): left the reach) and, for the first NP
 // searches only, res_pos[k * kLdsTile + t] (suffix start of the match).
 // list0/list1: this wave's two work lists (NS * kLdsPerWave items each).
-template <int NS, int NP, int kPerLane, typename Active, typename ThrGt>
+// kPrune: bit 0 = drop in the first round, bit 1 = in the work-list rounds, bit 2 = in the tail
+template <int NS, int NP, int kPerLane, int kPrune, typename Active, typename ThrGt>
 __device__ __forceinline__ void lds_search_wave(const uint32_t *s_sa, const uint32_t *s_lcp, uint32_t n,
                                                 uint32_t base, uint32_t *res_len, uint32_t *res_pos,
                                                 uint16_t *list0, uint16_t *list1, Active active, ThrGt thr_gt,
-                                                uint32_t far_bit) {
+                                                uint32_t far_bit, unsigned long long *phase_clock = nullptr) {
     const int lane = lane_id();
     const int w = threadIdx.x >> 6;
     const uint64_t lt = lanemask_lt();
@@ -173,7 +174,7 @@ __device__ __forceinline__ void lds_search_wave(const uint32_t *s_sa, const uint
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
             const int o = k ^ 1;
-            if (st[k] == 2 && st[o] == 1 && m[k] <= m[o]) st[k] = 0;
+            if ((kPrune & 1) && st[k] == 2 && st[o] == 1 && m[k] <= m[o]) st[k] = 0;
         }
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
@@ -187,6 +188,7 @@ __device__ __forceinline__ void lds_search_wave(const uint32_t *s_sa, const uint
         }
     }
 
+    if (phase_clock) phase_clock[0] = __builtin_readcyclecounter();
     // ---- drain the work list: 64 items at a time, kLdsStep more steps each --------------------
     // (while the list is long enough to keep most lanes busy)
     int cur = 0;
@@ -208,7 +210,7 @@ __device__ __forceinline__ void lds_search_wave(const uint32_t *s_sa, const uint
                 const int st = lds_scan_round<kLdsStep>(s_sa, s_lcp, li, done, greater, up,
                                                         greater ? thr_gt(i) : i, m, pos);
                 int stp = st;
-                if (st == 2 && (k | 1) < NP) {  // (the partner's position tells a found partner from a pending one)
+                if ((kPrune & 2) && st == 2 && (k | 1) < NP) {  // (the partner's position tells a found partner from a pending one)
                     const uint32_t ol = res_len[(k ^ 1) * kLdsTile + t], op = res_pos[(k ^ 1) * kLdsTile + t];
                     if (op != kNoPos && m <= ol) stp = 0;  // cannot beat what the other direction found
                 }
@@ -229,6 +231,7 @@ __device__ __forceinline__ void lds_search_wave(const uint32_t *s_sa, const uint
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
+    if (phase_clock) phase_clock[1] = __builtin_readcyclecounter();
     // ---- the long tail: few searches left, each possibly far from done (a search that has taken
     // s steps needs about s more).  Rounds of 8 steps would finish almost nothing per round, and
     // the kernel is bound by instruction issue, so the tail is organised for few instructions per
@@ -267,14 +270,17 @@ __device__ __forceinline__ void lds_search_wave(const uint32_t *s_sa, const uint
                 }
             }
             next += (uint32_t)__popc(idle_rows);
-            if (busy && (k | 1) < NP) {  // dropped if it cannot beat what the other direction has found
+            if ((kPrune & 4) && busy && (k | 1) < NP) {  // dropped if it cannot beat what the other direction has found
                 const uint32_t ol = res_len[(k ^ 1) * kLdsTile + t], op = res_pos[(k ^ 1) * kLdsTile + t];
                 if (op != kNoPos && m <= ol) {
                     if (rl == 0) res_len[k * kLdsTile + t] = 0u;  // (its position entry is still kNoPos)
                     busy = false;
                 }
             }
-            if (!__ballot(busy)) break;
+            if (!__ballot(busy)) {
+                if (next >= cnt) break;
+                continue;  // every row dropped its search: take the next entries
+            }
             // my four steps: s0 + 4 rl + 1 .. s0 + 4 rl + 4
             uint32_t c[kPerLane], v[kPerLane];
             bool in[kPerLane];
@@ -340,6 +346,195 @@ __device__ __forceinline__ void lds_search_wave(const uint32_t *s_sa, const uint
             }
         }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// The same searches WITHOUT the long tail: block minima let a search skip 16 ranks per step.
+//
+// Phase timing of the list / row scheme above (clock per wavefront, 2^28 bases): staging 3.7 k cycles,
+// first round 6.2 k, work-list rounds 6.5 k, the tail of <= 24 long searches 29 k, epilogue 6 k -- more than
+// half of the kernel goes to a handful of searches that walk up to 256 ranks 16 at a time.  Here the
+// workgroup also keeps, per aligned block of 16 staged ranks, the minimum (maximum) suffix start and the
+// minimum LCP crossed when the block is passed upwards / downwards.  A search that is still going after
+//   round 0   4 steps, every rank, branch-free (as above), and
+//   round A   16 more steps, the unfinished searches 64 at a time (as above),
+// continues by BLOCKS:
+//   round B   the next 16 blocks away from the rank, nearest first: running minimum of the block LCP
+//             minima, stop at the first block that holds a qualifying suffix or drives the minimum to 0;
+//   round C   the 16 ranks of that block, nearest first, from the minimum carried so far: ends inside.
+// Blocks that overlap ranks already passed are harmless (a minimum is idempotent and those ranks do not
+// qualify).  No stop within the 16 blocks (>= 261 ranks away): the search leaves the reach with its bound,
+// exactly as before.  Every search takes at most four rounds, all of them 64 searches wide.
+constexpr int kBlk = 16;
+constexpr int kNumBlk = kLdsSpan / kBlk;  // 96
+static_assert(kLdsSpan % kBlk == 0 && kLdsReach % kBlk == 0 && kLdsTile % kBlk == 0, "aligned blocks");
+constexpr int kStepA = 16;
+
+struct BlockTables {
+    uint32_t *mn, *mx;    // min / max suffix start of the block (mx may be null)
+    uint32_t *lup, *ldn;  // min LCP crossed passing the block upwards (entries 16B+1 .. 16B+16) / downwards (16B .. 16B+15)
+};
+
+// run by the whole workgroup after the tile has been staged (and a barrier); followed by a barrier
+template <bool kMax>
+__device__ __forceinline__ void build_block_tables(const uint32_t *s_sa, const uint32_t *s_lcp, const BlockTables &T) {
+    const int B = (int)threadIdx.x;
+    if (B < kNumBlk) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(s_sa + kBlk * B);
+        const uint4 *c = reinterpret_cast<const uint4 *>(s_lcp + kBlk * B);
+        uint32_t mn = 0xffffffffu, mx = 0u, lo = 0xffffffffu;
+        uint32_t first = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint4 a = p[q], l = c[q];
+            const uint32_t av[4] = {a.x, a.y, a.z, a.w}, lv[4] = {l.x, l.y, l.z, l.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                mn = av[e] < mn ? av[e] : mn;
+                mx = av[e] > mx ? av[e] : mx;
+                if (q == 0 && e == 0)
+                    first = lv[e];
+                else
+                    lo = lv[e] < lo ? lv[e] : lo;  // entries 16B+1 .. 16B+15
+            }
+        }
+        const uint32_t last = s_lcp[kBlk * B + kBlk];
+        T.mn[B] = mn;
+        if (kMax) T.mx[B] = mx;
+        T.ldn[B] = lo < first ? lo : first;
+        T.lup[B] = lo < last ? lo : last;
+    }
+}
+
+template <int NS, int NP, typename Active, typename ThrGt>
+__device__ __forceinline__ void lds_search_wave_blocks(const uint32_t *s_sa, const uint32_t *s_lcp,
+                                                       const BlockTables &T, uint32_t n, uint32_t base,
+                                                       uint32_t *res_len, uint32_t *res_pos, uint16_t *list0,
+                                                       uint16_t *list1, Active active, ThrGt thr_gt,
+                                                       uint32_t far_bit, unsigned long long *phase_clock = nullptr) {
+    const int lane = lane_id();
+    const int w = threadIdx.x >> 6;
+    const uint64_t lt = lanemask_lt();
+    uint32_t cnt = 0;
+
+    // ---- round 0: every rank, every search, steps 1..kLdsStep0 --------------------------------
+#pragma unroll 1
+    for (int row = 0; row < kLdsPerWave / 64; ++row) {
+        const int tl = row * 64 + lane;
+        const int t = w * kLdsPerWave + tl;
+        const uint64_t rr = (uint64_t)base + t;
+        const int li = t + kLdsReach;
+        const uint32_t i = s_sa[li];
+        const bool valid = rr < n && active(i);
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const bool greater = k >= 2, up = (k & 1) == 0;
+            uint32_t m = 0xffffffffu, pos = kNoPos;
+            int st = 0;
+            if (valid) st = lds_scan_round<kLdsStep0>(s_sa, s_lcp, li, 0, greater, up, greater ? thr_gt(i) : i, m, pos);
+            res_len[k * kLdsTile + t] = (st == 0) ? 0u : m;
+            if (k < NP) res_pos[k * kLdsTile + t] = (st == 1) ? pos : kNoPos;
+            const bool pending = st == 2;
+            const uint64_t bal = __ballot(pending);
+            if (pending) list0[cnt + (uint32_t)__popcll(bal & lt)] = (uint16_t)(tl | (k << 8));  // rank in the wave | search << 8
+            cnt += (uint32_t)__popcll(bal);
+        }
+    }
+    if (phase_clock) phase_clock[0] = __builtin_readcyclecounter();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- round A: kStepA more steps for the searches still going ---------------------------------
+    uint32_t cnt_b = 0;
+    for (uint32_t c0 = 0; c0 < cnt; c0 += 64) {
+        const bool have = c0 + lane < cnt;
+        const uint32_t item = have ? list0[c0 + lane] : 0u;
+        const int tl = item & 255, k = (item >> 8) & 3;
+        const int t = w * kLdsPerWave + tl;
+        const int li = t + kLdsReach;
+        const bool greater = k >= 2, up = (k & 1) == 0;
+        bool pending = false;
+        if (have) {
+            const uint32_t i = s_sa[li];
+            uint32_t m = res_len[k * kLdsTile + t], pos = kNoPos;
+            const int st = lds_scan_round<kStepA>(s_sa, s_lcp, li, kLdsStep0, greater, up, greater ? thr_gt(i) : i, m, pos);
+            pending = st == 2;
+            res_len[k * kLdsTile + t] = (st == 0) ? 0u : m;
+            if (k < NP) res_pos[k * kLdsTile + t] = (st == 1) ? pos : kNoPos;
+        }
+        const uint64_t bal = __ballot(pending);
+        if (pending) list1[cnt_b + (uint32_t)__popcll(bal & lt)] = (uint16_t)item;
+        cnt_b += (uint32_t)__popcll(bal);
+    }
+    if (phase_clock) phase_clock[1] = __builtin_readcyclecounter();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- rounds B + C: by blocks, then inside the block that stops the search ---------------------
+    for (uint32_t c0 = 0; c0 < cnt_b; c0 += 64) {
+        const bool have = c0 + lane < cnt_b;
+        const uint32_t item = have ? list1[c0 + lane] : 0u;
+        const int tl = item & 255, k = (item >> 8) & 3;
+        const int t = w * kLdsPerWave + tl;
+        const int li = t + kLdsReach;
+        const bool greater = k >= 2, up = (k & 1) == 0;
+        const uint32_t i = s_sa[li];
+        const uint32_t x = greater ? thr_gt(i) : i;
+        const uint32_t flip = greater ? 0xffffffffu : 0u;
+        const uint32_t xf = x ^ flip;
+        const uint32_t m_in = have ? res_len[k * kLdsTile + t] : 0xffffffffu;
+        // first block beyond the kLdsStep0 + kStepA ranks already passed (it may overlap them)
+        const int b0 = up ? (li - (kLdsStep0 + kStepA + 1)) >> 4 : (li + (kLdsStep0 + kStepA + 1)) >> 4;
+        const uint32_t *tv = greater ? T.mx : T.mn;
+        const uint32_t *tc = up ? T.lup : T.ldn;
+        uint32_t c[kBlk], v[kBlk];
+#pragma unroll
+        for (int j = 0; j < kBlk; ++j) {
+            const int B = up ? b0 - j : b0 + j;
+            const bool in = have && B >= 0 && B < kNumBlk;
+            const int Bc = in ? B : 0;
+            const uint32_t cc = tc[Bc], vv = tv[Bc];
+            c[j] = in ? cc : 0xffffffffu;
+            v[j] = in ? (vv ^ flip) : 0xffffffffu;  // (flipped: "qualifies" is "< xf" for both kinds; out of range never does)
+        }
+        uint32_t run = m_in;
+#pragma unroll
+        for (int j = 0; j < kBlk; ++j) {
+            run = c[j] < run ? c[j] : run;
+            c[j] = run;
+        }
+        int jstar = -1;
+        uint32_t m_before = run;  // no stop: the bound the search leaves the reach with
+#pragma unroll
+        for (int j = kBlk - 1; j >= 0; --j) {
+            const bool stop = c[j] == 0 || v[j] < xf;
+            jstar = stop ? j : jstar;
+            m_before = stop ? (j ? c[j - 1] : m_in) : m_before;
+        }
+        const bool inside = have && jstar >= 0;
+        // round C: the ranks of block Bs, nearest first: anchor = the rank just in front of the block
+        const int Bs = up ? b0 - jstar : b0 + jstar;
+        const int anchor = inside ? (up ? kBlk * Bs + kBlk : kBlk * Bs - 1) : li;
+        uint32_t m = m_before, pos = kNoPos;
+        const int st = lds_scan_round<kBlk>(s_sa, s_lcp, anchor, 0, greater, up, x, m, pos);
+        if (have) {
+            uint32_t out_len, out_pos = kNoPos;
+            if (inside && st == 1) {
+                out_len = m;
+                out_pos = pos;
+            } else if (inside && st == 0) {
+                out_len = 0;
+            } else {  // left the reach (st == 2 inside a stopping block cannot happen; it would be treated the same way)
+                out_len = far_mark(m_before, far_bit);
+            }
+            res_len[k * kLdsTile + t] = out_len;
+            if (k < NP) res_pos[k * kLdsTile + t] = out_pos;
+        }
+    }
+    if (phase_clock) phase_clock[2] = __builtin_readcyclecounter();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }

@@ -16,8 +16,11 @@
 //   selection  (:338-352)  forward wins ties; RC must beat the forward match, or 1 if none.
 // When the best forward neighbour does not overlap position i (the common case) L_f is an LCA
 // depth, hence explicit, and fwd = L_f directly; only overlapping positions take the exact path.
+#include <algorithm>
+
 #include "nearest_lds.hpp"
 #include "pipeline.hpp"
+#include "queues.hpp"
 #include "radix_sort.hpp"
 
 namespace nolzss {
@@ -32,89 +35,104 @@ __device__ __forceinline__ uint32_t rc_select(uint32_t fwd, uint32_t rc) {
 }
 
 // combine the forward neighbours (lp/jp above, ls/js below) and the reverse-complement length
-// into the factor code of position i, or queue i for the exact forward search
-// (*dst receives the code, or for queued positions a forward lower bound with P(bound) true)
-__device__ __forceinline__ void rc_decide(uint32_t i, uint32_t lp, uint32_t jp, uint32_t ls, uint32_t js,
-                                          uint32_t rc, uint32_t *__restrict__ dst,
-                                          uint32_t *__restrict__ queue, uint32_t *__restrict__ queue_rc,
-                                          uint32_t *__restrict__ queue_count) {
+// into the factor code of position i; returns true if i needs the exact forward search
+// (*dst then receives a forward lower bound with P(bound) true)
+__device__ __forceinline__ bool rc_decide(uint32_t i, uint32_t lp, uint32_t jp, uint32_t ls, uint32_t js,
+                                          uint32_t rc, uint32_t *__restrict__ dst) {
     const uint32_t M = lp > ls ? lp : ls;
     const bool fwd_final = (M == 0) || (lp == M && i - jp >= M) || (ls == M && i - js >= M);
     if (fwd_final) {
         *dst = rc_select(M, rc);
-        return;
+        return false;
     }
     uint32_t lo = 0;
     if (lp > 0) { const uint32_t c = lp < i - jp ? lp : i - jp; lo = c > lo ? c : lo; }
     if (ls > 0) { const uint32_t c = ls < i - js ? ls : i - js; lo = c > lo ? c : lo; }
     *dst = lo;  // provisional: P(lo) holds
-    const uint32_t k = atomicAdd(queue_count, 1u);
-    queue[k] = i;
-    queue_rc[k] = rc;
+    return true;
 }
 
 // LDS-tiled candidate search (nearest_lds.hpp): four searches per rank of the original strand
 __global__ __launch_bounds__(kLdsThreads) void rc_tile_kernel(const uint32_t *__restrict__ sa,
                                                               const uint32_t *__restrict__ lcp, uint32_t m,
                                                               uint32_t N, uint32_t *__restrict__ code_by_rank,
-                                                              uint32_t *__restrict__ queue,
-                                                              uint32_t *__restrict__ queue_rc,
-                                                              uint32_t *__restrict__ queue_count,
-                                                              uint32_t *__restrict__ far_queue,
-                                                              uint32_t *__restrict__ far_count) {
+                                                              ShardQueue exact_q, ShardQueue far_q) {
     constexpr int NS = 4, NP = 2;
-    __shared__ uint32_t s_sa[kLdsSpan];
-    __shared__ uint32_t s_lcp[kLdsSpan + 1];
+    __shared__ __align__(16) uint32_t s_sa[kLdsSpan];
+    __shared__ __align__(16) uint32_t s_lcp[kLdsSpan + 4];
     __shared__ uint32_t s_len[NS * kLdsTile];
     __shared__ uint32_t s_pos[NP * kLdsTile];
     __shared__ uint16_t s_list[kLdsWaves][2][NS * kLdsPerWave];
+    __shared__ uint32_t s_blk[4 * kNumBlk];
     const uint32_t base = blockIdx.x * (uint32_t)kLdsTile;
+    const uint32_t shard = blockIdx.x % kQShards;
     stage_tile(sa, lcp, m, base, s_sa, s_lcp);
+    __syncthreads();
+    const BlockTables T{s_blk, s_blk + kNumBlk, s_blk + 2 * kNumBlk, s_blk + 3 * kNumBlk};
+    build_block_tables<true>(s_sa, s_lcp, T);
     __syncthreads();
     const int w = threadIdx.x >> 6;
     const uint32_t far_bit = m <= 0x80000000u ? 0x80000000u : 0u;
-    lds_search_wave<NS, NP, 4>(s_sa, s_lcp, m, base, s_len, s_pos, s_list[w][0], s_list[w][1],
-                            [N](uint32_t i) { return i < N; }, [N](uint32_t i) { return 2u * N - i; }, far_bit);
-#pragma unroll 1
-    for (int row = 0; row < kLdsPerWave / 64; ++row) {
+    lds_search_wave_blocks<NS, NP>(s_sa, s_lcp, T, m, base, s_len, s_pos, s_list[w][0], s_list[w][1],
+                                   [N](uint32_t i) { return i < N; }, [N](uint32_t i) { return 2u * N - i; }, far_bit);
+    constexpr int kRows = kLdsPerWave / 64;
+    bool far[kRows], exact[kRows];
+    uint32_t mask[kRows], rcl[kRows], fslot[kRows], eslot[kRows];
+#pragma unroll
+    for (int row = 0; row < kRows; ++row) {
         const int t = w * kLdsPerWave + row * 64 + lane_id();
         const uint64_t rr = (uint64_t)base + t;
-        if (rr >= m) break;
         const uint32_t i = s_sa[t + kLdsReach];
+        far[row] = exact[row] = false;
+        mask[row] = rcl[row] = 0;
+        if (rr >= m) continue;
         if (i >= N) {  // only positions of the original strand are factorized (:241)
             code_by_rank[rr] = 0;
             continue;
         }
         uint32_t lp = s_len[t], ls = s_len[kLdsTile + t];
         uint32_t ru = s_len[2 * kLdsTile + t], rd = s_len[3 * kLdsTile + t];
+        // which of the four searches left the reach (they restart behind the ranks already cleared)
+        if (far_bit)
+            mask[row] = (far_is(lp, far_bit) ? 1u : 0u) | (far_is(ls, far_bit) ? 2u : 0u) | (far_is(ru, far_bit) ? 4u : 0u) |
+                        (far_is(rd, far_bit) ? 8u : 0u);
         // a search that left the reach matters only if its bound can beat the other direction
         // (reverse-complement lengths <= 1 can never be chosen)
         const bool far_f = far_resolve(lp, ls, far_bit, 0u);
         const bool far_r = far_resolve(ru, rd, far_bit, 1u);
-        if (far_f || far_r) {
-            far_queue[atomicAdd(far_count, 1u)] = (uint32_t)rr;  // finish from global memory
-            // which of the four searches left the reach (they restart behind the ranks already cleared)
-            uint32_t mask = 0;
-            if (far_bit)
-                mask = (far_is(lp, far_bit) ? 1u : 0u) | (far_is(ls, far_bit) ? 2u : 0u) | (far_is(ru, far_bit) ? 4u : 0u) |
-                       (far_is(rd, far_bit) ? 8u : 0u);
-            code_by_rank[rr] = mask;
-            continue;
+        far[row] = far_f || far_r;  // finished from global memory
+        if (!far[row]) {
+            rcl[row] = ru > rd ? ru : rd;
+            exact[row] = rc_decide(i, lp, s_pos[t], ls, s_pos[kLdsTile + t], rcl[row], code_by_rank + rr);
         }
-        rc_decide(i, lp, s_pos[t], ls, s_pos[kLdsTile + t], ru > rd ? ru : rd, code_by_rank + rr, queue, queue_rc,
-                  queue_count);
+    }
+    shard_slots<kRows>(far_q, shard, far, fslot);
+    shard_slots<kRows>(exact_q, shard, exact, eslot);
+#pragma unroll
+    for (int row = 0; row < kRows; ++row) {
+        const int t = w * kLdsPerWave + row * 64 + lane_id();
+        const uint64_t rr = (uint64_t)base + t;
+        if (far[row]) {
+            far_q.items[fslot[row]] = (uint32_t)rr;
+            code_by_rank[rr] = mask[row];
+        }
+        if (exact[row]) {
+            exact_q.items[eslot[row]] = s_sa[t + kLdsReach];
+            exact_q.items2[eslot[row]] = rcl[row];
+        }
     }
 }
 
-// ranks whose searches leave the LDS reach: pyramid searches from global memory
+// ranks whose searches leave the LDS reach: pyramid searches from global memory.  Grid (kQShards, Y).
 __global__ __launch_bounds__(kThreads) void rc_far_kernel(
-    const uint32_t *__restrict__ far_queue, uint32_t count, const uint32_t *__restrict__ sa,
-    const uint32_t *__restrict__ lcp, uint32_t m, uint32_t N, Pyramid Pmin, Pyramid Pmax, Pyramid Plcp,
-    const uint32_t *__restrict__ by_rank, uint32_t *__restrict__ code, uint32_t *__restrict__ queue,
-    uint32_t *__restrict__ queue_rc, uint32_t *__restrict__ queue_count) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < count; k += stride) {
-        const uint32_t r = far_queue[k];
+    ShardQueue far_q, const uint32_t *__restrict__ sa, const uint32_t *__restrict__ lcp, uint32_t m, uint32_t N,
+    Pyramid Pmin, Pyramid Pmax, Pyramid Plcp, const uint32_t *__restrict__ by_rank, uint32_t *__restrict__ code,
+    ShardQueue exact_q) {
+    const uint32_t shard = blockIdx.x;
+    const uint32_t count = far_q.counts[shard * kQPad];
+    const uint32_t *items = far_q.items + (size_t)shard * far_q.cap;
+    for (uint32_t k = blockIdx.y * blockDim.x + threadIdx.x; k < count; k += gridDim.y * blockDim.x) {
+        const uint32_t r = items[k];
         const uint32_t i = sa[r];
         const uint32_t mask = by_rank[r];  // searches that left the tile's reach (0: unknown, search all from r)
         // forward: earlier suffixes, SA[q] < i
@@ -138,18 +156,25 @@ __global__ __launch_bounds__(kThreads) void rc_far_kernel(
             far_down<true>(sa, m, Pmax, Plcp, r, thr, ru > 2u ? ru : 2u, rd, unused);
         else
             nearest_down<true>(sa, lcp, m, Pmax, Plcp, r, thr, ru > 2u ? ru : 2u, rd, unused);
-        rc_decide(i, lp, jp, ls, js, ru > rd ? ru : rd, code + i, queue, queue_rc, queue_count);
+        const uint32_t rc = ru > rd ? ru : rd;
+        const bool exact = rc_decide(i, lp, jp, ls, js, rc, code + i);
+        const uint32_t eslot = shard_slot(exact_q, shard, exact);  // (a rank reaches the exact queue at most once)
+        if (exact) {
+            exact_q.items[eslot] = i;
+            exact_q.items2[eslot] = rc;
+        }
     }
 }
 
-__global__ __launch_bounds__(kThreads) void rc_fallback_kernel(const uint32_t *__restrict__ queue,
-                                                               const uint32_t *__restrict__ queue_rc,
-                                                               uint32_t count, uint32_t m,
+__global__ __launch_bounds__(kThreads) void rc_fallback_kernel(ShardQueue exact_q, uint32_t m,
                                                                const uint32_t *__restrict__ isa,
                                                                const uint32_t *__restrict__ lcp, Pyramid Pmin,
                                                                Pyramid Plcp, uint32_t *__restrict__ code) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < count; k += stride) {
+    const uint32_t shard = blockIdx.x;
+    const uint32_t count = exact_q.counts[shard * kQPad];
+    const uint32_t *queue = exact_q.items + (size_t)shard * exact_q.cap;
+    const uint32_t *queue_rc = exact_q.items2 + (size_t)shard * exact_q.cap;
+    for (uint32_t k = blockIdx.y * blockDim.x + threadIdx.x; k < count; k += gridDim.y * blockDim.x) {
         const uint32_t i = queue[k];
         const uint32_t r = isa[i] - 1u;  // (1-based, pipeline.hpp)
         const uint32_t cap = (m - i) < i ? (m - i) : i;
@@ -279,18 +304,32 @@ uint32_t run_rc_pipeline_packed(Context &ctx, const PackedText &text, size_t sta
     uint32_t *code = arena.alloc<uint32_t>(m);
     {
         const size_t mark = arena.mark();
-        uint32_t *queue = arena.alloc<uint32_t>(N);
-        uint32_t *queue_rc = arena.alloc<uint32_t>(N);
-        uint32_t *far_queue = arena.alloc<uint32_t>(N);
-        uint32_t *counts = arena.alloc<uint32_t>(2);  // [0] exact-search queue, [1] far queue
+        const unsigned tiles = (unsigned)div_up(m, kLdsTile);
+        ShardQueue exact_q, far_q;
+        exact_q.cap = far_q.cap = (uint32_t)shard_queue_cap(tiles, kLdsTile);
+        exact_q.items = arena.alloc<uint32_t>((size_t)kQShards * exact_q.cap);
+        exact_q.items2 = arena.alloc<uint32_t>((size_t)kQShards * exact_q.cap);
+        far_q.items = arena.alloc<uint32_t>((size_t)kQShards * far_q.cap);
+        uint32_t *qcounts = arena.alloc<uint32_t>(2 * kQShards * kQPad);
+        exact_q.counts = qcounts;
+        far_q.counts = qcounts + kQShards * kQPad;
+        const uint32_t **count_ptrs = arena.alloc<const uint32_t *>(2);
+        uint32_t *totals = arena.alloc<uint32_t>(2);  // [0] exact-search queue, [1] far queue
         uint32_t *by_rank = arena.alloc<uint32_t>(m);
         uint32_t *scratch_idx = arena.alloc<uint32_t>(m);
         uint32_t *scratch_val = arena.alloc<uint32_t>(m);
-        HIP_CHECK(hipMemsetAsync(counts, 0, 2 * sizeof(uint32_t), s));
+        HIP_CHECK(hipMemsetAsync(qcounts, 0, 2 * kQShards * kQPad * sizeof(uint32_t), s));
+        const uint32_t *h_ptrs[2] = {exact_q.counts, far_q.counts};
+        HIP_CHECK(hipMemcpyAsync(count_ptrs, h_ptrs, sizeof h_ptrs, hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipStreamSynchronize(s));  // h_ptrs is a local array
+        auto read_totals = [&](uint32_t h[2]) {
+            shard_totals_kernel<<<2, kQShards, 0, s>>>(count_ptrs, 2, totals);
+            KERNEL_CHECK();
+            ctx.read_back(totals, h, 2);
+        };
         {
             ProfScope ps(ctx.profiler(), "rc_candidates", s);
-            rc_tile_kernel<<<(unsigned)div_up(m, kLdsTile), kLdsThreads, 0, s>>>(sa, lcp, m, N, by_rank, queue,
-                                                                             queue_rc, counts, far_queue, counts + 1);
+            rc_tile_kernel<<<tiles, kLdsThreads, 0, s>>>(sa, lcp, m, N, by_rank, exact_q, far_q);
             KERNEL_CHECK();
         }
         {
@@ -300,21 +339,18 @@ uint32_t run_rc_pipeline_packed(Context &ctx, const PackedText &text, size_t sta
             bucketed_scatter(idx, val, m, code, m, arena, s, ctx.profiler(), true);
         }
         uint32_t h[2] = {0, 0};
-        ctx.read_back(counts, h, 2);
+        read_totals(h);
         if (h[1] > 0) {
             ProfScope ps(ctx.profiler(), "rc_far", s);
-            size_t g = div_up(h[1], kThreads);
-            if (g > 256u * 32u) g = 256u * 32u;
-            rc_far_kernel<<<(unsigned)g, kThreads, 0, s>>>(far_queue, h[1], sa, lcp, m, N, Pmin, Pmax, Plcp, by_rank,
-                                                           code, queue, queue_rc, counts);
+            const unsigned gy = (unsigned)std::min<size_t>(64, std::max<size_t>(1, div_up(h[1], (size_t)kQShards * kThreads)));
+            rc_far_kernel<<<dim3(kQShards, gy), kThreads, 0, s>>>(far_q, sa, lcp, m, N, Pmin, Pmax, Plcp, by_rank, code, exact_q);
             KERNEL_CHECK();
-            ctx.read_back(counts, h, 1);
+            read_totals(h);
         }
         if (h[0] > 0) {
             ProfScope ps(ctx.profiler(), "rc_fallback", s);
-            size_t g = div_up(h[0], kThreads);
-            if (g > 256u * 32u) g = 256u * 32u;
-            rc_fallback_kernel<<<(unsigned)g, kThreads, 0, s>>>(queue, queue_rc, h[0], m, isa, lcp, Pmin, Plcp, code);
+            const unsigned gy = (unsigned)std::min<size_t>(64, std::max<size_t>(1, div_up(h[0], (size_t)kQShards * kThreads)));
+            rc_fallback_kernel<<<dim3(kQShards, gy), kThreads, 0, s>>>(exact_q, m, isa, lcp, Pmin, Plcp, code);
             KERNEL_CHECK();
         }
         arena.rewind(mark);
