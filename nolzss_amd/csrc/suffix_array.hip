@@ -251,8 +251,16 @@ struct MaxSum {
 __device__ __forceinline__ uint64_t pack_desc(uint32_t status, MaxSum v) {
     return ((uint64_t)status << 62) | ((uint64_t)v.mx << 31) | (uint64_t)v.sum;
 }
+#ifndef NOLZSS_LOOKBACK_WINDOWS
+#define NOLZSS_LOOKBACK_WINDOWS 1
+#endif
 __device__ __forceinline__ MaxSum lookback_exclusive_packed(uint64_t *desc, uint32_t tile, MaxSum aggregate,
                                                             uint32_t *err) {
+    // kWin windows of 64 descriptors are loaded per round trip and evaluated nearest first.  (Measured with
+    // NOLZSS_REGROUP_PHASES at 2^30: a tile spends 27 k cycles on loads and heads, 15 k in this walk, 6 k on
+    // its output; four windows per round trip did not shorten the walk -- it waits for the slowest of the
+    // tiles in front to publish, not for the number of descriptors -- so one window stays the default.)
+    constexpr int kWin = NOLZSS_LOOKBACK_WINDOWS;
     const int lane = lane_id();
     MaxSum excl{0u, 0u};
     if (tile == 0) {
@@ -261,31 +269,44 @@ __device__ __forceinline__ MaxSum lookback_exclusive_packed(uint64_t *desc, uint
     }
     if (lane == 0) desc_store(desc + tile, pack_desc(1u, aggregate));
     int64_t look = (int64_t)tile - 1;
+    uint32_t spins = 0;
     for (;;) {
-        const int64_t idx = look - lane;
-        uint64_t d, need, inc;
-        uint32_t spins = 0;
-        for (;;) {
-            d = idx >= 0 ? desc_load(desc + idx) : (2ull << 62);  // in front of tile 0: inclusive identity
-            const uint32_t st = (uint32_t)(d >> 62);
-            inc = __ballot(st == 2);
-            need = inc ? (((inc & (~inc + 1ull)) << 1) - 1ull) : ~0ull;
+        uint64_t d[kWin];
+#pragma unroll
+        for (int j = 0; j < kWin; ++j) {
+            const int64_t idx = look - 64 * j - lane;
+            d[j] = idx >= 0 ? desc_load(desc + idx) : (2ull << 62);  // in front of tile 0: inclusive identity
+        }
+        bool done = false, stalled = false;
+#pragma unroll
+        for (int j = 0; j < kWin; ++j) {
+            if (done || stalled) continue;  // (wave-uniform)
+            const uint32_t st = (uint32_t)(d[j] >> 62);
+            const uint64_t inc = __ballot(st == 2);
+            // every lane up to and including the first inclusive one must have been published
+            const uint64_t need = inc ? (((inc & (~inc + 1ull)) << 1) - 1ull) : ~0ull;
             const uint64_t missing = __ballot(st == 0) & need;
-            if (!missing) break;
+            if (missing) {  // not published yet: wait and read again from this window on
+                stalled = true;
+                continue;
+            }
+            const bool use = (need >> lane) & 1ull;
+            const uint32_t vm = use ? (uint32_t)(d[j] >> 31) & 0x7fffffffu : 0u;
+            const uint32_t vs = use ? (uint32_t)d[j] & 0x7fffffffu : 0u;
+            const uint32_t wm = wave_reduce(vm, OpMax<uint32_t>());
+            excl.mx = wm > excl.mx ? wm : excl.mx;
+            excl.sum += wave_reduce(vs, OpAdd<uint32_t>());
+            look -= 64;
+            if (inc) done = true;  // an inclusive prefix was reached
+        }
+        if (done) break;
+        if (stalled) {
             if (++spins > kSpinLimit) {  // cannot happen with ticket order; never hang the GPU
                 if (lane == 0) atomicExch(err, 1u);
                 return excl;
             }
             __builtin_amdgcn_s_sleep(1);
         }
-        const bool use = (need >> lane) & 1ull;
-        const uint32_t vm = use ? (uint32_t)(d >> 31) & 0x7fffffffu : 0u;
-        const uint32_t vs = use ? (uint32_t)d & 0x7fffffffu : 0u;
-        const uint32_t wm = wave_reduce(vm, OpMax<uint32_t>());
-        excl.mx = wm > excl.mx ? wm : excl.mx;
-        excl.sum += wave_reduce(vs, OpAdd<uint32_t>());
-        if (inc) break;  // an inclusive prefix was reached
-        look -= 64;
     }
     if (lane == 0) {
         MaxSum incl{excl.mx > aggregate.mx ? excl.mx : aggregate.mx, excl.sum + aggregate.sum};
@@ -322,6 +343,7 @@ struct RegroupArgs {
     int packed;               // both scans share the descriptors in desc_max (n < 2^31)
     uint32_t *ticket;         // [0] tile tickets, [1] error flag
     uint32_t *d_total;        // number of elements that stay active
+    unsigned long long *phases;  // (diagnostics, NOLZSS_REGROUP_PHASES) cycles per phase, summed over sampled tiles
 };
 
 // value of the previous / next lane of the wavefront (lane 0 / lane 63 keep `edge`)
@@ -339,8 +361,12 @@ __global__ __launch_bounds__(kFuseThreads) void regroup_kernel(RegroupArgs A) {
     __shared__ uint32_t s_tile;
     __shared__ uint32_t s_seg_max[kSegs], s_seg_sum[kSegs];  // per segment: last head slot, kept; then prefixes
     __shared__ uint32_t s_excl[2];
+    const bool timed = A.phases != nullptr && (blockIdx.x & 15) == 0 && threadIdx.x == 0;
+    unsigned long long clk[5] = {0, 0, 0, 0, 0};
+    if (timed) clk[0] = __builtin_readcyclecounter();
     if (threadIdx.x == 0) s_tile = atomicAdd(A.ticket, 1u);  // (blockIdx order measured 5 % faster, not guaranteed)
     __syncthreads();
+    if (timed) clk[1] = __builtin_readcyclecounter();
     const uint32_t tile = s_tile;
     const uint32_t m = A.m;
     static_assert(kFuseTile == kSortTile, "the regroup tiles are the tiles of the segmented sort");
@@ -447,6 +473,7 @@ __global__ __launch_bounds__(kFuseThreads) void regroup_kernel(RegroupArgs A) {
         }
     }
     __syncthreads();
+    if (timed) clk[2] = __builtin_readcyclecounter();
     if (w == 0) {  // prefixes over the segments, then over the tiles in front
         static_assert(kSegs <= 64, "one lane per segment");
         const uint32_t vmax = lane < kSegs ? s_seg_max[lane] : 0u;
@@ -476,6 +503,7 @@ __global__ __launch_bounds__(kFuseThreads) void regroup_kernel(RegroupArgs A) {
         }
     }
     __syncthreads();
+    if (timed) clk[3] = __builtin_readcyclecounter();
     const uint32_t xmax = s_excl[0], xsum = s_excl[1];
 
     // slot of my group head: the last head at or in front of me
@@ -544,6 +572,12 @@ __global__ __launch_bounds__(kFuseThreads) void regroup_kernel(RegroupArgs A) {
             A.new_slot[kk] = slot[k];
             A.new_grp[kk] = head_of;
         }
+    }
+    if (timed) {
+        __builtin_amdgcn_s_waitcnt(0);
+        clk[4] = __builtin_readcyclecounter();
+        for (int k = 0; k < 4; ++k) atomicAdd(A.phases + k, clk[k + 1] - clk[k]);
+        atomicAdd(A.phases + 4, 1ull);
     }
 }
 
@@ -783,8 +817,11 @@ __global__ __launch_bounds__(kThreads) void small_sort_kernel(const uint32_t *__
         const size_t g0 = a - (act_slot[a] - g);  // list index of the group's first member
         const uint32_t mine = lo[a];
         uint32_t below = 0, cnt = 0;
-        bool large = false;
-        for (size_t b = g0; b < m; ++b) {
+        // a member of a large group sees that in one look (the group's members are contiguous in the list):
+        // on periodic texts every suffix sits in one of a few huge groups for twenty rounds, and counting
+        // to kSmallGroup + 1 from the group's head in every round cost as much as the radix sort beside it
+        bool large = g0 + kSmallGroup < m && act_grp[g0 + kSmallGroup] == g;
+        for (size_t b = g0; !large && b < m; ++b) {
             if (act_grp[b] != g) break;
             if (++cnt > kSmallGroup) {
                 large = true;
@@ -1130,8 +1167,21 @@ uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *grp, const 
         A.packed = n < 0x80000000u ? 1 : 0;  // slots and counts fit 31 bits
         A.ticket = reinterpret_cast<uint32_t *>(desc + 2 * tiles);
         A.d_total = d_total;
+        static const bool want_phases = getenv("NOLZSS_REGROUP_PHASES") != nullptr;
+        if (want_phases) {
+            A.phases = ctx.arena.alloc<unsigned long long>(8);
+            HIP_CHECK(hipMemsetAsync(A.phases, 0, 64, s));
+        }
         regroup_kernel<kRound0><<<(unsigned)tiles, kFuseThreads, 0, s>>>(A);
         KERNEL_CHECK();
+        if (want_phases) {
+            unsigned long long h[8];
+            HIP_CHECK(hipMemcpyAsync(h, A.phases, 64, hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+            const double wn = h[4] ? (double)h[4] : 1.0;
+            fprintf(stderr, "[nolzss] regroup<%d> m=%u tiles=%zu phases (cycles per tile, %llu sampled): ticket %.0f  loads+heads %.0f  look-back %.0f  output %.0f\n",
+                    (int)kRound0, m, tiles, h[4], h[0] / wn, h[1] / wn, h[2] / wn, h[3] / wn);
+        }
         HIP_CHECK(hipMemcpyAsync(d_total + 1, A.ticket + 1, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
     }
     ctx.arena.rewind(pmark);
