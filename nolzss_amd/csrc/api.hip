@@ -49,8 +49,16 @@ std::map<int, std::unique_ptr<DeviceContext>> g_ctx;
 
 constexpr size_t kMaxText = 0xffffffffull - (1ull << 19);  // 32-bit index pipeline (sharded queue slots stay below 2^32)
 
-constexpr size_t kArenaBytesPerSymbol = 108;
-size_t arena_bytes_for(size_t n) { return kArenaBytesPerSymbol * n + (size_t(64) << 20); }
+// Device memory per text symbol.  The pipeline peaks at 49 bytes per symbol (candidate
+// stage) unless many suffixes are still tied after the direct round: the rounds that resolve those take 60
+// bytes per tied suffix on top of 32 per symbol -- 96 when EVERY suffix is tied (a periodic text).  The arena
+// asks for the worst case when the device has it and settles for what is there down to kArenaMinPerSymbol;
+// a text that then needs more fails in the suffix-array rounds with a message that says so.
+constexpr size_t kArenaBytesPerSymbol = 96;
+constexpr size_t kArenaMinPerSymbol = 52;
+constexpr size_t kArenaSlack = size_t(64) << 20;
+size_t arena_bytes_for(size_t n) { return kArenaBytesPerSymbol * n + kArenaSlack; }
+size_t arena_min_bytes_for(size_t n) { return kArenaMinPerSymbol * n + kArenaSlack; }
 
 constexpr int kMaxLanes = 16;  // concurrent pipelines (stream + arena each) per device
 
@@ -106,30 +114,46 @@ size_t trim_idle_arenas(int device, const Context *keep) {
     return released;
 }
 
-void reserve_arena(Context &ctx, size_t bytes) {
-    if (bytes <= ctx.arena.capacity()) return;
-    {
-        // An input that cannot fit is refused up front, with the sizes, as an argument error (ValueError in
-        // Python) instead of failing late with a device out-of-memory error.
+// The arena for a text of n symbols plus `extra` bytes (uploads): the worst-case size if the device has
+// it, else as much as there is, but never less than the minimum the pipeline needs on ordinary texts --
+// below that the input is refused up front, with the sizes, as an argument error (ValueError in Python)
+// instead of failing late with a device out-of-memory error.
+void reserve_arena_for(Context &ctx, size_t n, size_t extra = 0) {
+    const size_t want = arena_bytes_for(n) + extra, least = arena_min_bytes_for(n) + extra;
+    if (want <= ctx.arena.capacity()) return;
+    auto available = [&]() -> size_t {  // what a fresh reservation could get: free memory + the slab it replaces
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && bytes > total_b) {
-            char buf[256];
-            snprintf(buf, sizeof buf,
-                     "input too large for this device: the pipeline needs %.1f GiB of device memory, the device has %.1f GiB "
-                     "(one MI355X takes about %.1f Gi symbols in plain mode, half of that with reverse complement)",
-                     (double)bytes / 1073741824.0, (double)total_b / 1073741824.0,
-                     (double)total_b / (double)kArenaBytesPerSymbol / 1073741824.0);
-            throw std::invalid_argument(buf);
-        }
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return ~size_t(0);
+        return (size_t)((double)(free_b + ctx.arena.capacity()) * 0.97);
+    };
+    size_t avail = available();
+    if (avail < want) {
+        trim_idle_arenas(ctx.device, &ctx);
+        avail = available();
     }
+    if (avail < least) {
+        if (least <= ctx.arena.capacity()) return;  // (what is reserved already will have to do)
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        char buf[320];
+        snprintf(buf, sizeof buf,
+                 "input too large for this device: a text of %zu symbols needs at least %.1f GiB of device memory "
+                 "(%zu bytes per symbol), %.1f GiB are free of %.1f GiB (one MI355X takes about %.1f Gi symbols in plain "
+                 "mode, half of that with reverse complement)",
+                 n, (double)least / 1073741824.0, kArenaMinPerSymbol, (double)free_b / 1073741824.0,
+                 (double)total_b / 1073741824.0, (double)total_b * 0.97 / (double)kArenaMinPerSymbol / 1073741824.0);
+        throw std::invalid_argument(buf);
+    }
+    const size_t take = want <= avail ? want : avail;
+    if (take <= ctx.arena.capacity()) return;
     try {
-        ctx.arena.reserve(bytes);
+        ctx.arena.reserve(take);
         return;
     } catch (const HipError &) {
         (void)hipGetLastError();
     }
     trim_idle_arenas(ctx.device, &ctx);
-    ctx.arena.reserve(bytes);
+    ctx.arena.reserve(least > ctx.arena.capacity() ? least : ctx.arena.capacity());
 }
 
 struct DebugOut {
@@ -203,7 +227,7 @@ size_t run_plain_host(Context &ctx, const uint8_t *text, size_t n, size_t start_
                       DebugOut *dbg) {
     if (out) *out = nullptr;
     if (n == 0 || start_pos >= n) return 0;
-    reserve_arena(ctx, arena_bytes_for(n) + n);
+    reserve_arena_for(ctx, n, n);
     const size_t mark = ctx.arena.mark();
     uint8_t *d_text = ctx.arena.alloc<uint8_t>(n);
     {
@@ -452,7 +476,7 @@ size_t run_rc_host(Context &ctx, const uint8_t *S, size_t m, size_t start_pos, n
     if (out) *out = nullptr;
     if (m > kMaxText) throw std::invalid_argument("text too long: the device pipeline uses 32-bit indices");
     if (!rc_guards(m, start_pos)) return 0;
-    reserve_arena(ctx, arena_bytes_for(m) + m);
+    reserve_arena_for(ctx, m, m);
     const size_t mark = ctx.arena.mark();
     size_t z = 0;
     try {
@@ -570,7 +594,7 @@ int nolzss_factorize_device(const void *d_text, size_t n, size_t start_pos, int 
             (void)hipEventDestroy(ev);
             HIP_CHECK(e);
         }
-        reserve_arena(ses.ctx(), arena_bytes_for(n));
+        reserve_arena_for(ses.ctx(), n);
         *z = run_plain(ses.ctx(), static_cast<const uint8_t *>(d_text), n, start_pos,
                        emit == 2 ? out_host : nullptr, nullptr, emit == 1);
     });
@@ -645,7 +669,7 @@ static void dna_w_rc_common(const uint8_t *text, size_t n, int device, nolzss_fa
     if (!rc_guards(m, 0)) return;
     Session ses(device, nullptr, lane);
     Context &ctx = ses.ctx();
-    reserve_arena(ctx, arena_bytes_for(m) + m + n);
+    reserve_arena_for(ctx, m, m + n);
     uint8_t *d_T = ctx.arena.alloc<uint8_t>(n);
     uint8_t *d_S = ctx.arena.alloc<uint8_t>(m);
     HIP_CHECK(hipMemcpyAsync(d_T, text, n, hipMemcpyHostToDevice, ctx.stream));
@@ -1437,7 +1461,7 @@ bool run_merged_chunk(Context &ctx, const uint8_t *const *texts, const size_t *l
     Arena &arena = ctx.arena;
     hipStream_t s = ctx.stream;
     const size_t m2 = 2 * n + 2;  // with_rc: T' sep revcomp(T') sep
-    reserve_arena(ctx, (with_rc ? arena_bytes_for(m2) + m2 : arena_bytes_for(n)) + n + 32 * c + (size_t(1) << 20));
+    reserve_arena_for(ctx, with_rc ? m2 : n, (with_rc ? m2 : 0) + n + 32 * c + (size_t(1) << 20));
     const size_t mark = arena.mark();
     struct Rewind {
         Arena &a;
@@ -1764,7 +1788,7 @@ int nolzss_factorize_batch_device(const void *const *d_texts, const size_t *lens
                     const size_t k = next.fetch_add(1);
                     if (k >= m) break;
                     const size_t j = order[k];
-                    reserve_arena(ses.ctx(), arena_bytes_for(lens[j]));
+                    reserve_arena_for(ses.ctx(), lens[j]);
                     z[j] = run_plain(ses.ctx(), static_cast<const uint8_t *>(d_texts[j]), lens[j], 0, nullptr, nullptr,
                                      emit == 1);
                 }

@@ -123,35 +123,49 @@ __device__ inline void lcp_interval(const Pyramid &Plcp, uint32_t r, uint32_t d,
     hi = pyr_nearest_right<false>(Plcp, r + 1, d) - 1;
 }
 
-// P(d): min SA[I(d)] + d <= i   (monotone: true for d implies true for d - 1)
-__device__ __forceinline__ bool lpnf_pred(const Pyramid &Psa, const Pyramid &Plcp, uint32_t r, uint32_t i,
-                                          uint32_t d) {
+// g(d) = min SA[I(d)]: the leftmost occurrence of the d symbols at position i (r = its rank); g never
+// decreases as d grows.  P(d): g(d) + d <= i   (monotone: true for d implies true for d - 1)
+__device__ __forceinline__ uint32_t lpnf_leftmost(const Pyramid &Psa, const Pyramid &Plcp, uint32_t r, uint32_t d) {
     uint32_t lo, hi;
     lcp_interval(Plcp, r, d, lo, hi);
-    return (uint64_t)pyr_range<false>(Psa, lo, hi) + d <= i;
+    return pyr_range<false>(Psa, lo, hi);
+}
+__device__ __forceinline__ bool lpnf_pred(const Pyramid &Psa, const Pyramid &Plcp, uint32_t r, uint32_t i,
+                                          uint32_t d) {
+    return (uint64_t)lpnf_leftmost(Psa, Plcp, r, d) + d <= i;
 }
 
-// max{ d in [lo, cap] : P(d) } given that P(lo) holds: gallop up, then bisect.
+// max{ d in [lo, cap] : P(d) } given that P(lo) holds.
+// Every evaluation with P(d) true also bounds the answer from above: L* >= d implies g(L*) >= g(d), hence
+// L* <= i - g(d).  Where the search is needed at all -- the best earlier match overlaps position i, i.e. the
+// text is periodic around i -- the leftmost occurrence is the same for a long range of d (the start of the
+// periodic run), so the bound i - g(lo) is usually the answer itself and the SECOND evaluation confirms it;
+// galloping up from lo and bisecting took 2 * log2(L*) evaluations (50 on a long run, each two descents of
+// the LCP pyramid and a range minimum of the SA pyramid from global memory).
 __device__ inline uint32_t lpnf_search(const Pyramid &Psa, const Pyramid &Plcp, uint32_t r, uint32_t i,
                                        uint32_t lo, uint32_t cap) {
-    uint32_t hi = cap, step = 1;
-    while (lo < hi) {
-        uint32_t d = lo + step;
-        if (d > hi || d < lo) d = hi;
-        if (lpnf_pred(Psa, Plcp, r, i, d)) {
-            lo = d;
-            step <<= 1;
-        } else {
-            hi = d - 1;
-            break;
-        }
+    uint32_t hi = cap;
+    if (lo >= hi) return lo;
+    {
+        const uint32_t g = lpnf_leftmost(Psa, Plcp, r, lo < 1u ? 1u : lo);  // (I(0) is everything; lo = 0 only bounds from below)
+        const uint32_t bound = i - g;  // g <= i: P(lo) holds (for lo = 0: the occurrence at i itself is in I(1))
+        hi = bound < hi ? bound : hi;
     }
     while (lo < hi) {
+        // the upper end first: true there ends the search
+        const uint32_t gh = lpnf_leftmost(Psa, Plcp, r, hi);
+        if ((uint64_t)gh + hi <= i) return hi;
+        --hi;
+        if (lo >= hi) break;
         const uint32_t mid = lo + (hi - lo + 1) / 2;
-        if (lpnf_pred(Psa, Plcp, r, i, mid))
+        const uint32_t gm = lpnf_leftmost(Psa, Plcp, r, mid);
+        if ((uint64_t)gm + mid <= i) {
             lo = mid;
-        else
+            const uint32_t bound = i - gm;
+            hi = bound < hi ? bound : hi;
+        } else {
             hi = mid - 1;
+        }
     }
     return lo;
 }

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(kThreads) void rs_hist_kernel(Src src, size_t n, in
     // XCD-contiguous tile ranges, as in the scatter kernel: the table is bin-major, so the 256 counts of a
     // tile go to 256 different lines, each shared with the 15 neighbouring tiles -- written from one XCD
     // those 4-byte writes merge in its L2; dealt round-robin over the XCDs every one of them reached HBM
-    // as a partial line (67 M of them per pass at 2^30 keys).
+    // as a partial line (67 M of them per pass at 2^30 keys): 11.7 -> 8.6 ms per step for all histograms.
     const uint32_t tile = xcd_tile(blockIdx.x, num_tiles);
     if (tile == 0xffffffffu) return;
     __syncthreads();
@@ -150,44 +150,39 @@ __global__ __launch_bounds__(kThreads) void rs_hist_kernel(Src src, size_t n, in
     tile_hist[ext.hist0 + (size_t)threadIdx.x * ext.hstride] = c4.x + c4.y + c4.z + c4.w;
 }
 
-// kST threads per workgroup (256 or 512) share the 4096-key tile: 16 or 8 keys per thread.  With 8 the
-// kernel needs ~half the registers (139 VGPRs at 16 keys per thread allow 3 waves per SIMD = 12 per CU;
-// the LDS of a tile would allow 16) and twice the wavefronts hide the latency of the tile's loads.
-template <typename KeyT, typename OutT, typename Src, int kST>
-__global__ __launch_bounds__(kST) void rs_scatter_kernel(
+template <typename KeyT, typename OutT, typename Src>
+__global__ __launch_bounds__(kThreads) void rs_scatter_kernel(
     Src src, OutT *__restrict__ keys_out, uint32_t *__restrict__ vals_out, size_t n, int shift,
     const uint32_t *__restrict__ tile_base, uint32_t num_tiles, SegView seg) {
-    constexpr int kSW = kST / 64;          // wavefronts
-    constexpr int kKPT = kTile / kST;      // keys per thread
-    constexpr int kSpan = 64 * kKPT;       // keys per wavefront, kKPT rows of 64
-    static_assert(kST >= kBins && kTile % kST == 0 && kSpan <= 2048, "one thread per bin; 11-bit wave-local counters");
     const uint32_t tile = xcd_tile(blockIdx.x, num_tiles);
     if (tile == 0xffffffffu) return;
     const TileExtent ext = tile_extent(tile, n, num_tiles, seg);
-    __shared__ KeyT s_keys[kTile];      // the tile sorted by digit: keys ...
-    __shared__ uint32_t s_vals[kTile];  // ... and values (separate buffers: no write positions held in registers)
-    __shared__ uint32_t s_whist[kSW * kBins];
+    __shared__ uint64_t s_stage[kTile];  // keys, then values, take turns here
+    KeyT *s_keys = reinterpret_cast<KeyT *>(s_stage);
+    uint32_t *s_vals = reinterpret_cast<uint32_t *>(s_stage);
+    __shared__ uint32_t s_whist[kWaves * kBins];
     __shared__ uint32_t s_glob[kBins];
-    __shared__ uint32_t s_scan[kSW];
+    __shared__ uint32_t s_scan[kWaves];
 
     const int tid = threadIdx.x;
     const int w = tid >> 6;
     const int lane = tid & 63;
 
-    for (int k = tid; k < kSW * kBins; k += kST) s_whist[k] = 0;
+#pragma unroll
+    for (int k = 0; k < kWaves; ++k) s_whist[k * kBins + tid] = 0;
     __syncthreads();
 
     const size_t base = ext.first;
-    KeyT key[kKPT];
-    uint32_t val[kKPT];
-    uint32_t lrank[kKPT];
+    KeyT key[kKeysPerThread];
+    uint32_t val[kKeysPerThread];
+    uint32_t lrank[kKeysPerThread];
 
     // all loads of the tile go out before anything is ranked (the ranking below goes through
     // volatile LDS counters, which the compiler will not move loads across: interleaved, every row
     // would wait for its own round trip to HBM)
 #pragma unroll
-    for (int row = 0; row < kKPT; ++row) {
-        const uint32_t local = (uint32_t)w * kSpan + (uint32_t)row * 64 + lane;
+    for (int row = 0; row < kKeysPerThread; ++row) {
+        const uint32_t local = (uint32_t)w * kWaveSpan + (uint32_t)row * 64 + lane;
         const bool valid = local < ext.count;
         key[row] = valid ? src.key(base + local) : KeyT(0);
         val[row] = valid ? src.val(base + local) : 0;
@@ -201,8 +196,8 @@ __global__ __launch_bounds__(kST) void rs_scatter_kernel(
     // <= 1024 keys per wave) | lanes of my group below me << 11 | lane of the first member << 17
     uint32_t *wcount = s_whist + w * kBins;
 #pragma unroll
-    for (int row = 0; row < kKPT; ++row) {
-        const bool valid = (uint32_t)w * kSpan + (uint32_t)row * 64 + lane < ext.count;
+    for (int row = 0; row < kKeysPerThread; ++row) {
+        const bool valid = (uint32_t)w * kWaveSpan + (uint32_t)row * 64 + lane < ext.count;
         const uint32_t d = digit_of(key[row], shift);
         // lanes with the same digit: the complement of the lanes that differ in some bit.  Per bit,
         // m = 0 / ~0 (bit clear / set, one v_bfe_i32), and (ballot ^ m) is the set of lanes whose bit
@@ -222,7 +217,7 @@ __global__ __launch_bounds__(kST) void rs_scatter_kernel(
         lrank[row] = seen | ((uint32_t)__popcll(below) << 11) | ((uint32_t)(peers ? __builtin_ctzll(peers) : 0) << 17);
     }
 #pragma unroll
-    for (int row = 0; row < kKPT; ++row) {
+    for (int row = 0; row < kKeysPerThread; ++row) {
         const uint32_t packed = lrank[row];
         lrank[row] = ((uint32_t)__shfl((int)packed, (int)(packed >> 17), 64) & 0x7ffu) + ((packed >> 11) & 63u);
     }
@@ -230,54 +225,59 @@ __global__ __launch_bounds__(kST) void rs_scatter_kernel(
 
     // thread = bin: turn per-wave counts into tile-local start positions
     {
-        const int d = tid & (kBins - 1);
-        const bool bin_thread = tid < kBins;
-        uint32_t c[kSW], total = 0;
+        const int d = tid;
+        uint32_t c[kWaves], total = 0;
 #pragma unroll
-        for (int k = 0; k < kSW; ++k) {
-            c[k] = bin_thread ? s_whist[k * kBins + d] : 0u;
+        for (int k = 0; k < kWaves; ++k) {
+            c[k] = s_whist[k * kBins + d];
             total += c[k];
         }
         uint32_t tile_total;
-        const uint32_t bin_start = block_scan_exclusive<kSW>(total, OpAdd<uint32_t>(), s_scan, tile_total);
-        if (bin_thread) {
-            uint32_t run = bin_start;
+        const uint32_t bin_start = block_scan_exclusive<kWaves>(total, OpAdd<uint32_t>(), s_scan, tile_total);
+        uint32_t run = bin_start;
 #pragma unroll
-            for (int k = 0; k < kSW; ++k) {
-                s_whist[k * kBins + d] = run;
-                run += c[k];
-            }
-            s_glob[d] = tile_base[ext.hist0 + (size_t)d * ext.hstride] - bin_start;
+        for (int k = 0; k < kWaves; ++k) {
+            s_whist[k * kBins + d] = run;
+            run += c[k];
         }
+        s_glob[d] = tile_base[ext.hist0 + (size_t)d * ext.hstride] - bin_start;
     }
     __syncthreads();
 
     // tile-local sorted position of every element (reuses lrank)
 #pragma unroll
-    for (int row = 0; row < kKPT; ++row) {
+    for (int row = 0; row < kKeysPerThread; ++row) {
         const uint32_t d = digit_of(key[row], shift);
         lrank[row] += s_whist[w * kBins + d];
     }
 #pragma unroll
-    for (int row = 0; row < kKPT; ++row) {
-        if ((uint32_t)w * kSpan + (uint32_t)row * 64 + lane < ext.count) {
-            s_keys[lrank[row]] = key[row];
-            s_vals[lrank[row]] = val[row];
-        }
+    for (int row = 0; row < kKeysPerThread; ++row) {
+        if ((uint32_t)w * kWaveSpan + (uint32_t)row * 64 + lane < ext.count) s_keys[lrank[row]] = key[row];
     }
     __syncthreads();
 
     const uint32_t count = ext.count;
+    uint32_t gpos[kKeysPerThread];
 #pragma unroll
-    for (int j = 0; j < kKPT; ++j) {
-        const uint32_t p = (uint32_t)j * kST + tid;
+    for (int j = 0; j < kKeysPerThread; ++j) {
+        const uint32_t p = (uint32_t)j * kThreads + tid;
         if (p < count) {
             const KeyT k = s_keys[p];
-            const uint32_t v = s_vals[p];
-            const uint32_t gpos = s_glob[digit_of(k, shift)] + p;
-            keys_out[gpos] = (OutT)k;
-            vals_out[gpos] = v;
+            const uint32_t d = digit_of(k, shift);
+            gpos[j] = s_glob[d] + p;
+            keys_out[gpos[j]] = (OutT)k;
         }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int row = 0; row < kKeysPerThread; ++row) {
+        if ((uint32_t)w * kWaveSpan + (uint32_t)row * 64 + lane < ext.count) s_vals[lrank[row]] = val[row];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kKeysPerThread; ++j) {
+        const uint32_t p = (uint32_t)j * kThreads + tid;
+        if (p < count) vals_out[gpos[j]] = s_vals[p];
     }
 }
 
@@ -304,10 +304,12 @@ void radix_pass(Src src, OutT *keys_out, uint32_t *vals_out, size_t n, int shift
                                                    : (small ? "rs_scatter.u32.small" : "rs_scatter.u32"))
                               : "rs_scatter.text";
         ProfScope ps(prof, cls, stream, scatter_bytes);
+        // (Round 2 tried 512 threads with 8 keys each -- 75 instead of 139 VGPRs, 24 instead of 12 wavefronts
+        // per CU -- and separate LDS buffers for keys and values: the u32 passes stayed at 3.9 TB/s at 2^30
+        // pairs either way.  The pass is bound by its scattered 64-byte write runs, not by latency hiding.)
         const uint32_t grid = (uint32_t)div_up(num_tiles, 8) * 8;
-        // (512 threads with 8 keys each -- half the registers, twice the wavefronts per CU -- measured the same
-        // 3.9 TB/s at 2^30 pairs: the pass is bound by the scattered 64-byte write runs, not by latency hiding)
-        rs_scatter_kernel<KeyT, OutT, Src, kThreads><<<grid, kThreads, 0, stream>>>(src, keys_out, vals_out, n, shift, hist, num_tiles, seg);
+        rs_scatter_kernel<KeyT, OutT, Src><<<grid, kThreads, 0, stream>>>(src, keys_out, vals_out, n, shift, hist,
+                                                                          num_tiles, seg);
         KERNEL_CHECK();
     }
 }
@@ -386,7 +388,7 @@ __global__ __launch_bounds__(kThreads) void window_scatter_kernel(const uint32_t
 }  // namespace
 
 void bucketed_scatter(uint32_t *idx[2], uint32_t *val[2], size_t count, uint32_t *out, uint32_t n_out,
-                      Arena &arena, hipStream_t stream, Profiler *prof, bool keep_input) {
+                      Arena &arena, hipStream_t stream, Profiler *prof, bool keep_input, bool keep_val) {
     if (count == 0) return;
     const size_t amark = arena.mark();
     int nbits = 1;
@@ -401,7 +403,7 @@ void bucketed_scatter(uint32_t *idx[2], uint32_t *val[2], size_t count, uint32_t
         // pass 1: buffer 0 -> 1; pass 2: 1 -> 0, or 1 -> a third buffer if the input must survive
         radix_sort_pairs(idx, val, count, shifts, 1, arena, stream, prof);
         uint32_t *idx2[2] = {idx[1], keep_input ? arena.alloc<uint32_t>(count) : idx[0]};
-        uint32_t *val2[2] = {val[1], keep_input ? arena.alloc<uint32_t>(count) : val[0]};
+        uint32_t *val2[2] = {val[1], (keep_input && keep_val) ? arena.alloc<uint32_t>(count) : val[0]};
         radix_sort_pairs(idx2, val2, count, shifts + 1, 1, arena, stream, prof);
         {
             ProfScope ps(prof, "window_scatter", stream, 12.0 * (double)count);
@@ -424,7 +426,7 @@ void bucketed_scatter(uint32_t *idx[2], uint32_t *val[2], size_t count, uint32_t
             cur = 1;
             if (nbits > window_bits + kRadixBits) {
                 uint32_t *idx2[2] = {idx[1], keep_input ? arena.alloc<uint32_t>(count) : idx[0]};
-                uint32_t *val2[2] = {val[1], keep_input ? arena.alloc<uint32_t>(count) : val[0]};
+                uint32_t *val2[2] = {val[1], (keep_input && keep_val) ? arena.alloc<uint32_t>(count) : val[0]};
                 shift = window_bits + kRadixBits;
                 radix_sort_pairs(idx2, val2, count, &shift, 1, arena, stream, prof);
                 idx[1] = idx2[1];  // (local copies of the caller's pointers)

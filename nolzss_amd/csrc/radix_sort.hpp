@@ -92,7 +92,8 @@ void radix_sort_dna_keys(const PackedText &text, uint32_t *keys32[2], uint32_t *
 // window by window in LDS instead).  idx[0]/val[0] hold the input, idx[1]/val[1] are scratch of
 // the same size.  With keep_input the input arrays survive (a third pair of buffers is taken
 // from the arena); otherwise they are used as scratch too.  The pointer arrays may be updated.
+// keep_val = false (with keep_input): only idx[0] survives, val[0] is used as a ping-pong buffer too.
 void bucketed_scatter(uint32_t *idx[2], uint32_t *val[2], size_t count, uint32_t *out, uint32_t n_out,
-                      Arena &arena, hipStream_t stream, Profiler *prof, bool keep_input);
+                      Arena &arena, hipStream_t stream, Profiler *prof, bool keep_input, bool keep_val = true);
 
 }  // namespace nolzss

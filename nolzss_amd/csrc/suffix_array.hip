@@ -1372,8 +1372,13 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     Arena &arena = ctx.arena;
     const size_t mark = arena.mark();
 
-    uint64_t *keys[2] = {arena.alloc<uint64_t>(n), arena.alloc<uint64_t>(n)};
-    // The value buffers of the key sort: the one the last pass lands in IS sa (no copy afterwards).
+    // Buffers live in scopes (the arena is a stack): what the whole construction needs first -- the two
+    // active lists and the rank of every slot -- then the buffers of one phase at a time, released when the
+    // phase ends.  Everything behind the direct round is sized by the number of suffixes that are still
+    // tied, not by n: 32 n bytes stay for the whole construction (sa, rank, lcp from the caller, the
+    // lists, rank_by_slot), the key sort adds 12.5 n (2-bit texts) and the rank scatter 12 n on top of
+    // them, the doubling rounds 60 bytes per TIED suffix (96 n only when every suffix is tied, as on a
+    // periodic text; a text with 5 % of its suffixes tied after the direct round peaks at 45 n).
     // (NOLZSS_DNA_FAST_MIN: smallest text that takes the bucketed sort; the tests lower it)
     static const uint32_t dna_fast_min =
         getenv("NOLZSS_DNA_FAST_MIN") ? (uint32_t)atoll(getenv("NOLZSS_DNA_FAST_MIN")) : (1u << 20);
@@ -1401,21 +1406,30 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         key_passes = (kb + kRadixBits - 1) / kRadixBits;
         if (key_passes > 8) key_passes = 8;
     }
-    uint32_t *vals_other = arena.alloc<uint32_t>(n);
-    uint32_t *vals[2] = {vals_other, vals_other};
-    vals[key_passes & 1] = sa;
     uint32_t *act_slot[2] = {arena.alloc<uint32_t>(n), arena.alloc<uint32_t>(n)};
     uint32_t *act_grp[2] = {arena.alloc<uint32_t>(n), arena.alloc<uint32_t>(n)};
-    uint32_t *tmp_a = arena.alloc<uint32_t>(n);
-    uint32_t *tmp_b = arena.alloc<uint32_t>(n);
-    uint32_t *tmp_c = arena.alloc<uint32_t>(n);
-    uint32_t *rank_val = arena.alloc<uint32_t>(n);
     uint32_t *rank_by_slot = arena.alloc<uint32_t>(n);
-    uint32_t *scratch_idx = arena.alloc<uint32_t>(n);
-    uint32_t *scratch_val = arena.alloc<uint32_t>(n);
     uint32_t *d_total = arena.alloc<uint32_t>(4);  // survivors, look-back error flag, elements whose rank changed
     uint32_t *seg_mem = arena.alloc<uint32_t>((size_t)kSegDescWords * (div_up(n, kSortTile) + 257));  // 16-byte aligned
     uint32_t *rank = isa;
+
+    // ---- phase: key sort + first regroup -----------------------------------------------------
+    const size_t sort_mark = arena.mark();
+    // the bucketed sort of plain DNA works on 8-byte (u32 key, u32 suffix) records: two 4n-byte key buffers;
+    // the general sort on 12-byte records: two 8n-byte key buffers
+    uint64_t *keys[2];
+    if (dna_fast) {
+        uint32_t *k32 = arena.alloc<uint32_t>(2 * (size_t)n + 4);
+        keys[0] = reinterpret_cast<uint64_t *>(k32);
+        keys[1] = reinterpret_cast<uint64_t *>(k32 + (((size_t)n + 1) & ~size_t(1)));
+    } else {
+        keys[0] = arena.alloc<uint64_t>(n);
+        keys[1] = arena.alloc<uint64_t>(n);
+    }
+    // The value buffers of the key sort: the one the last pass lands in IS sa (no copy afterwards).
+    uint32_t *vals_other = arena.alloc<uint32_t>(n);
+    uint32_t *vals[2] = {vals_other, vals_other};
+    vals[key_passes & 1] = sa;
 
     // ---- round 0: order by the first K symbols -------------------------------------------
     // (the keys are never materialised in text order: the first radix pass computes them from the
@@ -1468,7 +1482,7 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         low_bits = kSegTermBits;
     }
     uint32_t m = regroup<true>(ctx, keys[cur], nullptr, nullptr, vals[cur], nullptr, n, n, sa, rank, act_slot[0],
-                               act_grp[0], scratch_idx, scratch_val, rank_val, d_total, lcp,
+                               act_grp[0], nullptr, nullptr, nullptr, d_total, lcp,
                                k_syms * text.bits, tag_bits, text.bits, nullptr, low_bits, 0, rank_by_slot, nullptr,
                                dna_fast ? reinterpret_cast<const uint32_t *>(keys[cur]) : nullptr,
                                dna_fast ? &seg : nullptr,
@@ -1477,12 +1491,9 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
                                (dna_fast || (independent && text.terms.mirror)) ? (uint32_t)k_syms : 0u, false,
                                text.terms.seq_shift);
 
-    // ---- doubling rounds ------------------------------------------------------------------
-    // in the rounds the 8n-byte key buffers are reused as four u32 arrays
-    uint32_t *lo = reinterpret_cast<uint32_t *>(keys[0]);
-    uint32_t *out_lo = lo + n;
-    uint32_t *rvals = rank_by_slot;  // free once rank[] has been written (before the doubling rounds)
-    uint32_t *out_vals = vals_other;
+    arena.rewind(sort_mark);  // keys and the second value buffer are done
+
+    // ---- doubling rounds: set-up ------------------------------------------------------------
     int nbits = 1;
     while (nbits < 32 && (1ull << nbits) <= (uint64_t)n) ++nbits;  // ranks and slots are <= n
     const int half_passes = (nbits + kRadixBits - 1) / kRadixBits;
@@ -1495,12 +1506,15 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     static const bool trace = getenv("NOLZSS_TRACE") != nullptr;  // active-list sizes to stderr
     if (trace) fprintf(stderr, "[nolzss] n=%u: %u suffixes tied after the %d-symbol key sort\n", n, m, k_syms);
 
-    // one pass writes rank[] for everybody: rank[sa[slot]] = rank_by_slot[slot]
+    // one pass writes rank[] for everybody: rank[sa[slot]] = rank_by_slot[slot] (rank_by_slot is not needed
+    // afterwards: it serves as one of the ping-pong buffers)
     auto write_all_ranks = [&] {
         ProfScope ps(ctx.profiler(), "sa_rank_scatter", s);
-        uint32_t *idx[2] = {sa, scratch_idx};
-        uint32_t *val[2] = {rank_by_slot, scratch_val};
-        bucketed_scatter(idx, val, n, rank, n, arena, s, ctx.profiler(), true);
+        const size_t smark = arena.mark();
+        uint32_t *idx[2] = {sa, arena.alloc<uint32_t>(n)};
+        uint32_t *val[2] = {rank_by_slot, arena.alloc<uint32_t>(n)};
+        bucketed_scatter(idx, val, n, rank, n, arena, s, ctx.profiler(), true, /*keep_val=*/false);
+        arena.rewind(smark);
     };
 
     // ---- direct round: small groups are finished by comparing packed suffixes ---------------
@@ -1508,6 +1522,8 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     // rounds, so it is written once, after this round, instead of after each of the two)
     if (m > 0 && h < n) {
         const uint32_t *slot = act_slot[a_cur], *grp = act_grp[a_cur];
+        const size_t direct_mark = arena.mark();
+        uint32_t *out_lo = arena.alloc<uint32_t>(m);
         uint32_t *lcp_list = arena.alloc<uint32_t>(m);
         // at most 32 words (1024 bases of DNA) deep; longer ties are cheaper in the doubling rounds
         static const uint32_t cap_words = getenv("NOLZSS_REFINE_WORDS") ? (uint32_t)atoi(getenv("NOLZSS_REFINE_WORDS")) : 32u;
@@ -1533,11 +1549,12 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
             }
             KERNEL_CHECK();
         }
-        m = regroup<false>(ctx, nullptr, grp, out_lo, out_vals, slot, m, n, sa, rank, act_slot[a_cur ^ 1],
-                           act_grp[a_cur ^ 1], scratch_idx, scratch_val, rank_val, d_total, lcp,
+        m = regroup<false>(ctx, nullptr, grp, out_lo, nullptr, slot, m, n, sa, rank, act_slot[a_cur ^ 1],
+                           act_grp[a_cur ^ 1], nullptr, nullptr, nullptr, d_total, lcp,
                            0, 0, 0, lcp_list, 0, (uint32_t)h, rank_by_slot, nullptr, nullptr, nullptr, 0u,
                            /*sa_is_current=*/true);
         a_cur ^= 1;
+        arena.rewind(direct_mark);
         // every group that is still tied agrees on at least min_depth symbols (K if a group was too large
         // for the round, more if the round left all its ties at the cap or at a bail-out depth): the
         // doubling rounds start there instead of repeating the steps K, 2K, 4K, ...
@@ -1549,6 +1566,35 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         if (trace) fprintf(stderr, "[nolzss]   direct round (cap %u symbols): %u still tied, on at least %llu symbols\n", cap, m, (unsigned long long)h);
     }
     write_all_ranks();
+
+    // Work arrays of the rounds that follow, one entry per tied suffix -- or per text position when the
+    // pair-run pass will run (it works in text order; the rounds behind it then use the same arrays).
+    static const long long pair_runs_min = getenv("NOLZSS_PAIR_RUNS_MIN") ? atoll(getenv("NOLZSS_PAIR_RUNS_MIN")) : -1;
+    const bool pair_runs = m > 0 && (pair_runs_min >= 0 ? (long long)m >= pair_runs_min : m >= n / 16);
+    const size_t wlen = m == 0 ? 0 : (pair_runs ? (size_t)n : (size_t)m);
+    uint32_t *tmp_a = nullptr, *tmp_b = nullptr, *tmp_c = nullptr, *rank_val = nullptr, *scratch_idx = nullptr;
+    uint32_t *scratch_val = nullptr, *lo = nullptr, *out_lo = nullptr, *out_vals = nullptr;
+    if (m > 0) {
+        try {
+            tmp_a = arena.alloc<uint32_t>(wlen);
+            tmp_b = arena.alloc<uint32_t>(wlen);
+            tmp_c = arena.alloc<uint32_t>(wlen);
+            rank_val = arena.alloc<uint32_t>(wlen);
+            scratch_idx = arena.alloc<uint32_t>(wlen);
+            scratch_val = arena.alloc<uint32_t>(wlen);
+            lo = arena.alloc<uint32_t>(wlen);
+            out_lo = arena.alloc<uint32_t>(wlen);
+            out_vals = arena.alloc<uint32_t>(wlen);
+        } catch (const HipError &) {
+            char buf[256];
+            snprintf(buf, sizeof buf,
+                     "suffix array: %u of %u suffixes are still tied after the direct round (a highly repetitive text); "
+                     "the rounds that resolve them need about %.1f GiB more device memory than this device has left",
+                     m, n, 60.0 * (double)wlen / 1073741824.0);
+            throw HipError(buf);
+        }
+    }
+    uint32_t *rvals = rank_by_slot;  // free now that rank[] has been written
 
     // one range-minimum pyramid over the LCP values known so far; the regroup kernel keeps it current
     Pyramid Plcp{};
@@ -1563,12 +1609,11 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     // groups without finishing them -- three copies, one of which differs behind the run -- is followed by
     // another one over the smaller groups.  NOLZSS_PAIR_RUNS_MIN: smallest number of tied suffixes for
     // which it runs, the tests set 1)
-    static const long long pair_runs_min = getenv("NOLZSS_PAIR_RUNS_MIN") ? atoll(getenv("NOLZSS_PAIR_RUNS_MIN")) : -1;
-    for (int pass = 0; pass < 10 && m > 0 && (pair_runs_min >= 0 ? (long long)m >= pair_runs_min : m >= n / 16); ++pass) {
+    for (int pass = 0; pair_runs && pass < 10 && m > 0 && (pair_runs_min >= 0 ? (long long)m >= pair_runs_min : m >= n / 16); ++pass) {
         ProfScope ps(ctx.profiler(), "sa_pair_runs", s);
         uint32_t *link = tmp_a, *gsz = rank_val, *rev = tmp_b, *end_of = tmp_c, *togo = scratch_idx;
-        uint32_t *end_place = scratch_val, *end_lcp = reinterpret_cast<uint32_t *>(keys[0]);
-        uint32_t *end_head = reinterpret_cast<uint32_t *>(keys[0]) + n;
+        uint32_t *end_place = scratch_val, *end_lcp = lo;
+        uint32_t *end_head = out_lo;
         const unsigned g = grid_for(n, kThreads, 256u * 64u);
         {
             ProfScope p1(ctx.profiler(), "runs_link", s);
@@ -1635,7 +1680,7 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         if (n_large > 0) {  // members of groups larger than kSmallGroup: global radix sort
             ProfScope ps(ctx.profiler(), "sa_sort_large", s);
             const size_t lmark = arena.mark();
-            uint64_t *lk[2] = {keys[1], arena.alloc<uint64_t>(n_large)};
+            uint64_t *lk[2] = {arena.alloc<uint64_t>(n_large), arena.alloc<uint64_t>(n_large)};
             uint32_t *lv[2] = {arena.alloc<uint32_t>(n_large), arena.alloc<uint32_t>(n_large)};
             uint32_t *lidx = tmp_c;
             gather_large_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(tmp_a, tmp_b, grp, lo, rvals, m, lk[0],

@@ -305,7 +305,7 @@ def test_arenas_are_given_back_and_taken_again(pkg):
         c1, _ = native.factorize_batch(recs, want_factors=False)
         assert native.debug_arena()[0] > 0
         released = native.debug_trim_arenas()
-        assert released >= 4 * 108 * (1 << 18)
+        assert released >= 4 * 96 * (1 << 18)   # four lanes, the worst-case reservation of a 2^18-base record each
         assert native.debug_arena()[0] == 0
         c2, _ = native.factorize_batch(recs, want_factors=False)
     finally:
