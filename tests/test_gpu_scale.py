@@ -208,6 +208,44 @@ def test_beyond_2Gi_positions(native):
     assert native.count_factors(text) == len(f)
 
 
+@pytest.mark.timeout(1500)
+def test_genome_scale_capacity(native):
+    """The documented capacity of one MI355X: a 3.2 Gbase text in plain mode -- the
+    size of a human genome, 49 bytes per base of device memory at the peak, 52 reserved at the least -- and a
+    1.55 Gbase text with its reverse complement (3.1 G symbols).  Tiling, sampled true-match checks, the
+    exact prefix of the parse against the oracle, and an input beyond the limits refused up front."""
+    n = 3_200_000_000
+    text = gen.random_dna(n, seed=91)
+    text[n - (1 << 20):] = text[5:5 + (1 << 20)]          # the parse must end with (about) this copy
+    f = native.factorize_array(text)
+    _check_tiling(f, n)
+    assert int(f["length"][-1]) > (1 << 20) - 64 and abs(int(f["ref"][-1]) - 5) < 64
+    _check_matches(text, f, 20_000, np.random.default_rng(5))
+    far = np.flatnonzero(f["start"] > np.uint64(3_000_000_000))
+    _check_matches(text, f[far[0]:], 20_000, np.random.default_rng(6))
+    P = 1 << 22
+    exp = oracle.factors_array(text[:P])
+    cut = int(np.searchsorted(f["start"] + f["length"], P, side="right"))
+    assert cut > 100_000 and cut <= len(exp)
+    for k in ("start", "length", "ref"):
+        assert np.array_equal(f[k][:cut], exp[k][:cut]), k
+    z = len(f)
+    del f
+    assert native.count_factors(text) == z
+    cap, peak = native.debug_arena()
+    assert peak <= 52 * n + (64 << 20), (cap, peak)
+    # reverse-complement mode at 1.55 Gbases: S has 3.1 G symbols
+    n2 = 1_550_000_000
+    f2 = native.factorize_dna_w_rc_array(text[:n2])
+    _check_tiling(f2, n2)
+    _check_matches(text[:n2], f2, 20_000, np.random.default_rng(7), rc_mode=True)
+    assert (f2["ref"] >> np.uint64(63)).any()
+    del f2
+    # beyond the 32-bit index range: an argument error up front, not a device out-of-memory error
+    with pytest.raises(ValueError, match="text too long"):
+        native.count_factors_dna_w_rc(np.zeros((1 << 31) + 5, dtype=np.uint8))
+
+
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("name", ["allA_8M", "period3_4M", "fib_4M", "abracadabra_x400k", "two_long_copies_8M",
                                   "long_copy_with_edits_6M"])
