@@ -197,3 +197,43 @@ def test_shard_plan_matches_python_plan():
         lens = [rng.choice([0, 1, 5, 5, 100, rng.randint(1, 10**6)]) for _ in range(rng.randint(0, 40))]
         bins = rng.randint(1, 9)
         assert _noLZSS.debug_lpt_plan(lens, bins) == lpt_assignment(lens, bins)
+
+
+def test_nucleotide_reader_large_file_in_pieces(tmp_path):
+    """files above 16 MiB are read by several host threads, each from a line that starts with '>': same
+    records, same dict semantics across pieces, same first error with its line number in the FILE"""
+    import numpy as np
+    rng = np.random.default_rng(12)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    parts = []
+    for k in range(36):
+        seq = acgt[rng.integers(0, 4, size=700_000 + 1000 * k, dtype=np.uint8)].tobytes()
+        if k % 5 == 0:
+            seq = seq.lower()
+        rid = f"rec{k % 30} some words"            # rec0..rec5 come twice: the later record replaces the bases
+        lines = b"\n".join(seq[i:i + 70] for i in range(0, len(seq), 70))
+        parts.append(b">" + rid.encode() + (b"\r\n" if k % 7 == 0 else b"\n") + lines + b"\n" + (b"\n" if k % 3 == 0 else b""))
+    p = tmp_path / "big.fa"
+    p.write_bytes(b"".join(parts))
+    assert p.stat().st_size > 24 * (1 << 20)
+    exp, exp_err = _python_reader(p)
+    got, got_err = _native_reader(p)
+    assert exp_err is None and got_err is None
+    assert len(got) == 30 and got == exp
+    # an empty header in the last third: the line number counts the whole file
+    bad = parts[:30] + [b">\nACGT\n"] + parts[30:]
+    p.write_bytes(b"".join(bad))
+    exp, exp_err = _python_reader(p)
+    got, got_err = _native_reader(p)
+    assert exp is None and got is None and got_err == exp_err and "Empty sequence header at line" in got_err
+    # two errors: the one that comes first in the file is reported
+    bad = parts[:10] + [b"> \nAC\n"] + parts[10:33] + [b">\nAC\n"] + parts[33:]
+    p.write_bytes(b"".join(bad))
+    assert _native_reader(p)[1] == _python_reader(p)[1]
+    # an invalid nucleotide far into the file
+    bad = list(parts)
+    bad[20] = bad[20][:5000] + b"N" + bad[20][5000:]
+    p.write_bytes(b"".join(bad))
+    exp, exp_err = _python_reader(p)
+    got, got_err = _native_reader(p)
+    assert exp is None and got is None and _same_error(got_err, exp_err)
