@@ -66,8 +66,7 @@ __device__ __forceinline__ bool lpf_decide(uint32_t i, uint32_t lp, uint32_t jp,
     return true;
 }
 
-// kBlocks: block-table search (nearest_lds.hpp, lds_search_wave_blocks); false: the list / row scheme
-template <bool kBlocks, bool kTimed>
+template <bool kTimed>
 __global__ __launch_bounds__(kLdsThreads) void lpf_tile_kernel(const uint32_t *__restrict__ sa,
                                                                const uint32_t *__restrict__ lcp, uint32_t n,
                                                                uint32_t *__restrict__ lstar_by_rank,
@@ -84,27 +83,20 @@ __global__ __launch_bounds__(kLdsThreads) void lpf_tile_kernel(const uint32_t *_
     __shared__ uint32_t s_len[NS * kLdsTile];
     __shared__ uint32_t s_pos[NS * kLdsTile];
     __shared__ uint16_t s_list[kLdsWaves][2][NS * kLdsPerWave];
-    __shared__ uint32_t s_blk[kBlocks ? 3 * kNumBlk : 1];
+    __shared__ uint32_t s_blk[3 * kNumBlk];
     const uint32_t base = blockIdx.x * (uint32_t)kLdsTile;
     const uint32_t shard = blockIdx.x % kQShards;
     stage_tile(sa, lcp, n, base, s_sa, s_lcp);
     __syncthreads();
-    const BlockTables T{s_blk, nullptr, s_blk + (kBlocks ? kNumBlk : 0), s_blk + (kBlocks ? 2 * kNumBlk : 0)};
-    if (kBlocks) {
-        build_block_tables<false>(s_sa, s_lcp, T);
-        __syncthreads();
-    }
+    const BlockTables T{s_blk, nullptr, s_blk + kNumBlk, s_blk + 2 * kNumBlk};
+    build_block_tables<false>(s_sa, s_lcp, T);
+    __syncthreads();
     if (timed) clk[1] = __builtin_readcyclecounter();
     const int w = threadIdx.x >> 6;
     const uint32_t far_bit = n <= 0x80000000u ? 0x80000000u : 0u;
-    if (kBlocks)
-        lds_search_wave_blocks<NS, NS>(s_sa, s_lcp, T, n, base, s_len, s_pos, s_list[w][0], s_list[w][1],
-                                       [](uint32_t) { return true; }, [](uint32_t) { return 0u; }, far_bit,
-                                       timed ? clk + 2 : nullptr);
-    else
-        lds_search_wave<NS, NS, 1, 0>(s_sa, s_lcp, n, base, s_len, s_pos, s_list[w][0], s_list[w][1],
-                                      [](uint32_t) { return true; }, [](uint32_t) { return 0u; }, far_bit,
-                                      timed ? clk + 2 : nullptr);
+    lds_search_wave_blocks<NS, NS>(s_sa, s_lcp, T, n, base, s_len, s_pos, s_list[w][0], s_list[w][1],
+                                   [](uint32_t) { return true; }, [](uint32_t) { return 0u; }, far_bit,
+                                   timed ? clk + 2 : nullptr);
     if (timed) clk[4] = __builtin_readcyclecounter();
     // epilogue: every rank is decided, or goes to the far queue (a search beyond the reach whose bound can
     // still beat the other direction) or to the exact-search queue -- ONE atomic per wavefront and queue
@@ -238,21 +230,16 @@ uint32_t build_lstar(Context &ctx, uint32_t n, const uint32_t *sa, const uint32_
     };
     {
         ProfScope ps(ctx.profiler(), "lpf", s, 12.0 * (double)n);
-        static const bool old_scheme = getenv("NOLZSS_LPF_LISTS") != nullptr;  // (A/B: the list / row scheme)
         static const bool want_phases = getenv("NOLZSS_LPF_PHASES") != nullptr;
         unsigned long long *phases = nullptr;
         if (want_phases) {
             phases = ctx.arena.alloc<unsigned long long>(8);
             HIP_CHECK(hipMemsetAsync(phases, 0, 64, s));
         }
-        if (phases && old_scheme)
-            lpf_tile_kernel<false, true><<<tiles, kLdsThreads, 0, s>>>(sa, lcp, n, by_rank, exact_q, far_q, far_aux, phases);
-        else if (phases)
-            lpf_tile_kernel<true, true><<<tiles, kLdsThreads, 0, s>>>(sa, lcp, n, by_rank, exact_q, far_q, far_aux, phases);
-        else if (old_scheme)
-            lpf_tile_kernel<false, false><<<tiles, kLdsThreads, 0, s>>>(sa, lcp, n, by_rank, exact_q, far_q, far_aux, nullptr);
+        if (phases)
+            lpf_tile_kernel<true><<<tiles, kLdsThreads, 0, s>>>(sa, lcp, n, by_rank, exact_q, far_q, far_aux, phases);
         else
-            lpf_tile_kernel<true, false><<<tiles, kLdsThreads, 0, s>>>(sa, lcp, n, by_rank, exact_q, far_q, far_aux, nullptr);
+            lpf_tile_kernel<false><<<tiles, kLdsThreads, 0, s>>>(sa, lcp, n, by_rank, exact_q, far_q, far_aux, nullptr);
         KERNEL_CHECK();
         if (phases) {
             unsigned long long h[8];
@@ -260,7 +247,7 @@ uint32_t build_lstar(Context &ctx, uint32_t n, const uint32_t *sa, const uint32_
             HIP_CHECK(hipStreamSynchronize(s));
             const double w = h[5] ? (double)h[5] : 1.0;
             fprintf(stderr, "[nolzss] lpf_tile phases (cycles per wavefront, %llu sampled): stage %.0f  round0 %.0f  %s %.0f  %s %.0f  epilogue %.0f\n",
-                    h[5], h[0] / w, h[1] / w, old_scheme ? "worklist" : "roundA", h[2] / w, old_scheme ? "tail" : "roundsBC", h[3] / w, h[4] / w);
+                    h[5], h[0] / w, h[1] / w, "roundA", h[2] / w, "roundsBC", h[3] / w, h[4] / w);
         }
     }
     {
