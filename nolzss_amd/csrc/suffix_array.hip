@@ -335,6 +335,7 @@ struct RegroupArgs {
     uint32_t *rank_by_slot;   // rank per slot
     uint32_t *lcp;
     int sym_bits, tag_bits, bits, low_bits;  // round 0 key layout
+    int bits_shift;                          // log2(bits): a division by a run-time value costs ~20 instructions per item
     const uint32_t *lcp_list; // later rounds: LCP decided by the direct comparison round
     uint32_t dbl_h;
     Pyramid Plcp;
@@ -354,8 +355,17 @@ __device__ __forceinline__ uint32_t lane_next(uint32_t v, uint32_t edge) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x130, 0xf, 0xf, false);  // wave_shl:1
 }
 
-template <bool kRound0>
+// kDnaFast (round 0 of the bucketed 2-bit key sort): the key layout is known at compile time -- 34 symbol
+// bits, 6-bit tag, no low bits, no sequence numbers, short suffixes flagged -- which folds the shifts and
+// masks of every item (the kernel is bound by VALU issue: ~1300 instructions per wavefront and 512 suffixes)
+template <bool kRound0, bool kDnaFast>
 __global__ __launch_bounds__(kFuseThreads) void regroup_kernel(RegroupArgs A) {
+    const int low_bits = kDnaFast ? 0 : A.low_bits;
+    const int tag_bits = kDnaFast ? KeyLayout<2>::kTagBits : A.tag_bits;
+    const int sym_bits = kDnaFast ? 2 * KeyLayout<2>::kSyms : A.sym_bits;
+    const int bits_shift = kDnaFast ? 1 : A.bits_shift;
+    const uint32_t short_tag = kDnaFast ? (uint32_t)KeyLayout<2>::kSyms : A.short_tag;
+    const uint32_t seq_shift = kDnaFast ? 0u : A.seq_shift;
     constexpr int kWaves = kFuseThreads / 64;
     constexpr int kSegs = kFuseItems * kWaves;  // 64-element segments of the tile, in element order
     __shared__ uint32_t s_tile;
@@ -375,7 +385,7 @@ __global__ __launch_bounds__(kFuseThreads) void regroup_kernel(RegroupArgs A) {
     const int lane = lane_id();
     const int w = threadIdx.x >> 6;
     const uint64_t lt = lanemask_lt();
-    const bool bucketed = kRound0 && A.keys32 != nullptr;
+    const bool bucketed = kDnaFast || (kRound0 && A.keys32 != nullptr);
 
     auto load_view = [&](size_t a) -> uint64_t {
         if (kRound0) {
@@ -417,7 +427,7 @@ __global__ __launch_bounds__(kFuseThreads) void regroup_kernel(RegroupArgs A) {
         bool head = !in || a == 0 || v != pv;  // "past the end" counts as a head
         // a suffix that meets a terminator inside the key window ties only with copies of itself at
         // other terminators, and the stable sort has left those in their final order
-        if (kRound0 && A.short_tag) head = head || ((uint32_t)(v >> A.low_bits) & ((1u << A.tag_bits) - 1u)) < A.short_tag;
+        if (kRound0 && short_tag) head = head || ((uint32_t)(v >> low_bits) & ((1u << tag_bits) - 1u)) < short_tag;
         // is the element behind me a head?
         const uint32_t edge_next = (lane == 63 && in && a + 1 < m) ? (edge[k] != v ? 1u : 0u) : 1u;
         const bool next_head = lane_next(head ? 1u : 0u, edge_next) != 0;
@@ -453,14 +463,14 @@ __global__ __launch_bounds__(kFuseThreads) void regroup_kernel(RegroupArgs A) {
             if (a == 0) {
                 l = 0;
             } else if (head) {
-                const uint64_t ka = v >> A.low_bits, kb = pv >> A.low_bits;
-                const uint64_t tmask = (1ull << A.tag_bits) - 1ull;
+                const uint64_t ka = v >> low_bits, kb = pv >> low_bits;
+                const uint64_t tmask = (1ull << tag_bits) - 1ull;
                 const uint32_t ta = (uint32_t)(ka & tmask), tb = (uint32_t)(kb & tmask);
-                const uint64_t x = (ka ^ kb) >> A.tag_bits << (64 - A.sym_bits);  // symbols, left-aligned
-                uint32_t ls = x ? (uint32_t)__clzll((long long)x) / (uint32_t)A.bits : 0xffffffffu;
+                const uint64_t x = (ka ^ kb) >> tag_bits << (64 - sym_bits);  // symbols, left-aligned
+                uint32_t ls = x ? (uint32_t)__clzll((long long)x) >> bits_shift : 0xffffffffu;  // (bits per symbol is 2, 4 or 8)
                 ls = ls < ta ? ls : ta;
                 l = ls < tb ? ls : tb;
-                if (A.seq_shift && (v >> A.seq_shift) != (pv >> A.seq_shift)) l = 0;  // different sequences
+                if (seq_shift && (v >> seq_shift) != (pv >> seq_shift)) l = 0;  // different sequences
             }
             A.lcp[a] = l;
         }
@@ -1161,6 +1171,7 @@ uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *grp, const 
         A.chg_idx = scratch_idx; A.chg_count = d_total + 2;
         HIP_CHECK(hipMemsetAsync(d_total + 2, 0, sizeof(uint32_t), s));
         A.sym_bits = sym_bits; A.tag_bits = tag_bits; A.bits = bits; A.low_bits = low_bits;
+        A.bits_shift = bits == 2 ? 1 : (bits == 4 ? 2 : 3);
         A.lcp_list = lcp_list; A.dbl_h = dbl_h; A.Plcp = Plcp;
         A.new_slot = new_slot; A.new_grp = new_grp;
         A.desc_max = desc; A.desc_sum = desc + tiles;
@@ -1172,7 +1183,13 @@ uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *grp, const 
             A.phases = ctx.arena.alloc<unsigned long long>(8);
             HIP_CHECK(hipMemsetAsync(A.phases, 0, 64, s));
         }
-        regroup_kernel<kRound0><<<(unsigned)tiles, kFuseThreads, 0, s>>>(A);
+        const bool fast_layout = kRound0 && keys32 && seg && low_bits == 0 && tag_bits == KeyLayout<2>::kTagBits &&
+                                 sym_bits == 2 * KeyLayout<2>::kSyms && bits == 2 && seq_shift == 0 &&
+                                 short_tag == (uint32_t)KeyLayout<2>::kSyms;
+        if (fast_layout)
+            regroup_kernel<kRound0, kRound0><<<(unsigned)tiles, kFuseThreads, 0, s>>>(A);  // (kDnaFast only exists for round 0)
+        else
+            regroup_kernel<kRound0, false><<<(unsigned)tiles, kFuseThreads, 0, s>>>(A);
         KERNEL_CHECK();
         if (want_phases) {
             unsigned long long h[8];
