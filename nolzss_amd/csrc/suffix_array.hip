@@ -37,6 +37,10 @@ namespace {
 
 constexpr int kThreads = 256;
 
+struct OpMinU32x {
+    __device__ __forceinline__ uint32_t operator()(uint32_t a, uint32_t b) const { return a < b ? a : b; }
+};
+
 inline unsigned grid_for(size_t work_items, int per_block, unsigned cap = 256u * 16u) {
     size_t g = div_up(work_items, (size_t)per_block);
     if (g < 1) g = 1;
@@ -802,17 +806,230 @@ __global__ __launch_bounds__(kThreads) void round_keys_kernel(const uint32_t *__
     }
 }
 
-// Segmented sort of the active list by lo inside each group.  Groups are contiguous in the
-// list and (for real sequence data) almost all tiny, so each element finds its place by
-// counting the smaller members of its own group -- one pass, no radix passes.  Members of
-// groups larger than kSmallGroup are flagged for the radix fallback instead.
-constexpr uint32_t kSmallGroup = 64;
-
 // *p = min(*p, v) for a value that millions of wavefronts report and that soon stops changing: look
 // first, the atomic only if it would lower the value (5 M atomics on one address cost 20 ms)
 __device__ __forceinline__ void lower_min(uint32_t *p, uint32_t v) {
     if (*reinterpret_cast<volatile uint32_t *>(p) > v) atomicMin(p, v);
 }
+
+// ---------------------------------------------------------------------------------------
+// Periodic runs.  On a text with long runs of a short period (a poly-A tract, a tandem repeat, a period-1000
+// text) the suffixes of a run tie on whatever depth h has been compared, in groups far larger than the
+// pair-run pass takes, and prefix doubling peels only h of them off per round: log2(run length) rounds over
+// everything.  The order inside such a group is arithmetic.  Let q be the smallest distance between two
+// members of a group in the text, q <= h / 2: the h symbols every member starts with then have period q, a
+// prefix of u^inf for one word u.  For a member x let rho(x) = q + lcp(x, x + q): the text keeps that period
+// for exactly rho(x) symbols from x; at x + rho(x) it breaks -- with a symbol smaller than the periodic
+// continuation ("down", also when the text ends there) or larger ("up").  Two members with different rho
+// agree on min(rho) symbols and the one that breaks first goes down below / up above the other; so the group
+// in suffix order is: the down members by ascending rho, then the up members by descending rho, the LCP of
+// neighbours with different keys being the smaller rho.  Members with the same key stay tied (a smaller
+// group for the next pass or the doubling rounds).
+// lcp(x, x + q) needs no text: along a run of text positions t, t + 1, .. whose suffixes all have their next
+// group member q behind them, lcp(t, t + q) = 1 + lcp(t + 1, t + 1 + q), so it is the distance to the end E
+// of that run of positions plus lcp(E, E + q), and suffixes E and E + q are in DIFFERENT groups: their order
+// is the order of their rank codes and their LCP the range minimum of the decided LCP entries between them.
+// A group with a member for which that fails (E and E + q tied with each other), or with q > h / 2, is
+// left alone as a whole.
+// ---------------------------------------------------------------------------------------
+constexpr uint32_t kPerNone = 0xffffffffu;   // gq: no distance seen yet
+constexpr uint32_t kPerBad = 0x80000000u;    // gq: flag "leave this group alone" (positions are below 2^31 here)
+
+// members of groups with more than `limit` members (the list is in slot order: a member's index inside its
+// group is slot - head): one atomic per workgroup
+__global__ __launch_bounds__(kThreads) void per_count_large_kernel(const uint32_t *__restrict__ act_slot,
+                                                                   const uint32_t *__restrict__ act_grp, uint32_t m,
+                                                                   uint32_t limit, uint32_t *__restrict__ count) {
+    uint32_t mine = 0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x; a < m; a += stride)
+        mine += (act_slot[a] - act_grp[a] >= limit) ? 1u : 0u;
+    mine = wave_reduce(mine, OpAdd<uint32_t>());
+    __shared__ uint32_t s_part[kThreads / 64];
+    if (lane_id() == 0) s_part[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int i = 0; i < kThreads / 64; ++i) t += s_part[i];
+        if (t) atomicAdd(count, t);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void per_keys_kernel(const uint32_t *__restrict__ act_slot,
+                                                            const uint32_t *__restrict__ act_grp, uint32_t m,
+                                                            const uint32_t *__restrict__ sa,
+                                                            uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x; a < m; a += stride) {
+        const uint32_t pos = sa[act_slot[a]];
+        keys[a] = ((uint64_t)act_grp[a] << 32) | pos;
+        vals[a] = pos;
+    }
+}
+
+// list sorted by (group, position): gq[group] = smallest distance between neighbours.  One atomic per
+// workgroup / wavefront where it holds one group only (a giant group would otherwise send every lane to
+// one address, 13 ns each).  The grid covers the list exactly once (no stride loop: barriers inside).
+__global__ __launch_bounds__(kThreads) void per_link_kernel(const uint64_t *__restrict__ keys, uint32_t m,
+                                                            uint32_t *__restrict__ gq) {
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = j < m;
+    const uint64_t k = in ? keys[j] : 0;
+    const uint32_t g = (uint32_t)(k >> 32);
+    uint32_t link = kPerNone;
+    if (in && j + 1 < m) {
+        const uint64_t k2 = keys[j + 1];
+        if ((uint32_t)(k2 >> 32) == g) link = (uint32_t)k2 - (uint32_t)k;
+    }
+    __shared__ uint32_t s_g0, s_min[kThreads / 64];
+    if (threadIdx.x == 0) s_g0 = g;
+    __syncthreads();
+    const int uniform = __syncthreads_and(in && g == s_g0);
+    if (uniform) {
+        const uint32_t w = wave_reduce(link, OpMinU32x());
+        if (lane_id() == 0) s_min[threadIdx.x >> 6] = w;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t b = s_min[0];
+            for (int i = 1; i < kThreads / 64; ++i) b = s_min[i] < b ? s_min[i] : b;
+            if (b != kPerNone) atomicMin(&gq[g], b);
+        }
+        return;
+    }
+    const uint32_t g_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
+    if (__ballot(!in || g != g_first) == 0) {  // the wavefront holds one group
+        const uint32_t w = wave_reduce(link, OpMinU32x());
+        if (lane_id() == 0 && w != kPerNone) atomicMin(&gq[g], w);
+    } else if (in && link != kPerNone) {
+        atomicMin(&gq[g], link);
+    }
+}
+
+// PQ[pos] = q for a member whose next group member is exactly q behind it, q = the group's distance (0 for
+// everything else; the array was cleared).  Groups whose q exceeds half the depth compared so far are
+// flagged; the smallest such q is reported (hint: try again when the depth has passed twice that).
+__global__ __launch_bounds__(kThreads) void per_flags_kernel(const uint64_t *__restrict__ keys, uint32_t m,
+                                                             uint32_t *__restrict__ gq, uint32_t half_depth,
+                                                             uint32_t *__restrict__ PQ, uint32_t *__restrict__ hint) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) {
+        const uint64_t k = keys[j];
+        const uint32_t g = (uint32_t)(k >> 32), pos = (uint32_t)k;
+        const uint32_t q = *reinterpret_cast<volatile uint32_t *>(&gq[g]) & ~kPerBad;
+        const bool head = j == 0 || (uint32_t)(keys[j - 1] >> 32) != g;
+        if (q > half_depth) {  // (also kPerNone & ~kPerBad)
+            if (head) {
+                atomicOr(&gq[g], kPerBad);
+                if (q != (kPerNone & ~kPerBad)) lower_min(hint, q);
+            }
+            continue;
+        }
+        uint32_t link = 0;
+        if (j + 1 < m) {
+            const uint64_t k2 = keys[j + 1];
+            if ((uint32_t)(k2 >> 32) == g) link = (uint32_t)k2 - pos;
+        }
+        if (link == q) PQ[pos] = q;
+    }
+}
+
+// rev[n - 1 - t] = (n - 1 - t) + 1 unless the run of positions goes on from t to t + 1 (both carry the same
+// distance): the inclusive max-scan of rev names, for every t, the last position of its run
+__global__ __launch_bounds__(kThreads) void per_breaks_kernel(const uint32_t *__restrict__ PQ, uint32_t n,
+                                                              uint32_t *__restrict__ rev) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
+        const uint32_t q = PQ[t];
+        const bool on = q != 0 && t + 1 < n && PQ[t + 1] == q;
+        rev[n - 1 - t] = on ? 0u : (uint32_t)(n - 1 - t) + 1u;
+    }
+}
+
+// sort key of every member: rho for the down members, ~rho for the up members (0 is never a key)
+__global__ __launch_bounds__(kThreads) void per_rho_kernel(const uint64_t *__restrict__ keys, uint32_t m,
+                                                           uint32_t *__restrict__ gq, const uint32_t *__restrict__ PQ,
+                                                           const uint32_t *__restrict__ end_of,
+                                                           const uint32_t *__restrict__ rank, uint32_t n, Pyramid Plcp,
+                                                           uint32_t *__restrict__ kraw) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) {
+        const uint64_t k = keys[j];
+        const uint32_t g = (uint32_t)(k >> 32), pos = (uint32_t)k;
+        const uint32_t gv = *reinterpret_cast<volatile uint32_t *>(&gq[g]);
+        kraw[j] = 0;
+        if (gv & kPerBad) continue;
+        const uint32_t q = gv;
+        // E: the first position at or behind pos whose suffix does NOT have its next group member q behind it
+        uint32_t E = pos;
+        if (PQ[pos] == q) E = ((n - 1) - (end_of[n - 1 - pos] - 1u)) + 1u;
+        bool ok = E < n;
+        uint32_t lam = 0, c1 = 0, c2 = 0;
+        if (ok) {
+            c1 = rank[E];
+            const uint64_t e2 = (uint64_t)E + q;
+            c2 = e2 < n ? rank[e2] : 0u;  // past the end: sorts first, shares nothing
+            if (c1 == c2) {
+                ok = false;  // tied with each other: nothing is known about them yet
+            } else if (c2 != 0) {
+                const uint32_t a = c1 < c2 ? c1 : c2, b = c1 < c2 ? c2 : c1;
+                lam = pyr_range<false>(Plcp, a, b - 1u);  // decided entries between the two groups
+                if (lam >= kLcpPendingMin) ok = false;
+            }
+        }
+        if (!ok) {
+            atomicOr(&gq[g], kPerBad);
+            continue;
+        }
+        const uint32_t rho = (E - pos) + lam + q;  // <= n - pos
+        kraw[j] = c2 < c1 ? rho : ~rho;            // down (suffix E + q is the smaller one) : up
+    }
+}
+
+// second sort key (group, K): K = 0 for every member of a group that is left alone
+__global__ __launch_bounds__(kThreads) void per_keys2_kernel(const uint64_t *__restrict__ keys, uint32_t m,
+                                                             const uint32_t *__restrict__ gq,
+                                                             const uint32_t *__restrict__ kraw,
+                                                             uint64_t *__restrict__ keys2, uint32_t *__restrict__ vals2) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) {
+        const uint64_t k = keys[j];
+        const uint32_t g = (uint32_t)(k >> 32);
+        const uint32_t K = (gq[g] & kPerBad) ? 0u : kraw[j];
+        keys2[j] = ((uint64_t)g << 32) | K;
+        vals2[j] = (uint32_t)k;
+    }
+}
+
+// the sorted view the regroup kernel takes, and the LCP of every boundary that appears inside an old group
+__global__ __launch_bounds__(kThreads) void per_view_kernel(const uint64_t *__restrict__ keys2,
+                                                            const uint32_t *__restrict__ vals2, uint32_t m,
+                                                            uint32_t *__restrict__ grp, uint32_t *__restrict__ lo,
+                                                            uint32_t *__restrict__ vals, uint32_t *__restrict__ lcp_list) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) {
+        const uint64_t k = keys2[j];
+        const uint32_t g = (uint32_t)(k >> 32), K = (uint32_t)k;
+        grp[j] = g;
+        lo[j] = K;
+        vals[j] = vals2[j];
+        uint32_t l = kLcpPending;
+        if (j > 0) {
+            const uint64_t kp = keys2[j - 1];
+            const uint32_t Kp = (uint32_t)kp;
+            if ((uint32_t)(kp >> 32) == g && Kp != K) {
+                const uint32_t ra = (Kp & 0x80000000u) ? ~Kp : Kp, rb = (K & 0x80000000u) ? ~K : K;
+                l = ra < rb ? ra : rb;
+            }
+        }
+        lcp_list[j] = l;
+    }
+}
+
+// Segmented sort of the active list by lo inside each group.  Groups are contiguous in the
+// list and (for real sequence data) almost all tiny, so each element finds its place by
+// counting the smaller members of its own group -- one pass, no radix passes.  Members of
+// groups larger than kSmallGroup are flagged for the radix fallback instead.
+constexpr uint32_t kSmallGroup = 64;
 
 __global__ __launch_bounds__(kThreads) void small_sort_kernel(const uint32_t *__restrict__ act_slot,
                                                               const uint32_t *__restrict__ act_grp,
@@ -1621,6 +1838,76 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         Plcp = build_pyramid(lcp, n + 1, false, arena, s);
     }
 
+    // ---- periodic runs: groups whose members lie one short period apart are ordered arithmetically ----
+    // (kernels and the argument above, "Periodic runs".  Tried when a large part of the text is still tied:
+    // once behind the direct round, and again in the doubling rounds when the depth has passed twice the
+    // shortest distance that was too long for it.  NOLZSS_NO_PERIODIC switches the pass off.)
+    static const bool periodic_off = getenv("NOLZSS_NO_PERIODIC") != nullptr;
+    uint32_t per_hint = 0;
+    int per_attempts = 0;
+    auto periodic_pass = [&]() -> bool {
+        if (periodic_off || m == 0 || n >= 0x80000000u || wlen < n || per_attempts >= 3) return false;
+        ProfScope ps(ctx.profiler(), "sa_periodic", s);
+        const uint32_t *slot = act_slot[a_cur], *grp = act_grp[a_cur];
+        if (per_attempts == 0) {
+            // worth its two sorts only where large groups hold a good part of what is tied: copies of long
+            // regions tie in groups of a few members (the pair-run pass takes those), runs of a short period
+            // in groups as large as the runs are long
+            HIP_CHECK(hipMemsetAsync(d_total + 3, 0, sizeof(uint32_t), s));
+            per_count_large_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(slot, grp, m, kRunGroupMax, d_total + 3);
+            KERNEL_CHECK();
+            uint32_t in_large = 0;
+            ctx.read_back(d_total + 3, &in_large, 1);
+            if (in_large < m / 8) {
+                per_attempts = 3;  // (never again for this text)
+                return false;
+            }
+        }
+        ++per_attempts;
+        uint32_t *PQ = tmp_a, *rev = tmp_b, *end_of = tmp_c, *gq = lo, *kraw = rank_val;
+        uint32_t *d_hint = d_total + 3;
+        const size_t lmark = arena.mark();
+        uint64_t *pk[2] = {arena.alloc<uint64_t>(m), arena.alloc<uint64_t>(m)};
+        uint32_t *pv[2] = {arena.alloc<uint32_t>(m), arena.alloc<uint32_t>(m)};
+        HIP_CHECK(hipMemsetAsync(gq, 0xff, (size_t)n * sizeof(uint32_t), s));
+        HIP_CHECK(hipMemsetAsync(PQ, 0, (size_t)n * sizeof(uint32_t), s));
+        HIP_CHECK(hipMemsetAsync(d_hint, 0xff, sizeof(uint32_t), s));
+        per_keys_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(slot, grp, m, sa, pk[0], pv[0]);
+        KERNEL_CHECK();
+        const int c = radix_sort_pairs(pk, pv, m, shifts, npasses, arena, s, ctx.profiler());
+        per_link_kernel<<<(unsigned)div_up(m, kThreads), kThreads, 0, s>>>(pk[c], m, gq);
+        KERNEL_CHECK();
+        const uint32_t half_depth = (uint32_t)std::min<uint64_t>(h / 2, 0x7ffffffeu);
+        per_flags_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(pk[c], m, gq, half_depth, PQ, d_hint);
+        KERNEL_CHECK();
+        per_breaks_kernel<<<grid_for(n, kThreads, 256u * 64u), kThreads, 0, s>>>(PQ, n, rev);
+        KERNEL_CHECK();
+        scan_inclusive_max_u32(rev, end_of, n, arena, s);
+        per_rho_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(pk[c], m, gq, PQ, end_of, rank, n, Plcp, kraw);
+        KERNEL_CHECK();
+        per_keys2_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(pk[c], m, gq, kraw, pk[c ^ 1], pv[c ^ 1]);
+        KERNEL_CHECK();
+        uint64_t *pk2[2] = {pk[c ^ 1], pk[c]};
+        uint32_t *pv2[2] = {pv[c ^ 1], pv[c]};
+        const int c2 = radix_sort_pairs(pk2, pv2, m, shifts, npasses, arena, s, ctx.profiler());
+        uint32_t *grp_sorted = tmp_a, *lcp_list = tmp_b;  // (PQ and rev are done)
+        per_view_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(pk2[c2], pv2[c2], m, grp_sorted, out_lo, out_vals, lcp_list);
+        KERNEL_CHECK();
+        arena.rewind(lmark);
+        uint32_t hint = 0;
+        ctx.read_back(d_hint, &hint, 1);
+        per_hint = hint == 0xffffffffu ? 0u : hint;
+        const uint32_t before = m;
+        m = regroup<false>(ctx, nullptr, grp_sorted, out_lo, out_vals, slot, m, n, sa, rank, act_slot[a_cur ^ 1],
+                           act_grp[a_cur ^ 1], scratch_idx, scratch_val, rank_val, d_total, lcp,
+                           0, 0, 0, lcp_list, 0, 0u, nullptr, &Plcp);
+        a_cur ^= 1;
+        if (trace) fprintf(stderr, "[nolzss]   periodic runs (depth %llu): %u of %u tied suffixes finished%s\n",
+                           (unsigned long long)h, before - m, before, per_hint ? " (a longer period waits for more depth)" : "");
+        return m < before - before / 8;
+    };
+    if (pair_runs) periodic_pass();
+
     // ---- long exact repeats: small groups along runs of text positions are finished arithmetically ---
     // (worth its passes over the text only when a large part of it is still tied; a pass that splits
     // groups without finishing them -- three copies, one of which differs behind the run -- is followed by
@@ -1679,6 +1966,10 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
 
     while (m > 0) {
         if (h >= n || rounds > 40) throw HipError("suffix array: prefix doubling failed to converge");
+        if (pair_runs && per_hint != 0 && h >= 2ull * per_hint && m >= n / 16) {
+            periodic_pass();
+            if (m == 0) break;
+        }
         const uint32_t *slot = act_slot[a_cur], *grp = act_grp[a_cur];
         {
             ProfScope ps(ctx.profiler(), "sa_round_keys", s);

@@ -264,3 +264,63 @@ print("ok", len(texts))
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
     done = [int(line.split("pair runs:")[1].split()[0]) for line in r.stderr.splitlines() if "pair runs:" in line]
     assert len(done) >= 15 and sum(done) > 100000, done  # the path ran and finished pairs
+
+
+def test_periodic_runs_pass():
+    """Runs of a short period tie the suffixes of a run in groups that only log2(run length) doubling
+    rounds would resolve; the periodic-run pass orders them arithmetically (suffix_array.hip, "Periodic
+    runs").  One child process with a tiny direct-round cap (NOLZSS_REFINE_WORDS=1: 49 symbols) and
+    NOLZSS_PAIR_RUNS_MIN=1 sends every run longer than that through the pass: single runs, several runs of
+    the same and of different periods, runs that break upwards / downwards / at the end of the text, runs
+    inside random text, Fibonacci words, other alphabets, reverse complement.  SA, ISA, LCP and the factors
+    are compared with the oracle."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys
+sys.path.insert(0, "tests")
+import numpy as np
+import gen, oracle_lib as oracle
+from nolzss_amd import _noLZSS as native
+rng = np.random.default_rng(9)
+def R(k, seed): return gen.random_dna(k, seed).tobytes()
+def fib(k):
+    a, b = b"A", b"AC"
+    while len(b) < k: a, b = b, b + a
+    return b[:k]
+texts = [
+    b"A" * 5000, b"AC" * 3000, b"ACG" * 2500 + b"T", (b"ACGTTGA" * 1500)[:9001], b"A" * 3000 + b"C" + b"A" * 2000,
+    b"A" * 2000 + b"C" + b"A" * 3000, b"AC" * 2000 + b"AA" + b"AC" * 1500, R(500, 1) + b"A" * 4000 + R(500, 2),
+    R(300, 3) + b"AC" * 1200 + R(200, 4) + b"AC" * 2100 + b"G" + b"CA" * 900 + R(100, 5),
+    R(100, 6) + b"T" * 1000 + R(50, 7) + b"T" * 1500 + R(50, 8) + b"T" * 1200 + R(70, 9) + b"T" * 999,
+    (R(23, 10) * 300) + R(40, 11) + (R(23, 10) * 200), (R(97, 12) * 90), (R(97, 12) * 90)[:-13] + b"G",
+    fib(20000), fib(6765) + b"C" + fib(4181), b"abcab" * 2000, b"ab" * 3000 + b"c" + b"ab" * 2500 + b"a",
+    bytes(range(65, 75)) * 800, (b"AAC" * 2000 + b"AAT" * 2000) * 2, b"G" * 7000 + b"A",
+    b"ACGT" * 1500 + b"ACGA" * 1500 + b"ACGT" * 700, R(2000, 13) * 5,
+]
+for k in range(12):   # random mixtures of runs
+    parts = []
+    for _ in range(int(rng.integers(2, 9))):
+        unit = R(int(rng.integers(1, 30)), 100 + int(rng.integers(0, 5)))
+        parts.append(unit * int(rng.integers(1, 400)))
+        if rng.random() < 0.6: parts.append(R(int(rng.integers(1, 200)), 200 + k))
+    texts.append(b"".join(parts))
+for t in texts:
+    d = native.debug_arrays(t)
+    sa = oracle.suffix_array(t)
+    assert np.array_equal(d["sa"].astype(np.int64), sa.astype(np.int64)), ("sa", len(t), t[:40])
+    lcp = oracle.lcp_array(t, sa)
+    assert np.array_equal(d["lcp"][:len(t)].astype(np.int64), lcp.astype(np.int64)), ("lcp", len(t), t[:40])
+    f, e = native.factorize_array(t), oracle.factors_array(t)
+    assert len(f) == len(e) and all(np.array_equal(f[k], e[k]) for k in ("start", "length", "ref")), ("factors", len(t), t[:40])
+for t in [b"A" * 3000 + b"T" * 3000, b"AC" * 2500 + b"GT" * 2500, R(50, 20) + b"AAG" * 1500 + R(60, 21) + b"CTT" * 1500]:
+    assert native.factorize_dna_w_rc(t) == oracle.factorize_dna_w_rc(t), ("rc", len(t))
+print("ok", len(texts))
+'''
+    env = dict(os.environ, NOLZSS_REFINE_WORDS="1", NOLZSS_PAIR_RUNS_MIN="1", NOLZSS_TRACE="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    done = [int(line.split("periodic runs")[1].split(":")[1].split()[0]) for line in r.stderr.splitlines() if "periodic runs" in line]
+    assert len(done) >= 20 and sum(done) > 50000, done  # the pass ran and finished suffixes
