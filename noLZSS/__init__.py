@@ -9,8 +9,8 @@ from the ctypes mirror `nolzss_amd._noLZSS` -- every one of them calls the same 
 (include/nolzss_hip.h) of libnolzss_hip.so.  There is no CPU fallback: without the compiled module or
 the HIP library the import fails.
 """
+from nolzss_amd import _noLZSS as _mirror  # first: loads libnolzss_hip.so (and the HIP runtime it shares with torch)
 from . import _noLZSS  # compiled (pybind11); ImportError if it has not been built
-from nolzss_amd import _noLZSS as _mirror
 
 _native_set_device = _noLZSS.set_device
 for _name in dir(_mirror):

@@ -39,12 +39,37 @@ class Factor(C.Structure):
     _fields_ = [("start", C.c_uint64), ("length", C.c_uint64), ("ref", C.c_uint64)]
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64; a process that initialises the system's HIP runtime
+    first (through this library) and torch's afterwards ends up with two runtimes, and torch then reports no
+    GPU.  When torch is installed, its runtime is loaded first so that libnolzss_hip.so binds to the same one
+    (the loader resolves the SONAME to the copy already in the process) -- whatever the import order.
+    NOLZSS_SYSTEM_HIP=1 keeps the system runtime."""
+    import importlib.util
+    import os
+    if os.environ.get("NOLZSS_SYSTEM_HIP"):
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.origin:
+        return
+    cand = Path(spec.origin).resolve().parent / "lib" / "libamdhip64.so"
+    if cand.exists():
+        try:
+            C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def _load():
     if not LIB_PATH.exists():
         raise ImportError(
             f"{LIB_PATH} not found: build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()' or make -C nolzss_amd/csrc). "
             "nolzss_amd has no CPU fallback.")
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(str(LIB_PATH))
     vp, sz = C.c_void_p, C.c_size_t
     szp, vpp = C.POINTER(C.c_size_t), C.POINTER(C.c_void_p)

@@ -312,3 +312,24 @@ def test_arenas_are_given_back_and_taken_again(pkg):
         os.environ.pop("NOLZSS_BATCH_MERGE_BELOW", None)
     assert c1 == c2
     assert native.count_factors(recs[0]) == c1[0]
+
+
+def test_factorize_device_is_ordered_behind_the_default_stream(pkg):
+    """nolzss_factorize_device with stream = NULL runs on the library's own non-blocking stream; it must wait
+    for what torch's default stream has queued (an asynchronous upload of the text, a kernel that writes it)
+    without the caller synchronising.  Also: importing the package first and torch second
+    must leave torch with its GPU (nolzss_amd/_lib.py shares torch's HIP runtime)."""
+    import torch
+    assert torch.cuda.is_available(), "torch lost the GPU to a second HIP runtime"
+    native = pkg._noLZSS
+    n = 1 << 24
+    text = gen.repeat_dna(n, 77, lo=16, hi=4096)
+    exp = oracle.count_factors(text)
+    pinned = torch.from_numpy(text).pin_memory()
+    for _ in range(3):
+        d = torch.empty(n, dtype=torch.uint8, device="cuda")
+        d.zero_()                                   # a kernel on the default stream ...
+        d.copy_(pinned, non_blocking=True)          # ... and an asynchronous upload behind it
+        z, _ = native.factorize_device(d.data_ptr(), n, emit=1)   # no torch.cuda.synchronize() in between
+        assert z == exp
+        del d
