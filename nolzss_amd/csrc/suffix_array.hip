@@ -817,8 +817,9 @@ __device__ __forceinline__ void lower_min(uint32_t *p, uint32_t v) {
 // text) the suffixes of a run tie on whatever depth h has been compared, in groups far larger than the
 // pair-run pass takes, and prefix doubling peels only h of them off per round: log2(run length) rounds over
 // everything.  The order inside such a group is arithmetic.  Let q be the smallest distance between two
-// members of a group in the text, q <= h / 2: the h symbols every member starts with then have period q, a
-// prefix of u^inf for one word u.  For a member x let rho(x) = q + lcp(x, x + q): the text keeps that period
+// members of a group in the text, q <= h: the h symbols every member starts with then have period q (two
+// members q apart agree on h symbols, so h + q symbols have that period, and every other member starts with
+// the same h symbols), a prefix of u^inf for one word u that those h >= q symbols determine.  For a member x let rho(x) = q + lcp(x, x + q): the text keeps that period
 // for exactly rho(x) symbols from x; at x + rho(x) it breaks -- with a symbol smaller than the periodic
 // continuation ("down", also when the text ends there) or larger ("up").  Two members with different rho
 // agree on min(rho) symbols and the one that breaks first goes down below / up above the other; so the group
@@ -829,8 +830,11 @@ __device__ __forceinline__ void lower_min(uint32_t *p, uint32_t v) {
 // group member q behind them, lcp(t, t + q) = 1 + lcp(t + 1, t + 1 + q), so it is the distance to the end E
 // of that run of positions plus lcp(E, E + q), and suffixes E and E + q are in DIFFERENT groups: their order
 // is the order of their rank codes and their LCP the range minimum of the decided LCP entries between them.
-// A group with a member for which that fails (E and E + q tied with each other), or with q > h / 2, is
-// left alone as a whole.
+// A group with a member for which that fails (E and E + q tied with each other) is left alone as a whole.
+// A group whose q exceeds the depth h compared so far (after the 17-base key sort a large group has only
+// been compared to depth 17: a 171-base satellite monomer, a period-1000 text) is taken if the TEXT shows
+// that its members agree on q symbols -- every member is compared with the next member of its group in text
+// order, q symbols deep (per_verify_kernel; q <= kPerVerifyMax) -- and left to the doubling rounds otherwise.
 // ---------------------------------------------------------------------------------------
 constexpr uint32_t kPerNone = 0xffffffffu;   // gq: no distance seen yet
 constexpr uint32_t kPerBad = 0x80000000u;    // gq: flag "leave this group alone" (positions are below 2^31 here)
@@ -908,6 +912,34 @@ __global__ __launch_bounds__(kThreads) void per_link_kernel(const uint64_t *__re
 // PQ[pos] = q for a member whose next group member is exactly q behind it, q = the group's distance (0 for
 // everything else; the array was cleared).  Groups whose q exceeds half the depth compared so far are
 // flagged; the smallest such q is reported (hint: try again when the depth has passed twice that).
+constexpr uint32_t kPerVerifyMax = 4096;  // longest period whose groups are checked against the text
+
+// members of groups with depth < q <= kPerVerifyMax: do I agree with the next member of my group (in text
+// order) on q symbols?  If every such pair does, all members agree on q symbols.  Pairs exactly q apart need
+// no text: lcp(x, x + q) = (E - x) + lcp(E, E + q) is known from the run of positions (per_rho_kernel).
+template <int BITS>
+__global__ __launch_bounds__(kThreads) void per_verify_kernel(const uint64_t *__restrict__ keys, uint32_t m,
+                                                              uint32_t *__restrict__ gq, uint32_t depth, uint32_t n,
+                                                              const uint64_t *__restrict__ words, TermTable terms) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j + 1 < m; j += stride) {
+        const uint64_t k = keys[j], k2 = keys[j + 1];
+        const uint32_t g = (uint32_t)(k >> 32);
+        if ((uint32_t)(k2 >> 32) != g) continue;
+        const uint32_t gv = *reinterpret_cast<volatile uint32_t *>(&gq[g]);
+        if (gv & kPerBad) continue;
+        const uint32_t q = gv;
+        if (q <= depth || q > kPerVerifyMax) continue;
+        // (plain texts only: the later member is the shorter suffix, so "agrees on min(q, what the later one has
+        // left)" carries from pair to pair -- every member starts with the group's period word as far as it goes)
+        const uint32_t b = (uint32_t)k2, left = n - b, need = q < left ? q : left;
+        // (a pair exactly q apart is checked without the text, from the length of its run of positions:
+        // per_rho_kernel; what is compared here are the few pairs that join two runs)
+        if (b - (uint32_t)k == q) continue;
+        if (suffix_lcp<BITS>(words, terms, (uint32_t)k, b, 0u, q) < need) atomicOr(&gq[g], kPerBad);
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void per_flags_kernel(const uint64_t *__restrict__ keys, uint32_t m,
                                                              uint32_t *__restrict__ gq, uint32_t half_depth,
                                                              uint32_t *__restrict__ PQ, uint32_t *__restrict__ hint) {
@@ -950,7 +982,7 @@ __global__ __launch_bounds__(kThreads) void per_rho_kernel(const uint64_t *__res
                                                            uint32_t *__restrict__ gq, const uint32_t *__restrict__ PQ,
                                                            const uint32_t *__restrict__ end_of,
                                                            const uint32_t *__restrict__ rank, uint32_t n, Pyramid Plcp,
-                                                           uint32_t *__restrict__ kraw) {
+                                                           uint32_t depth, uint32_t *__restrict__ kraw) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) {
         const uint64_t k = keys[j];
@@ -964,10 +996,17 @@ __global__ __launch_bounds__(kThreads) void per_rho_kernel(const uint64_t *__res
         if (PQ[pos] == q) E = ((n - 1) - (end_of[n - 1 - pos] - 1u)) + 1u;
         bool ok = E < n;
         uint32_t lam = 0, c1 = 0, c2 = 0;
+        if (ok && (uint64_t)E + q >= n) {
+            // the text ends before suffix E has seen a whole period (only a member without a next member:
+            // E = pos): periodic as far as it goes, and the end sorts first
+            const uint32_t full = (E - pos) + q, left = n - pos;
+            kraw[j] = full < left ? full : left;
+            continue;
+        }
         if (ok) {
             c1 = rank[E];
             const uint64_t e2 = (uint64_t)E + q;
-            c2 = e2 < n ? rank[e2] : 0u;  // past the end: sorts first, shares nothing
+            c2 = e2 < n ? rank[e2] : 0u;  // (e2 < n here)
             if (c1 == c2) {
                 ok = false;  // tied with each other: nothing is known about them yet
             } else if (c2 != 0) {
@@ -979,6 +1018,15 @@ __global__ __launch_bounds__(kThreads) void per_rho_kernel(const uint64_t *__res
         if (!ok) {
             atomicOr(&gq[g], kPerBad);
             continue;
+        }
+        // a group taken on a period longer than the depth compared so far: this member and the next one
+        // (q behind it) must agree on q symbols, or as far as the later one goes
+        if (q > depth && E != pos) {
+            const uint32_t left = n - (pos + q), need = q < left ? q : left;
+            if ((E - pos) + lam < need) {
+                atomicOr(&gq[g], kPerBad);
+                continue;
+            }
         }
         const uint32_t rho = (E - pos) + lam + q;  // <= n - pos
         kraw[j] = c2 < c1 ? rho : ~rho;            // down (suffix E + q is the smaller one) : up
@@ -1840,7 +1888,7 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
 
     // ---- periodic runs: groups whose members lie one short period apart are ordered arithmetically ----
     // (kernels and the argument above, "Periodic runs".  Tried when a large part of the text is still tied:
-    // once behind the direct round, and again in the doubling rounds when the depth has passed twice the
+    // once behind the direct round, and again in the doubling rounds when the depth has reached the
     // shortest distance that was too long for it.  NOLZSS_NO_PERIODIC switches the pass off.)
     static const bool periodic_off = getenv("NOLZSS_NO_PERIODIC") != nullptr;
     uint32_t per_hint = 0;
@@ -1877,13 +1925,24 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         const int c = radix_sort_pairs(pk, pv, m, shifts, npasses, arena, s, ctx.profiler());
         per_link_kernel<<<(unsigned)div_up(m, kThreads), kThreads, 0, s>>>(pk[c], m, gq);
         KERNEL_CHECK();
-        const uint32_t half_depth = (uint32_t)std::min<uint64_t>(h / 2, 0x7ffffffeu);
-        per_flags_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(pk[c], m, gq, half_depth, PQ, d_hint);
+        const uint32_t depth = (uint32_t)std::min<uint64_t>(h, 0x7ffffffeu);
+        const bool can_verify = text.terms.count == 1;  // (one segment: see per_verify_kernel)
+        if (can_verify && depth < kPerVerifyMax) {  // longer periods than the depth: taken if the text confirms them
+            const unsigned gv = grid_for(m, kThreads, 256u * 64u);
+            switch (text.bits) {
+            case 2: per_verify_kernel<2><<<gv, kThreads, 0, s>>>(pk[c], m, gq, depth, n, text.words, text.terms); break;
+            case 4: per_verify_kernel<4><<<gv, kThreads, 0, s>>>(pk[c], m, gq, depth, n, text.words, text.terms); break;
+            default: per_verify_kernel<8><<<gv, kThreads, 0, s>>>(pk[c], m, gq, depth, n, text.words, text.terms); break;
+            }
+            KERNEL_CHECK();
+        }
+        // (groups the text check has flagged are out; the others pass up to kPerVerifyMax, beyond it up to the depth)
+        per_flags_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(pk[c], m, gq, (can_verify && depth < kPerVerifyMax) ? kPerVerifyMax : depth, PQ, d_hint);
         KERNEL_CHECK();
         per_breaks_kernel<<<grid_for(n, kThreads, 256u * 64u), kThreads, 0, s>>>(PQ, n, rev);
         KERNEL_CHECK();
         scan_inclusive_max_u32(rev, end_of, n, arena, s);
-        per_rho_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(pk[c], m, gq, PQ, end_of, rank, n, Plcp, kraw);
+        per_rho_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(pk[c], m, gq, PQ, end_of, rank, n, Plcp, depth, kraw);
         KERNEL_CHECK();
         per_keys2_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(pk[c], m, gq, kraw, pk[c ^ 1], pv[c ^ 1]);
         KERNEL_CHECK();
@@ -1966,7 +2025,7 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
 
     while (m > 0) {
         if (h >= n || rounds > 40) throw HipError("suffix array: prefix doubling failed to converge");
-        if (pair_runs && per_hint != 0 && h >= 2ull * per_hint && m >= n / 16) {
+        if (pair_runs && per_hint != 0 && h >= per_hint && m >= n / 16) {
             periodic_pass();
             if (m == 0) break;
         }

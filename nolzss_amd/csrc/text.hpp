@@ -93,14 +93,15 @@ __device__ __forceinline__ uint64_t sym_word(const uint64_t *__restrict__ w, uin
 
 // Common prefix length of suffixes a and b of the packed text, starting the comparison at
 // offset h0 (caller guarantees the first min(h0, limit) symbols match), capped at the nearer
-// terminator.
+// terminator and at `cap`.
 template <int BITS>
 __device__ __forceinline__ uint32_t suffix_lcp(const uint64_t *__restrict__ w, const TermTable &terms,
-                                               uint32_t a, uint32_t b, uint32_t h0) {
+                                               uint32_t a, uint32_t b, uint32_t h0, uint32_t cap = 0xffffffffu) {
     constexpr uint32_t kPerWord = 64 / BITS;
     const uint32_t la = terms.pos[term_lower_bound(terms, a)] - a;
     const uint32_t lb = terms.pos[term_lower_bound(terms, b)] - b;
-    const uint32_t limit = la < lb ? la : lb;
+    uint32_t limit = la < lb ? la : lb;
+    limit = limit < cap ? limit : cap;  // (the result is capped too)
     if (h0 >= limit) return limit;
     uint32_t h = h0;
     while (h < limit) {

@@ -272,7 +272,7 @@ def test_periodic_runs_pass():
     runs").  One child process with a tiny direct-round cap (NOLZSS_REFINE_WORDS=1: 49 symbols) and
     NOLZSS_PAIR_RUNS_MIN=1 sends every run longer than that through the pass: single runs, several runs of
     the same and of different periods, runs that break upwards / downwards / at the end of the text, runs
-    inside random text, Fibonacci words, other alphabets, reverse complement.  SA, ISA, LCP and the factors
+    inside random text, periods longer than the depth compared so far (with runs that only look alike), Fibonacci words, other alphabets, reverse complement.  SA, ISA, LCP and the factors
     are compared with the oracle."""
     import os
     import subprocess
@@ -299,6 +299,11 @@ texts = [
     bytes(range(65, 75)) * 800, (b"AAC" * 2000 + b"AAT" * 2000) * 2, b"G" * 7000 + b"A",
     b"ACGT" * 1500 + b"ACGA" * 1500 + b"ACGT" * 700, R(2000, 13) * 5,
 ]
+# periods longer than the depth compared so far (cap 49): taken only if the members really agree on a period
+U = R(60, 30); V = bytearray(U); V[50] = ord("A") if V[50] != ord("A") else ord("C"); V = bytes(V)
+W = R(171, 31)
+texts += [U * 50, U * 40 + R(77, 32) + U * 35, U * 40 + R(77, 33) + V * 40, V * 30 + U * 45, (U * 30)[:-7], W * 40,
+          W * 25 + R(30, 34) + W * 30 + b"A", R(40, 35) + (U * 33)[5:] + R(3, 36) + U * 20]
 for k in range(12):   # random mixtures of runs
     parts = []
     for _ in range(int(rng.integers(2, 9))):
