@@ -1575,6 +1575,7 @@ void finish_packing(Context &ctx, PackedText &t, const uint8_t *d_text, size_t n
     HIP_CHECK(hipStreamSynchronize(s));  // table is a local vector
     t.terms.pos = d_terms;
     t.terms.count = (uint32_t)table.size();
+    t.terms.end = (uint32_t)n;
     if (table.size() > 256) {
         const uint32_t blocks = (uint32_t)(n >> kTermBlockShift) + 3;
         uint32_t *coarse = ctx.arena.alloc<uint32_t>(blocks);

@@ -30,6 +30,7 @@ constexpr int kIndSyms = 12, kIndTagBits = 4, kIndKeyBits = kIndSyms * 2 + kIndT
 struct TermTable {
     const uint32_t *pos = nullptr;  // sorted terminator positions, pos[count-1] = n
     uint32_t count = 0;
+    uint32_t end = 0;               // n (= pos[count - 1]): a text of one segment needs no table look-up
     // optional (tables with many terminators): coarse[b] = smallest k with pos[k] >= b << kTermBlockShift,
     // clamped to count - 1; (n >> kTermBlockShift) + 3 entries
     const uint32_t *coarse = nullptr;
@@ -160,8 +161,10 @@ template <int BITS>
 __device__ __forceinline__ uint64_t initial_key(const uint64_t *__restrict__ words, const TermTable &terms,
                                                 bool segmented, uint32_t i) {
     const uint64_t w = sym_word<BITS>(words, i);
-    const uint32_t k = term_lower_bound(terms, i);
-    const uint32_t lim = terms.pos[k] - i;  // symbols before the next terminator
+    // (one segment: no search and, above all, no load that the key would have to wait for behind its text
+    // window -- the first radix pass generates 2^30 keys)
+    const uint32_t k = terms.count == 1 ? 0u : term_lower_bound(terms, i);
+    const uint32_t lim = (terms.count == 1 ? terms.end : terms.pos[k]) - i;  // symbols before the next terminator
     if (BITS == 2 && segmented && terms.seq_shift == 0) {
         const uint32_t tag = lim < (uint32_t)kSegSyms ? lim : (uint32_t)kSegSyms;
         uint64_t sym = w >> (64 - kSegSyms * 2);
