@@ -1138,17 +1138,26 @@ __global__ __launch_bounds__(kThreads) void small_sort_kernel(const uint32_t *__
 //   * cls = number of strictly smaller members; members still tied at the end keep list order.
 // A group whose pairs do not fit the list any more is left as it is (out_lo = 0): the doubling
 // rounds handle it like any other unfinished group.
-constexpr int kRefineTile = 256;
+// 192 list positions + the 64-member span = 256 threads: four wavefronts, one per SIMD, 8 workgroups per CU.
+// (Round 1 ran 256 + 64 = 320 threads: five wavefronts load the SIMDs unevenly and every workgroup stayed for
+// 6.25 comparison rounds on average -- as long as its slowest member; phase clocks, NOLZSS_REFINE_PHASES:
+// set-up 6.7 k, fetch 12.4 k, compare 13.7 k cycles.  128 / 192 / 256 / 320 positions: 25.5 / 24.5 / 30.8 / 30.6 ms;
+// 192 with the pair list cut to 20 KiB of LDS per workgroup (8 instead of 7 per CU): 22.1 ms.)
+constexpr int kRefineTile = 192;
 constexpr int kRefineThreads = kRefineTile + (int)kSmallGroup;  // one thread per possible member
 constexpr int kRefineWaves = kRefineThreads / 64;
 constexpr int kRefineWords = 4;
-constexpr int kPairCap = 2432;  // pairs per workgroup (256 members in groups of up to ~20 fit; 6 workgroups per CU)
+constexpr int kPairCap = 1664;  // pairs per workgroup (192 members in groups of up to ~18 fit); 20 KiB of LDS: 8 workgroups = 32 waves per CU
 
-template <int BITS>
+template <int BITS, bool kTimed>
 __global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void group_refine_kernel(
     const uint32_t *__restrict__ act_slot, const uint32_t *__restrict__ act_grp, uint32_t *sa,
     const uint64_t *__restrict__ words, TermTable terms, uint32_t m, uint32_t h0, uint32_t cap,
-    uint32_t *__restrict__ out_lo, uint32_t *__restrict__ lcp_list, uint32_t *__restrict__ min_depth) {
+    uint32_t *__restrict__ out_lo, uint32_t *__restrict__ lcp_list, uint32_t *__restrict__ min_depth,
+    unsigned long long *__restrict__ phases) {
+    const bool timed = kTimed && phases != nullptr && (blockIdx.x & 31) == 0 && threadIdx.x == 0;
+    unsigned long long ck0 = 0, ck_fetch = 0, ck_cmp = 0, ck_rounds = 0, ck1 = 0, ck2 = 0;
+    if (timed) ck0 = __builtin_readcyclecounter();
     constexpr int kW32 = 2 * kRefineWords;  // window in 32-bit words, text order
     constexpr int kChunks = kW32 / 4;
     constexpr uint32_t kPer32 = 32 / BITS;
@@ -1247,6 +1256,7 @@ __global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(
         for (int y = 0; y < my_j; ++y) s_pair[my_off + y] = (uint32_t)t | ((uint32_t)(my_gl + y) << 16);
     s_tied[0][t] = handled ? 1 : 0;
     __syncthreads();
+    if (timed) ck1 = __builtin_readcyclecounter();
     // each wavefront owns a stretch of the pair list
     const uint32_t seg = ((npairs + kRefineWaves - 1) / kRefineWaves + 63u) & ~63u;
     const uint32_t seg0 = (uint32_t)w * seg;
@@ -1281,7 +1291,9 @@ __global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(
                     s_w[c][t] = make_uint4(win[4 * c], win[4 * c + 1], win[4 * c + 2], win[4 * c + 3]);
             }
             s_tied[cur ^ 1][t] = 0;
+            unsigned long long ca = timed ? __builtin_readcyclecounter() : 0;
             __syncthreads();
+            unsigned long long cb = timed ? __builtin_readcyclecounter() : 0;
 
             uint32_t kept = 0;
             bool any_tie = false;
@@ -1345,10 +1357,12 @@ __global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(
             // comparing on to the cap would cost a window fetch per member per round for nothing.
             // Leave those ties to the doubling rounds, which need only log2(LCP) steps.
             const int busy = __syncthreads_count(any_tie);
+            if (timed) { const unsigned long long cc = __builtin_readcyclecounter(); ck_fetch += cb - (ck2 ? ck2 : ck1); ck_cmp += cc - cb; ck2 = cc; ck_rounds += 1; (void)ca; }
             if (busy == 0 || (h >= h0 + kPerRound && busy > kRefineThreads / 4)) break;
         }
     }
 
+    const unsigned long long ck3 = timed ? __builtin_readcyclecounter() : 0;
     if (cnt > 0 && lane == 0) lower_min(min_depth, depth);
     // ---- members still tied keep their list order: count the tied partners in front of me --------
     // (s_goff is free now)
@@ -1368,6 +1382,17 @@ __global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(
         // LCP to the predecessor in the new order: the closest smaller member shares the
         // longest prefix; a tied predecessor (then this is not a new head) stays pending
         lcp_list[pos] = ties_before ? kLcpPending : s_best[t];
+    }
+    if (timed) {
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned long long ck4 = __builtin_readcyclecounter();
+        atomicAdd(phases + 0, ck1 - ck0);
+        atomicAdd(phases + 1, ck_fetch);
+        atomicAdd(phases + 2, ck_cmp);
+        atomicAdd(phases + 3, ck4 - ck3);
+        atomicAdd(phases + 4, ck_rounds);
+        atomicAdd(phases + 5, 1ull);
+        atomicAdd(phases + 6, ck4 - ck0);
     }
 }
 
@@ -1816,21 +1841,35 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         {
             ProfScope ps(ctx.profiler(), "sa_direct_sort", s);
             const unsigned g = (unsigned)div_up(m, kRefineTile);
+            static const bool want_rphases = getenv("NOLZSS_REFINE_PHASES") != nullptr;
+            unsigned long long *rphases = nullptr;
+            if (want_rphases) {
+                rphases = arena.alloc<unsigned long long>(8);
+                HIP_CHECK(hipMemsetAsync(rphases, 0, 64, s));
+            }
             switch (text.bits) {
             case 2:
-                group_refine_kernel<2><<<g, kRefineThreads, 0, s>>>(slot, grp, sa, text.words, text.terms, m, (uint32_t)h, cap,
-                                                              out_lo, lcp_list, d_min_depth);
+                if (rphases) group_refine_kernel<2, true><<<g, kRefineThreads, 0, s>>>(slot, grp, sa, text.words, text.terms, m, (uint32_t)h, cap, out_lo, lcp_list, d_min_depth, rphases);
+                else group_refine_kernel<2, false><<<g, kRefineThreads, 0, s>>>(slot, grp, sa, text.words, text.terms, m, (uint32_t)h, cap, out_lo, lcp_list, d_min_depth, nullptr);
                 break;
             case 4:
-                group_refine_kernel<4><<<g, kRefineThreads, 0, s>>>(slot, grp, sa, text.words, text.terms, m, (uint32_t)h, cap,
-                                                              out_lo, lcp_list, d_min_depth);
+                if (rphases) group_refine_kernel<4, true><<<g, kRefineThreads, 0, s>>>(slot, grp, sa, text.words, text.terms, m, (uint32_t)h, cap, out_lo, lcp_list, d_min_depth, rphases);
+                else group_refine_kernel<4, false><<<g, kRefineThreads, 0, s>>>(slot, grp, sa, text.words, text.terms, m, (uint32_t)h, cap, out_lo, lcp_list, d_min_depth, nullptr);
                 break;
             default:
-                group_refine_kernel<8><<<g, kRefineThreads, 0, s>>>(slot, grp, sa, text.words, text.terms, m, (uint32_t)h, cap,
-                                                              out_lo, lcp_list, d_min_depth);
+                if (rphases) group_refine_kernel<8, true><<<g, kRefineThreads, 0, s>>>(slot, grp, sa, text.words, text.terms, m, (uint32_t)h, cap, out_lo, lcp_list, d_min_depth, rphases);
+                else group_refine_kernel<8, false><<<g, kRefineThreads, 0, s>>>(slot, grp, sa, text.words, text.terms, m, (uint32_t)h, cap, out_lo, lcp_list, d_min_depth, nullptr);
                 break;
             }
             KERNEL_CHECK();
+            if (rphases) {
+                unsigned long long hp[8];
+                HIP_CHECK(hipMemcpyAsync(hp, rphases, 64, hipMemcpyDeviceToHost, s));
+                HIP_CHECK(hipStreamSynchronize(s));
+                const double wn = hp[5] ? (double)hp[5] : 1.0;
+                fprintf(stderr, "[nolzss] group_refine phases (cycles per workgroup, %llu sampled): set-up %.0f  fetch+wait %.0f  compare %.0f  output %.0f  total %.0f  rounds %.2f\n",
+                        hp[5], hp[0] / wn, hp[1] / wn, hp[2] / wn, hp[3] / wn, hp[6] / wn, hp[4] / wn);
+            }
         }
         m = regroup<false>(ctx, nullptr, grp, out_lo, nullptr, slot, m, n, sa, rank, act_slot[a_cur ^ 1],
                            act_grp[a_cur ^ 1], nullptr, nullptr, nullptr, d_total, lcp,
