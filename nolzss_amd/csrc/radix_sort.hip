@@ -357,7 +357,10 @@ __global__ __launch_bounds__(kThreads) void plain_scatter_kernel(const uint32_t 
 constexpr int kWindowBitsMax = 14;  // 2^14 entries = 64 KiB of LDS
 
 // permutation scatter, final step: the pairs of window w sit at list positions [w*W, (w+1)*W)
-__global__ __launch_bounds__(kThreads) void window_scatter_kernel(const uint32_t *__restrict__ idx,
+// (IdxT = uint16_t: the last partition pass kept only the low 16 bits of every index -- what lies above the
+// window bits is implied by the position in the list)
+template <typename IdxT>
+__global__ __launch_bounds__(kThreads) void window_scatter_kernel(const IdxT *__restrict__ idx,
                                                                   const uint32_t *__restrict__ val,
                                                                   uint32_t *__restrict__ out, uint32_t n_out,
                                                                   int window_bits) {
@@ -372,13 +375,13 @@ __global__ __launch_bounds__(kThreads) void window_scatter_kernel(const uint32_t
 #pragma unroll
         for (int j = 0; j < kBatch; ++j) {
             const uint32_t t = t0 + (uint32_t)j * kThreads + threadIdx.x;
-            ii[j] = t < len ? idx[base + t] : 0u;
+            ii[j] = t < len ? (uint32_t)idx[base + t] : 0u;
             vv[j] = t < len ? val[base + t] : 0u;
         }
 #pragma unroll
         for (int j = 0; j < kBatch; ++j) {
             const uint32_t t = t0 + (uint32_t)j * kThreads + threadIdx.x;
-            if (t < len) s_out[ii[j] - (uint32_t)base] = vv[j];
+            if (t < len) s_out[ii[j] & (W - 1u)] = vv[j];  // (the window starts at a multiple of W)
         }
     }
     __syncthreads();
@@ -404,12 +407,20 @@ void bucketed_scatter(uint32_t *idx[2], uint32_t *val[2], size_t count, uint32_t
         radix_sort_pairs(idx, val, count, shifts, 1, arena, stream, prof);
         uint32_t *idx2[2] = {idx[1], keep_input ? arena.alloc<uint32_t>(count) : idx[0]};
         uint32_t *val2[2] = {val[1], (keep_input && keep_val) ? arena.alloc<uint32_t>(count) : val[0]};
-        radix_sort_pairs(idx2, val2, count, shifts + 1, 1, arena, stream, prof);
+        // second pass (top digit): only the low 16 bits of an index travel on -- the window scatter needs the
+        // bits below the window size, and everything above them is the position in the list (6 instead of 8
+        // bytes per pair written here and read there)
+        uint16_t *idx16 = reinterpret_cast<uint16_t *>(idx2[1]);
         {
-            ProfScope ps(prof, "window_scatter", stream, 12.0 * (double)count);
+            const uint32_t num_tiles = (uint32_t)div_up(count, kTile);
+            uint32_t *hist = arena.alloc<uint32_t>((size_t)kBins * num_tiles);
+            radix_pass<uint32_t, uint16_t>(ArraySrc<uint32_t>{idx2[0], val2[0]}, idx16, val2[1], count, shifts[1], hist,
+                                           num_tiles, 4.0 * (double)count, 14.0 * (double)count, arena, stream, prof);
+        }
+        {
+            ProfScope ps(prof, "window_scatter", stream, 10.0 * (double)count);
             const uint32_t W = 1u << wb;
-            window_scatter_kernel<<<(unsigned)div_up(n_out, W), kThreads, 0, stream>>>(idx2[1], val2[1], out, n_out,
-                                                                                    wb);
+            window_scatter_kernel<uint16_t><<<(unsigned)div_up(n_out, W), kThreads, 0, stream>>>(idx16, val2[1], out, n_out, wb);
             KERNEL_CHECK();
         }
         arena.rewind(amark);
