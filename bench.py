@@ -85,6 +85,23 @@ def cpu_baseline(text: np.ndarray, sample: int):
             "sample": f"first {sample} bases of the rank-0 sequence, count_factors, {dt:.1f} s, z={z}"}
 
 
+def cpu_baseline_fasta(a):
+    """The FASTA shard on the host: the oracle on a bounded sample of the same records, one record per
+    thread on all cores (the reference's own per-sequence work queue, parallel_fasta_processor.cpp:360-385)."""
+    import oracle_lib as oracle  # checker only: never on the measured path
+    cores = os.cpu_count() or 1
+    L = 1 << a.fasta_record_log2
+    sample = min(a.fasta_records, 2 * cores)
+    recs = [gen.random_dna(L, 0x4000 + j) for j in range(sample)]
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as pool:  # (the oracle releases the GIL: ctypes)
+        zs = list(pool.map(oracle.count_factors, recs))
+    dt = time.perf_counter() - t0
+    return {"value": sample * L / dt, "unit": "bases/s", "cores": cores, "kind": "port",
+            "sample": f"the first {sample} of the {a.fasta_records} records, count_factors, one record per thread, "
+                      f"{dt:.1f} s, z[0]={zs[0]}"}
+
+
 class Job:
     """rank / world / collectives of this process"""
 
@@ -350,6 +367,8 @@ def main():
     if a.workload == "fasta512":
         a.fasta_steps, a.fasta_warmup = a.steps, a.warmup
         fa = run_fasta_shard(job, a, with_file=True)
+        if job.rank == 0 and job.world == 1 and not a.no_cpu_baseline:
+            fa["cpu_baseline"] = cpu_baseline_fasta(a)
         if job.rank == 0:
             out = {"metric": "bases/sec factorized (multi-sequence FASTA shard, 512 x 4 Mi bases) + HBM GB/s fraction",
                    "value": fa["value"], "unit": "bases/s", "n_gpus": job.world, "steps": a.steps, "warmup": a.warmup,

@@ -333,3 +333,44 @@ def test_factorize_device_is_ordered_behind_the_default_stream(pkg):
         z, _ = native.factorize_device(d.data_ptr(), n, emit=1)   # no torch.cuda.synchronize() in between
         assert z == exp
         del d
+
+
+def test_native_fasta_shards_and_device_batch(pkg, tmp_path):
+    """the sharded form of the native FASTA entry point (nolzss_read_nucleotide_fasta with shard_index /
+    shard_count: what every rank of a multi-GPU job calls) and the device-resident batch of bench.py, on one
+    GPU: the shards partition the records by the LPT plan and together give the counts of the unsharded call"""
+    import torch
+    native = pkg._noLZSS
+    recs = [(f"r{k}", gen.repeat_dna(30_000 + 7_919 * (k % 5), 300 + k, lo=16, hi=2048)) for k in range(11)]
+    path = tmp_path / "shards.fa"
+    gen.write_fasta(path, recs)
+    ids, lens, counts, owners, arrays = native.read_nucleotide_fasta_arrays(path)
+    assert ids == [r for r, _ in recs] and lens == [len(s) for _, s in recs] and owners == [0] * len(recs)
+    expected = [oracle.count_factors(s) for _, s in recs]
+    assert counts == expected
+    for a, (_, s) in zip(arrays, recs):
+        e = oracle.factors_array(s)
+        assert all(np.array_equal(a[k], e[k]) for k in ("start", "length", "ref"))
+    world = 3
+    seen = [0] * len(recs)
+    total = [0] * len(recs)
+    for rank in range(world):
+        ids_r, lens_r, counts_r, owners_r, arrays_r = native.read_nucleotide_fasta_arrays(
+            path, want_factors=True, shard_index=rank, shard_count=world)
+        assert ids_r == ids and lens_r == lens
+        assert owners_r == native.debug_lpt_plan(lens, world)          # the same plan on every rank
+        for j, o in enumerate(owners_r):
+            if o == rank:
+                seen[j] += 1
+                total[j] += counts_r[j]
+                assert len(arrays_r[j]) == expected[j]
+            else:
+                assert counts_r[j] == 0 and arrays_r[j] is None
+    assert seen == [1] * len(recs) and total == expected               # disjoint cover, same counts
+    with pytest.raises(ValueError):
+        native.read_nucleotide_fasta_arrays(path, shard_index=3, shard_count=3)
+    # records resident in device memory (bench.py's fasta512 form)
+    d = [torch.from_numpy(s).cuda() for _, s in recs]
+    torch.cuda.synchronize()
+    for emit in (0, 1):
+        assert native.factorize_batch_device([t.data_ptr() for t in d], lens, emit=emit) == expected
