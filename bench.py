@@ -89,7 +89,8 @@ def cpu_baseline_fasta(a):
     """The FASTA shard on the host: the oracle on a bounded sample of the same records, one record per
     thread on all cores (the reference's own per-sequence work queue, parallel_fasta_processor.cpp:360-385)."""
     import oracle_lib as oracle  # checker only: never on the measured path
-    cores = os.cpu_count() or 1
+    # (the box's share of host cores for one GPU is 16, whatever os.cpu_count() says)
+    cores = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
     L = 1 << a.fasta_record_log2
     sample = min(a.fasta_records, 2 * cores)
     recs = [gen.random_dna(L, 0x4000 + j) for j in range(sample)]
