@@ -35,7 +35,9 @@ acc = collections.defaultdict(lambda: collections.defaultdict(float)); calls = c
 for f in glob.glob(root + "/p*/**/*counter_collection.csv", recursive=True):
     seen = set()
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0][-60:]
+        import re
+        m = re.search(r"([A-Za-z_0-9]+_kernel)", r["Kernel_Name"])  # (the names start with "void nolzss::(anonymous namespace)::")
+        k = m.group(1) if m else r["Kernel_Name"][:60]
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         seen.add((k, r["Dispatch_Id"]))
     for k, _ in seen: calls[(k, f)] += 1
