@@ -10,7 +10,7 @@
 //     aligned block of 16 staged ranks the min (max) suffix start and the min LCP crossed passing it;
 //   * round 0: every lane advances each of its searches by 4 steps, branch-free (ends 4 of 5);
 //   * unfinished searches are compacted (ballot + popcount) into a per-wave work list in LDS and taken 64
-//     at a time: 16 more steps (round A), then 16 BLOCKS nearest first (round B), then the 16 ranks of the
+//     at a time: 12 more steps (round A), then 16 BLOCKS nearest first (round B), then the 16 ranks of the
 //     block that stops the search (round C) -- see lds_search_wave_blocks below;
 //   * a search that leaves the reach keeps its running LCP minimum as a bound (far_mark): the rank
 //     is finished from global memory with the pyramids only if that bound can still win.
@@ -145,7 +145,10 @@ __device__ __forceinline__ int lds_scan_round(const uint32_t *s_sa, const uint32
 constexpr int kBlk = 16;
 constexpr int kNumBlk = kLdsSpan / kBlk;  // 96
 static_assert(kLdsSpan % kBlk == 0 && kLdsReach % kBlk == 0 && kLdsTile % kBlk == 0, "aligned blocks");
-constexpr int kStepA = 16;
+constexpr int kStepA = 12;
+// (the first block of round B is the aligned block that holds the first rank not passed yet: it may reach back over
+// passed ranks, never to the rank itself)
+static_assert(kLdsStep0 + kStepA + 1 >= kBlk, "round B would look at the rank itself and at ranks on its other side");
 
 struct BlockTables {
     uint32_t *mn, *mx;    // min / max suffix start of the block (mx may be null)
