@@ -1650,7 +1650,7 @@ void factorize_many(const uint8_t *const *texts, const size_t *lens, size_t m, c
     // every lane with its own stream and arena, fed from the device's queue.
     static const size_t lanes = [] {
         const char *e = getenv("NOLZSS_BATCH_LANES");
-        const long v = e ? atol(e) : 4;
+        const long v = e ? atol(e) : 8;
         return (size_t)(v < 1 ? 1 : (v > kMaxLanes ? kMaxLanes : v));
     }();
     std::vector<int> status(n_dev * lanes, NOLZSS_OK);
@@ -1766,7 +1766,7 @@ int nolzss_factorize_batch_device(const void *const *d_texts, const size_t *lens
         std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return lens[a] > lens[b]; });
         static const size_t lanes_env = [] {
             const char *e = getenv("NOLZSS_BATCH_LANES");
-            const long v = e ? atol(e) : 4;
+            const long v = e ? atol(e) : 8;
             return (size_t)(v < 1 ? 1 : (v > kMaxLanes ? kMaxLanes : v));
         }();
         size_t lanes = std::min(lanes_env, m ? m : (size_t)1);
