@@ -1541,6 +1541,130 @@ bool run_merged_chunk(Context &ctx, const uint8_t *const *texts, const size_t *l
     return true;
 }
 
+// ---- the same with the records already resident in device memory ----------------------------
+struct GatherRec {
+    const uint8_t *src;
+    uint64_t off, len;  // record k goes to d_text[off, off + len), its separator (all but the last) behind it
+};
+// grid (pieces, records): a workgroup copies 4 KiB pieces of its record
+__global__ __launch_bounds__(256) void gather_records_kernel(const GatherRec *__restrict__ recs, uint32_t c,
+                                                             uint8_t *__restrict__ dst, uint8_t sep) {
+    for (uint32_t k = blockIdx.y; k < c; k += gridDim.y) {
+        const GatherRec r = recs[k];
+        for (uint64_t p0 = (uint64_t)blockIdx.x * 4096; p0 < r.len; p0 += (uint64_t)gridDim.x * 4096) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const uint64_t p = p0 + (uint64_t)j * 256 + threadIdx.x;
+                if (p < r.len) dst[r.off + p] = r.src[p];
+            }
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0 && k + 1 < c) dst[r.off + r.len] = sep;
+    }
+}
+
+// smallest j with fpos[j] >= the position of separator k (its own literal factor)
+__global__ void batch_bounds_pos_kernel(const uint32_t *__restrict__ fpos, uint32_t z,
+                                        const uint32_t *__restrict__ seps, uint32_t nsep, uint32_t *__restrict__ fidx,
+                                        uint32_t *__restrict__ err) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nsep) return;
+    const uint32_t target = seps[k];
+    uint32_t lo = 0, hi = z;
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (fpos[mid] >= target)
+            hi = mid;
+        else
+            lo = mid + 1;
+    }
+    fidx[k] = lo;
+    if (lo >= z || fpos[lo] != target) atomicOr(err, 1u);  // a separator matches nothing: a factor starts there
+}
+
+// Records ids[0..c) (device pointers, all non-empty) as ONE run of independent sequences: gathered on the
+// device, factorized together, counted per record (emit: the factor records are also built in device
+// memory, in record-relative coordinates, as the per-record runs leave them).  Returns false, with nothing
+// written, when the records hold anything but A/C/G/T.
+bool run_merged_chunk_device(Context &ctx, const void *const *d_texts, const size_t *lens, const std::vector<size_t> &ids,
+                             bool emit, size_t *zs) {
+    const size_t c = ids.size();
+    size_t n = c - 1;
+    for (size_t j : ids) n += lens[j];
+    Arena &arena = ctx.arena;
+    hipStream_t s = ctx.stream;
+    reserve_arena_for(ctx, n, n + 64 * c + (size_t(1) << 20));
+    const size_t mark = arena.mark();
+    struct Rewind {
+        Arena &a;
+        size_t m;
+        ~Rewind() { a.rewind(m); }
+    } rewind{arena, mark};
+    std::vector<GatherRec> table(c);
+    std::vector<uint32_t> seps;
+    seps.reserve(c - 1);
+    {
+        size_t at = 0;
+        for (size_t k = 0; k < c; ++k) {
+            table[k] = GatherRec{static_cast<const uint8_t *>(d_texts[ids[k]]), at, lens[ids[k]]};
+            at += lens[ids[k]];
+            if (k + 1 < c) seps.push_back((uint32_t)at++);
+        }
+    }
+    uint8_t *d_text = arena.alloc<uint8_t>(n);
+    GatherRec *d_table = arena.alloc<GatherRec>(c);
+    HIP_CHECK(hipMemcpyAsync(d_table, table.data(), sizeof(GatherRec) * c, hipMemcpyHostToDevice, s));
+    {
+        ProfScope ps(ctx.profiler(), "batch_gather", s, 2.0 * (double)n);
+        const size_t longest = lens[*std::max_element(ids.begin(), ids.end(), [&](size_t a, size_t b) { return lens[a] < lens[b]; })];
+        const unsigned gy = (unsigned)std::min<size_t>(c, 32768);
+        const unsigned gx = (unsigned)std::max<size_t>(1, std::min<size_t>(div_up(longest, 4096), div_up((size_t)65536, gy)));
+        gather_records_kernel<<<dim3(gx, gy), 256, 0, s>>>(d_table, (uint32_t)c, d_text, kBatchSeparator);
+        KERNEL_CHECK();
+    }
+    HIP_CHECK(hipStreamSynchronize(s));  // table is a local vector
+    PackedText text;
+    if (!pack_independent_text(ctx, d_text, n, seps, text)) return false;
+    uint32_t *sa = arena.alloc<uint32_t>(n);
+    uint32_t *isa = arena.alloc<uint32_t>(n);
+    uint32_t *lcp = arena.alloc<uint32_t>(n + 1);
+    build_suffix_array(ctx, text, sa, isa, lcp);
+    Pyramid Psa, Plcp;
+    {
+        ProfScope ps(ctx.profiler(), "pyramids", s);
+        Psa = build_pyramid(sa, (uint32_t)n, false, arena, s);
+        Plcp = build_lcp_pyramid(ctx, text, sa, lcp);
+    }
+    uint32_t *lstar = arena.alloc<uint32_t>(n);
+    build_lstar(ctx, (uint32_t)n, sa, isa, lcp, Psa, Plcp, lstar);
+    void *d_recs = nullptr;
+    uint32_t *d_fpos = nullptr;
+    const uint32_t z = resolve_chain(ctx, (uint32_t)n, 0, lstar, sa, isa, lcp, Psa, Plcp, emit ? &d_recs : nullptr, 0,
+                                     nullptr, &d_fpos);
+    std::vector<uint32_t> fidx(c, z);
+    if (c > 1) {
+        uint32_t *d_fidx = arena.alloc<uint32_t>(c);
+        HIP_CHECK(hipMemsetAsync(d_fidx + (c - 1), 0, sizeof(uint32_t), s));  // error flag
+        batch_bounds_pos_kernel<<<(unsigned)div_up(c - 1, 256), 256, 0, s>>>(d_fpos, z, text.terms.pos, (uint32_t)(c - 1),
+                                                                             d_fidx, d_fidx + (c - 1));
+        KERNEL_CHECK();
+        if (emit && z) {
+            batch_rebase_kernel<<<(unsigned)div_up(z, 256), 256, 0, s>>>(static_cast<nolzss_factor *>(d_recs), z, text.terms);
+            KERNEL_CHECK();
+        }
+        HIP_CHECK(hipMemcpyAsync(fidx.data(), d_fidx, c * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        if (fidx[c - 1]) throw HipError("merged batch: a separator is not a literal factor");
+        fidx[c - 1] = z;
+    }
+    HIP_CHECK(hipStreamSynchronize(s));
+    ctx.prof.collect();
+    for (size_t k = 0; k < c; ++k) {
+        const uint32_t a = k ? fidx[k - 1] + 1 : 0, b = fidx[k];
+        zs[ids[k]] = b - a;
+    }
+    return true;
+}
+
 std::atomic<uint64_t> g_merged_records{0}, g_single_records{0};
 
 // a worker thread failed: the same kind of error, with the same text, for the calling thread
@@ -1569,7 +1693,12 @@ void factorize_many(const uint8_t *const *texts, const size_t *lens, size_t m, c
     // 1. which records are merged: short, non-empty ones, in chunks of consecutive records
     // (with_rc: each record as T s0 revcomp(T) s1, dna_w_rc_common; a run holds both strands)
     const size_t below = with_rc ? merge_below() / 2 : merge_below();
-    const size_t run_bases = with_rc ? kMergeChunkBases / 2 : kMergeChunkBases;
+    static const size_t chunk_bases = [] {
+        const char *e = getenv("NOLZSS_BATCH_MERGE_BASES");
+        const long long v = e ? atoll(e) : 0;
+        return v > 0 ? (size_t)v : kMergeChunkBases;
+    }();
+    const size_t run_bases = with_rc ? chunk_bases / 2 : chunk_bases;
     std::vector<size_t> singles;
     std::vector<std::vector<size_t>> chunks;
     {
@@ -1761,8 +1890,98 @@ int nolzss_factorize_batch_device(const void *const *d_texts, const size_t *lens
         if (m && (!d_texts || !lens || !z)) throw std::invalid_argument("sequence array is null");
         if (emit != 0 && emit != 1) throw std::invalid_argument("emit must be 0 (count) or 1 (records built in HBM)");
         for (size_t j = 0; j < m; ++j) check_text_args(d_texts[j], lens[j], 0);
-        std::vector<size_t> order(m);
-        std::iota(order.begin(), order.end(), (size_t)0);
+        HIP_CHECK(hipSetDevice(device));
+        // Records shorter than dev_merge_below are gathered into runs of independent sequences of about
+        // dev_run_bases bases (run_merged_chunk_device): a 4 Mi-base record neither fills the GPU nor hides
+        // the ~100 launches and dozen read-backs of its pipeline run, eight of them in flight on eight
+        // streams reach 7 Gbases/s; one run over 256 of them works at the speed of a 2^30-base text.
+        static const size_t dev_merge_below = [] {
+            const char *e = getenv("NOLZSS_DEVICE_MERGE_BELOW");
+            return e ? (size_t)atoll(e) : (size_t(1) << 28);
+        }();
+        static const size_t dev_run_bases = [] {
+            const char *e = getenv("NOLZSS_DEVICE_MERGE_BASES");
+            const long long v = e ? atoll(e) : 0;
+            return v > 0 ? (size_t)v : (size_t(1) << 30);
+        }();
+        std::vector<size_t> order;  // the records that take a pipeline run of their own
+        std::vector<std::vector<size_t>> chunks;
+        {
+            size_t short_bases = 0;
+            for (size_t j = 0; j < m; ++j)
+                if (lens[j] && lens[j] < dev_merge_below) short_bases += lens[j] + 1;
+            // (two runs in flight fill each other's launch and read-back gaps: 2^28 bases go as two runs of
+            // 2^27 rather than one)
+            size_t runs = div_up(short_bases ? short_bases : 1, dev_run_bases);
+            if (runs < 2 && short_bases >= (size_t(1) << 27)) runs = 2;
+            const size_t share = div_up(short_bases, runs);
+            std::vector<size_t> cur;
+            size_t cur_bases = 0;
+            for (size_t j = 0; j < m; ++j) {
+                z[j] = 0;
+                if (lens[j] == 0) continue;
+                if (lens[j] >= dev_merge_below) {
+                    order.push_back(j);
+                    continue;
+                }
+                // (a run is one text: below the text limit, and the record table below 2^23 entries)
+                if (!cur.empty() && (cur_bases + lens[j] + 1 > kMaxText / 2 || cur.size() >= (size_t(1) << 23))) {
+                    chunks.push_back(std::move(cur));
+                    cur.clear();
+                    cur_bases = 0;
+                }
+                cur.push_back(j);
+                cur_bases += lens[j] + 1;
+                if (cur_bases >= share) {
+                    chunks.push_back(std::move(cur));
+                    cur.clear();
+                    cur_bases = 0;
+                }
+            }
+            if (!cur.empty()) chunks.push_back(std::move(cur));
+            for (auto it = chunks.begin(); it != chunks.end();)
+                if (it->size() < 2) {  // nothing to merge with
+                    order.push_back((*it)[0]);
+                    it = chunks.erase(it);
+                } else {
+                    ++it;
+                }
+        }
+        if (!chunks.empty()) {
+            static const size_t merge_lanes = [] {
+                const char *e = getenv("NOLZSS_DEVICE_MERGE_LANES");
+                const long v = e ? atol(e) : 2;
+                return (size_t)(v < 1 ? 1 : (v > kMaxLanes ? kMaxLanes : v));
+            }();
+            const size_t workers = std::min(merge_lanes, chunks.size());
+            std::vector<int> status(workers, NOLZSS_OK);
+            std::vector<std::string> messages(workers);
+            std::atomic<size_t> next{0};
+            std::mutex mu;
+            auto worker = [&](size_t w) {
+                status[w] = guarded([&] {
+                    Session ses(device, nullptr, (int)w);
+                    for (;;) {
+                        const size_t k = next.fetch_add(1);
+                        if (k >= chunks.size()) break;
+                        const bool ok = run_merged_chunk_device(ses.ctx(), d_texts, lens, chunks[k], emit == 1, z);
+                        std::lock_guard<std::mutex> lk(mu);
+                        if (ok)
+                            g_merged_records += chunks[k].size();
+                        else  // other alphabets: one by one
+                            order.insert(order.end(), chunks[k].begin(), chunks[k].end());
+                    }
+                });
+                if (status[w] != NOLZSS_OK) messages[w] = g_error;
+            };
+            std::vector<std::thread> threads;
+            for (size_t w = 0; w < workers; ++w) threads.emplace_back(worker, w);
+            for (auto &t : threads) t.join();
+            for (size_t w = 0; w < workers; ++w)
+                if (status[w] != NOLZSS_OK) rethrow_worker_error(status[w], messages[w]);
+        }
+        m = order.size();  // what is left takes the per-record path below
+        if (m == 0) return;
         std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return lens[a] > lens[b]; });
         static const size_t lanes_env = [] {
             const char *e = getenv("NOLZSS_BATCH_LANES");
@@ -1772,7 +1991,6 @@ int nolzss_factorize_batch_device(const void *const *d_texts, const size_t *lens
         size_t lanes = std::min(lanes_env, m ? m : (size_t)1);
         if (m) {  // no more lanes than arenas for the longest record fit the device
             size_t free_b = 0, total_b = 0;
-            HIP_CHECK(hipSetDevice(device));
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
                 const size_t fit = (size_t)((double)total_b * 0.85) / arena_bytes_for(lens[order[0]]);
                 lanes = std::max<size_t>(1, std::min(lanes, fit));
@@ -1791,6 +2009,7 @@ int nolzss_factorize_batch_device(const void *const *d_texts, const size_t *lens
                     reserve_arena_for(ses.ctx(), lens[j]);
                     z[j] = run_plain(ses.ctx(), static_cast<const uint8_t *>(d_texts[j]), lens[j], 0, nullptr, nullptr,
                                      emit == 1);
+                    ++g_single_records;
                 }
             });
             if (status[lane] != NOLZSS_OK) messages[lane] = g_error;

@@ -329,14 +329,17 @@ inline unsigned grid_for(size_t items, unsigned cap = 256u * 16u) {
 
 // Returns z; if d_factors_out != nullptr the z factor records are left in arena memory (this
 // stage's temporaries are then NOT released: the caller rewinds after copying the records out).
+// d_fpos_out (optional) receives the z factor starts, ascending, under the same rule -- without
+// d_factors_out nothing else is built.
 // Plain mode: rcN = 0, Pmax unused.  RC mode: n = N (factorized prefix of S), rcN = N and Pmax
 // is the max pyramid over SA.
 uint32_t resolve_chain(Context &ctx, uint32_t n, uint32_t start_pos, const uint32_t *lstar, const uint32_t *sa,
                        const uint32_t *isa, const uint32_t *lcp, const Pyramid &Psa, const Pyramid &Plcp,
-                       void **d_factors_out, uint32_t rcN, const Pyramid *Pmax) {
+                       void **d_factors_out, uint32_t rcN, const Pyramid *Pmax, uint32_t **d_fpos_out) {
     hipStream_t s = ctx.stream;
     Arena &arena = ctx.arena;
     if (d_factors_out) *d_factors_out = nullptr;
+    if (d_fpos_out) *d_fpos_out = nullptr;
     if (start_pos >= n) return 0;
 
     const uint32_t num_tiles = (uint32_t)div_up(n, kTile);
@@ -400,11 +403,18 @@ uint32_t resolve_chain(Context &ctx, uint32_t n, uint32_t start_pos, const uint3
     }
     uint32_t z = 0;
     ctx.read_back(d_total + 1, &z, 1);
-    if (!d_factors_out || z == 0) {
+    if ((!d_factors_out && !d_fpos_out) || z == 0) {
         arena.rewind(mark);
         return z;
     }
     fpos = arena.alloc<uint32_t>(z);
+    if (!d_factors_out) {  // the factor starts only (per-record counts of the merged batch)
+        ProfScope ps(ctx.profiler(), "factor_emit", s);
+        emit_positions_kernel<<<num_tiles, 64, 0, s>>>(cbits, tile_count, fpos);
+        KERNEL_CHECK();
+        *d_fpos_out = fpos;
+        return z;
+    }
     FactorRec *recs_tmp = arena.alloc<FactorRec>(z);
     {
         ProfScope ps(ctx.profiler(), "factor_emit", s);
@@ -420,6 +430,7 @@ uint32_t resolve_chain(Context &ctx, uint32_t n, uint32_t start_pos, const uint3
     }
     // the caller owns the arena mark: stage temporaries stay allocated until it rewinds
     *d_factors_out = recs_tmp;
+    if (d_fpos_out) *d_fpos_out = fpos;
     return z;
 }
 

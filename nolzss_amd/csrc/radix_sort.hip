@@ -79,11 +79,11 @@ inline uint32_t xcd_grid(uint32_t num_tiles) {
 template <typename KeyT> struct ArraySrc {
     const KeyT *__restrict__ keys;
     const uint32_t *__restrict__ vals;
-    __device__ __forceinline__ KeyT key(size_t idx) const { return keys[idx]; }
+    __device__ __forceinline__ KeyT key(size_t idx, const TileExtent &) const { return keys[idx]; }
     __device__ __forceinline__ uint32_t val(size_t idx) const { return vals[idx]; }
     // histogram passes: what to load, and the digit of what was loaded (kept apart so that all loads
     // of a tile are issued before the first digit is needed)
-    __device__ __forceinline__ KeyT hist_raw(size_t idx, int) const { return keys[idx]; }
+    __device__ __forceinline__ KeyT hist_raw(size_t idx, int, const TileExtent &) const { return keys[idx]; }
     __device__ __forceinline__ uint32_t hist_digit(KeyT raw, int shift) const { return digit_of(raw, shift); }
     __device__ __forceinline__ bool digits_from_window(int) const { return false; }
     __device__ __forceinline__ uint64_t window(size_t) const { return 0; }
@@ -93,17 +93,17 @@ template <int BITS> struct TextSrc {
     TermTable terms;
     bool segmented;
     bool digit_from_text = true;  // MSD histogram digit straight from the packed text (no terminators in the text)
-    __device__ __forceinline__ uint64_t key(size_t idx) const {
+    __device__ __forceinline__ uint64_t key(size_t idx, const TileExtent &) const {
         return initial_key<BITS>(words, terms, segmented, (uint32_t)idx);
     }
     __device__ __forceinline__ uint32_t val(size_t idx) const { return (uint32_t)idx; }
     // histogram passes only need the digit; the top 8 bits of a plain key are the first 8 / BITS
     // symbols, straight from the packed text (no length tag, no terminator search)
-    __device__ __forceinline__ uint64_t hist_raw(size_t idx, int shift) const {
+    __device__ __forceinline__ uint64_t hist_raw(size_t idx, int shift, const TileExtent &ext) const {
         constexpr int kKeyBits = KeyLayout<BITS>::kSyms * BITS + KeyLayout<BITS>::kTagBits;
         if (!segmented && digit_from_text && shift == kKeyBits - kRadixBits)
             return sym_word<BITS>(words, idx) >> (64 - kKeyBits);
-        return key(idx);
+        return key(idx, ext);
     }
     __device__ __forceinline__ uint32_t hist_digit(uint64_t raw, int shift) const { return digit_of(raw, shift); }
     // the most significant digits of 16 CONSECUTIVE suffixes are 8-bit windows of one 64-bit piece of a
@@ -114,6 +114,26 @@ template <int BITS> struct TextSrc {
         return BITS == 2 && !segmented && digit_from_text && shift == kKeyBits - kRadixBits;
     }
     __device__ __forceinline__ uint64_t window(size_t idx) const { return sym_word<BITS>(words, idx); }
+};
+// Independent records, one BUCKET per record (radix_sort_record_keys): the pairs of a tile are the suffixes at
+// the tile's own text positions, the key [kRecSyms bases][4-bit length tag] of a suffix needs the end of its
+// record -- the terminator of the tile's bucket, one scalar load per tile instead of a table search per suffix.
+struct RecordTextSrc {
+    const uint64_t *__restrict__ words;
+    const uint32_t *__restrict__ term_pos;  // terminator of record k (the separator behind it; n for the last one)
+    __device__ __forceinline__ uint32_t key(size_t idx, const TileExtent &ext) const {
+        const uint64_t w = sym_word<2>(words, idx);
+        const uint32_t lim = term_pos[ext.bucket] - (uint32_t)idx;
+        const uint32_t tag = lim < (uint32_t)kRecSyms ? lim : (uint32_t)kRecSyms;
+        uint32_t sym = (uint32_t)(w >> (64 - kRecSyms * 2));
+        if (tag < (uint32_t)kRecSyms) sym &= ~((1u << (2 * (kRecSyms - (int)tag))) - 1u);
+        return (sym << kRecTagBits) | tag;
+    }
+    __device__ __forceinline__ uint32_t val(size_t idx) const { return (uint32_t)idx; }
+    __device__ __forceinline__ uint32_t hist_raw(size_t idx, int, const TileExtent &ext) const { return key(idx, ext); }
+    __device__ __forceinline__ uint32_t hist_digit(uint32_t raw, int shift) const { return digit_of(raw, shift); }
+    __device__ __forceinline__ bool digits_from_window(int) const { return false; }
+    __device__ __forceinline__ uint64_t window(size_t) const { return 0; }
 };
 
 template <typename KeyT, typename Src>
@@ -150,7 +170,7 @@ __global__ __launch_bounds__(kThreads) void rs_hist_kernel(Src src, size_t n, in
 #pragma unroll
         for (int j = 0; j < kKeysPerThread; ++j) {
             const uint32_t local = (uint32_t)j * kThreads + threadIdx.x;
-            k[j] = local < ext.count ? (KeyT)src.hist_raw(ext.first + local, shift) : KeyT(0);
+            k[j] = local < ext.count ? (KeyT)src.hist_raw(ext.first + local, shift, ext) : KeyT(0);
         }
 #pragma unroll
         for (int j = 0; j < kKeysPerThread; ++j) {
@@ -197,7 +217,7 @@ __global__ __launch_bounds__(kThreads) void rs_scatter_kernel(
     for (int row = 0; row < kKeysPerThread; ++row) {
         const uint32_t local = (uint32_t)w * kWaveSpan + (uint32_t)row * 64 + lane;
         const bool valid = local < ext.count;
-        key[row] = valid ? src.key(base + local) : KeyT(0);
+        key[row] = valid ? (KeyT)src.key(base + local, ext) : KeyT(0);
         val[row] = valid ? src.val(base + local) : 0;
     }
     // rank inside the wavefront: rows of 64 keys in input order (keeps the sort stable).  The lowest
@@ -493,10 +513,10 @@ __global__ __launch_bounds__(kThreads) void seg_desc_kernel(const uint32_t *__re
                                                             const uint32_t *__restrict__ tile0,
                                                             const uint32_t *__restrict__ prev_ne,
                                                             const uint32_t *__restrict__ next_ne, uint32_t num_tiles,
-                                                            uint32_t *__restrict__ desc) {
+                                                            uint32_t *__restrict__ desc, uint32_t num_buckets) {
     const uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x;
     if (tile >= num_tiles) return;
-    uint32_t lo = 0, hi = kBins;  // largest b with tile0[b] <= tile (the non-empty one among equals)
+    uint32_t lo = 0, hi = num_buckets;  // largest b with tile0[b] <= tile (the non-empty one among equals)
     while (lo + 1 < hi) {
         const uint32_t mid = (lo + hi) >> 1;
         if (tile0[mid] <= tile)
@@ -557,7 +577,7 @@ void radix_sort_dna_keys(const PackedText &text, uint32_t *keys32[2], uint32_t *
     HIP_CHECK(hipStreamSynchronize(stream));  // h_tab is a local array
     seg_out.num_tiles = h_tile0[kBins];
     seg_desc_kernel<<<(unsigned)div_up(seg_out.num_tiles, kThreads), kThreads, 0, stream>>>(bstart, tile0, prev_ne, next_ne,
-                                                                                       seg_out.num_tiles, seg_mem);
+                                                                                       seg_out.num_tiles, seg_mem, (uint32_t)kBins);
     KERNEL_CHECK();
     seg_out.desc = seg_mem;
     // every bucket by the low 32 key bits, least significant digit first
@@ -569,6 +589,55 @@ void radix_sort_dna_keys(const PackedText &text, uint32_t *keys32[2], uint32_t *
         cur ^= 1;
     }
     arena.rewind(m);  // (cur == 1 again)
+}
+
+void radix_sort_record_keys(const PackedText &text, const std::vector<uint32_t> &h_terms, uint32_t *keys32[2],
+                            uint32_t *vals[2], uint32_t *seg_mem, SegView &seg_out, Arena &arena, hipStream_t stream,
+                            Profiler *prof) {
+    const size_t n = text.n;
+    const uint32_t nb = (uint32_t)h_terms.size();  // records = buckets; h_terms[k] = terminator of record k
+    if (text.bits != 2 || nb == 0 || h_terms.back() != n) throw HipError("radix_sort_record_keys: bad record table");
+    const size_t m = arena.mark();
+    // bucket k = the text positions of record k and of the separator behind it: already "partitioned"
+    std::vector<uint32_t> tab(4 * ((size_t)nb + 1));
+    uint32_t *h_start = tab.data(), *h_tile0 = h_start + nb + 1, *h_prev = h_tile0 + nb + 1, *h_next = h_prev + nb + 1;
+    h_start[0] = 0;
+    for (uint32_t k = 0; k + 1 < nb; ++k) h_start[k + 1] = h_terms[k] + 1;
+    h_start[nb] = (uint32_t)n;
+    h_tile0[0] = 0;
+    for (uint32_t k = 0; k < nb; ++k) h_tile0[k + 1] = h_tile0[k] + (uint32_t)div_up((size_t)(h_start[k + 1] - h_start[k]), kTile);
+    uint32_t last = 0xffffffffu;
+    for (uint32_t k = 0; k < nb; ++k) {
+        h_prev[k] = last;
+        if (h_start[k + 1] > h_start[k]) last = k;
+    }
+    last = 0xffffffffu;
+    for (uint32_t k = nb; k-- > 0;) {
+        h_next[k] = last;
+        if (h_start[k + 1] > h_start[k]) last = k;
+    }
+    h_prev[nb] = h_next[nb] = 0;
+    uint32_t *d_tab = arena.alloc<uint32_t>(tab.size());
+    HIP_CHECK(hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));  // tab is a local vector
+    seg_out.num_tiles = h_tile0[nb];
+    seg_desc_kernel<<<(unsigned)div_up(seg_out.num_tiles, kThreads), kThreads, 0, stream>>>(
+        d_tab, d_tab + (nb + 1), d_tab + 2 * ((size_t)nb + 1), d_tab + 3 * ((size_t)nb + 1), seg_out.num_tiles, seg_mem, nb);
+    KERNEL_CHECK();
+    seg_out.desc = seg_mem;
+    uint32_t *hist = arena.alloc<uint32_t>((size_t)kBins * seg_out.num_tiles);
+    const double text_bytes = (double)n * 2 / 8.0;
+    // least significant digit first inside every record; the first pass makes its pairs from the text
+    radix_pass<uint32_t, uint32_t>(RecordTextSrc{text.words, text.terms.pos}, keys32[1], vals[1], n, 0, hist,
+                                   seg_out.num_tiles, text_bytes, text_bytes + 8.0 * (double)n, arena, stream, prof, seg_out);
+    int cur = 1;
+    for (int p = 1; p < 4; ++p) {
+        radix_pass<uint32_t, uint32_t>(ArraySrc<uint32_t>{keys32[cur], vals[cur]}, keys32[cur ^ 1], vals[cur ^ 1], n,
+                                       8 * p, hist, seg_out.num_tiles, 4.0 * (double)n, 16.0 * (double)n, arena,
+                                       stream, prof, seg_out);
+        cur ^= 1;
+    }
+    arena.rewind(m);  // (cur == 0: the sorted pairs are in keys32[0] / vals[0])
 }
 
 int radix_sort_initial_keys(const PackedText &text, uint64_t *keys[2], uint32_t *vals[2], const int *shifts,

@@ -3,6 +3,8 @@
 #include "common.hpp"
 #include "text.hpp"
 
+#include <vector>
+
 namespace nolzss {
 
 constexpr int kRadixBits = 8;
@@ -82,6 +84,16 @@ int radix_sort_initial_keys(const PackedText &text, uint64_t *keys[2], uint32_t 
 // 12 + 4 * 32 (hist + scatter, keys + values).
 void radix_sort_dna_keys(const PackedText &text, uint32_t *keys32[2], uint32_t *vals[2], uint32_t *seg_mem,
                          SegView &seg_out, Arena &arena, hipStream_t stream, Profiler *prof = nullptr);
+
+// Independent records of 2-bit DNA (text.terms.seq_shift != 0), at most n / 2^16 of them: the records are
+// the buckets -- the text is "partitioned" as it lies -- and every bucket is sorted on 8-byte records by the
+// 32-bit key [kRecSyms bases][4-bit length tag], least significant digit first, the first pass making its
+// pairs from the packed text: FOUR passes (8 + 3 * 16 bytes per suffix) where the general sort of the merged
+// batch takes five on 12-byte records.  h_terms = host copy of the terminator table.  seg_mem: kSegDescWords *
+// (n / kSortTile + records + 1) words.  The sorted keys end in keys32[0], the suffixes in vals[0].
+void radix_sort_record_keys(const PackedText &text, const std::vector<uint32_t> &h_terms, uint32_t *keys32[2],
+                            uint32_t *vals[2], uint32_t *seg_mem, SegView &seg_out, Arena &arena, hipStream_t stream,
+                            Profiler *prof = nullptr);
 
 // out[idx[k]] = val[k] for k < count, idx[k] < n_out (entries with idx >= n_out are dropped).
 // A random 4-byte scatter over an array much larger than the caches costs a read-modify-write

@@ -1703,9 +1703,16 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         if ((1u << seq_bits) < text.terms.count) throw HipError("suffix array: too many independent sequences");
     }
     const bool dna_fast = text.bits == 2 && n >= dna_fast_min && !independent;
+    // independent LONG records (text.hpp, kRecSyms): the records are the buckets of the segmented sort
+    // (NOLZSS_REC_BUCKET_MIN: smallest average record that takes it; partial tiles cost 4096 / that)
+    static const uint64_t rec_bucket_min =
+        getenv("NOLZSS_REC_BUCKET_MIN") ? (uint64_t)atoll(getenv("NOLZSS_REC_BUCKET_MIN")) : (uint64_t(1) << 16);
+    const bool rec_fast = independent && !text.terms.mirror && n >= dna_fast_min && rec_bucket_min > 0 &&
+                          (uint64_t)text.terms.count * rec_bucket_min <= (uint64_t)n;
     int key_passes = 0;
     {
         int kb = dna_fast ? KeyLayout<2>::kSyms * 2 + KeyLayout<2>::kTagBits
+                 : rec_fast ? kRecSyms * 2 + kRecTagBits
                  : independent ? kIndKeyBits + seq_bits
                  : text.segmented ? kSegSyms * 2 + kSegTagBits + kSegTermBits
                  : text.bits == 2 ? KeyLayout<2>::kSyms * 2 + KeyLayout<2>::kTagBits
@@ -1718,7 +1725,8 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     uint32_t *act_grp[2] = {arena.alloc<uint32_t>(n), arena.alloc<uint32_t>(n)};
     uint32_t *rank_by_slot = arena.alloc<uint32_t>(n);
     uint32_t *d_total = arena.alloc<uint32_t>(4);  // survivors, look-back error flag, elements whose rank changed
-    uint32_t *seg_mem = arena.alloc<uint32_t>((size_t)kSegDescWords * (div_up(n, kSortTile) + 257));  // 16-byte aligned
+    uint32_t *seg_mem = arena.alloc<uint32_t>((size_t)kSegDescWords *
+                                              (div_up(n, kSortTile) + (rec_fast ? (size_t)text.terms.count + 1 : (size_t)257)));  // 16-byte aligned
     uint32_t *rank = isa;
 
     // ---- phase: key sort + first regroup -----------------------------------------------------
@@ -1726,7 +1734,7 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     // the bucketed sort of plain DNA works on 8-byte (u32 key, u32 suffix) records: two 4n-byte key buffers;
     // the general sort on 12-byte records: two 8n-byte key buffers
     uint64_t *keys[2];
-    if (dna_fast) {
+    if (dna_fast || rec_fast) {
         uint32_t *k32 = arena.alloc<uint32_t>(2 * (size_t)n + 4);
         keys[0] = reinterpret_cast<uint64_t *>(k32);
         keys[1] = reinterpret_cast<uint64_t *>(k32 + (((size_t)n + 1) & ~size_t(1)));
@@ -1769,6 +1777,14 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
             radix_sort_dna_keys(text, keys32, vals, seg_mem, seg, arena, s, ctx.profiler());
             cur = 1;
             if (vals[cur] != sa) throw HipError("suffix array: key sort did not end in sa");
+        } else if (rec_fast) {
+            std::vector<uint32_t> h_terms(text.terms.count);
+            HIP_CHECK(hipMemcpyAsync(h_terms.data(), text.terms.pos, sizeof(uint32_t) * h_terms.size(), hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+            uint32_t *keys32[2] = {reinterpret_cast<uint32_t *>(keys[0]), reinterpret_cast<uint32_t *>(keys[1])};
+            radix_sort_record_keys(text, h_terms, keys32, vals, seg_mem, seg, arena, s, ctx.profiler());
+            cur = 0;
+            if (vals[cur] != sa) throw HipError("suffix array: key sort did not end in sa");
         } else {
             cur = radix_sort_initial_keys(text, keys, vals, shifts0, np0, arena, s, ctx.profiler());
             if (np0 != key_passes || vals[cur] != sa) throw HipError("suffix array: key sort did not end in sa");
@@ -1784,6 +1800,11 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         k_syms = kIndSyms;
         tag_bits = kIndTagBits;
     }
+    if (rec_fast) {  // bucket = record, [kRecSyms bases][4-bit tag]
+        k_syms = kRecSyms;
+        tag_bits = kRecTagBits;
+    }
+    const bool bucketed = dna_fast || rec_fast;
     if (text.segmented && !dna_fast && !independent) {  // [kSegSyms symbols][5-bit tag][8-bit terminator index]
         k_syms = kSegSyms;
         tag_bits = kSegTagBits;
@@ -1792,12 +1813,12 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     uint32_t m = regroup<true>(ctx, keys[cur], nullptr, nullptr, vals[cur], nullptr, n, n, sa, rank, act_slot[0],
                                act_grp[0], nullptr, nullptr, nullptr, d_total, lcp,
                                k_syms * text.bits, tag_bits, text.bits, nullptr, low_bits, 0, rank_by_slot, nullptr,
-                               dna_fast ? reinterpret_cast<const uint32_t *>(keys[cur]) : nullptr,
-                               dna_fast ? &seg : nullptr,
+                               bucketed ? reinterpret_cast<const uint32_t *>(keys[cur]) : nullptr,
+                               bucketed ? &seg : nullptr,
                                // (mirrored independent sequences have two terminators each: a short suffix
                                // can tie with its copy at the other one)
                                (dna_fast || (independent && text.terms.mirror)) ? (uint32_t)k_syms : 0u, false,
-                               text.terms.seq_shift);
+                               rec_fast ? 32u : text.terms.seq_shift);
 
     arena.rewind(sort_mark);  // keys and the second value buffer are done
 

@@ -27,6 +27,9 @@ constexpr int kTermBlockShift = 12;
 // below 2^21 bases), so 12 bases separate as well as 17 do in a 2^30-base text, and every 8 key bits
 // less is a radix pass less.
 constexpr int kIndSyms = 12, kIndTagBits = 4, kIndKeyBits = kIndSyms * 2 + kIndTagBits;
+// LONG records (at most n / 2^16 of them): the record is the bucket of the segmented key sort
+// (radix_sort_record_keys) and the 32-bit key holds [14 bases][4-bit length tag] only
+constexpr int kRecSyms = 14, kRecTagBits = 4;
 struct TermTable {
     const uint32_t *pos = nullptr;  // sorted terminator positions, pos[count-1] = n
     uint32_t count = 0;

@@ -326,3 +326,85 @@ def test_several_runs_in_flight(native):
     crc, arc = native.factorize_batch(recs[:500], want_factors=True, with_rc=True)
     for j in rng.choice(500, size=20, replace=False).tolist():
         assert _same(arc[j], _rc_expected(recs[j])), j
+
+
+def test_record_bucket_sort_on_small_records():
+    """Runs of LONG records (on average >= 2^16 bases) sort with the records as the buckets of the segmented
+    key sort (radix_sort.hip, radix_sort_record_keys; key = 14 bases + length tag).  One child process with
+    NOLZSS_REC_BUCKET_MIN=1 and NOLZSS_DNA_FAST_MIN=1 sends small runs through it: records shorter than a tile
+    and shorter than the key, records that end inside the key window, copies of each other, one-base records,
+    record counts around 256; host-buffer batch (every factor against the oracle) and the device-resident
+    batch (counts, with and without records built in device memory)."""
+    import subprocess
+    import sys
+    code = r'''
+import sys
+sys.path.insert(0, "tests")
+import numpy as np, torch
+import gen, oracle_lib as oracle
+from nolzss_amd import _noLZSS as native
+rng = np.random.default_rng(21)
+def recs_of(count, lo, hi):
+    out = []
+    for k in range(count):
+        n = int(rng.integers(lo, hi + 1))
+        out.append(gen.repeat_dna(n, seed=9000 + k) if n >= 64 else gen.random_dna(n, seed=9000 + k))
+    return out
+sets = [recs_of(2, 5000, 9000), recs_of(7, 1, 40), recs_of(60, 1, 6000), recs_of(255, 10, 300), recs_of(256, 10, 300),
+        recs_of(257, 10, 300), recs_of(9, 4090, 4100), recs_of(3, 60000, 140000)]
+base = gen.repeat_dna(7000, seed=5)
+sets.append([base, base.copy(), base[:3000].copy(), base[100:].copy(), np.frombuffer(b"A" * 5000, dtype=np.uint8),
+             np.frombuffer(b"ACGT" * 1100, dtype=np.uint8), np.frombuffer(b"ACGTTGCATTGACC", dtype=np.uint8),
+             np.frombuffer(b"ACGTTGCATTGAC", dtype=np.uint8), np.frombuffer(b"ACGTTGCATTGACCA", dtype=np.uint8)]
+            + [np.frombuffer(c, dtype=np.uint8) for c in (b"A", b"C", b"G", b"T", b"AA", b"T" * 29)])
+total = 0
+for recs in sets:
+    m0, s0 = native.debug_batch_counters()
+    counts, arrays = native.factorize_batch(recs, want_factors=True)
+    m1, s1 = native.debug_batch_counters()
+    assert (m1 - m0, s1 - s0) == (len(recs), 0), (m1 - m0, s1 - s0)
+    for j, r in enumerate(recs):
+        exp = oracle.factors_array(r)
+        assert counts[j] == len(exp), (len(recs), j)
+        for k in ("start", "length", "ref"):
+            assert np.array_equal(arrays[j][k], exp[k]), (len(recs), j, k)
+    d = [torch.from_numpy(np.ascontiguousarray(r)).cuda() for r in recs]
+    torch.cuda.synchronize()
+    for emit in (0, 1):
+        m0, s0 = native.debug_batch_counters()
+        got = native.factorize_batch_device([t.data_ptr() for t in d], [len(r) for r in recs], emit=emit)
+        m1, s1 = native.debug_batch_counters()
+        assert got == counts, (len(recs), emit)
+        assert (m1 - m0, s1 - s0) == (len(recs), 0), (m1 - m0, s1 - s0)
+    total += len(recs)
+print("ok", total)
+'''
+    env = dict(os.environ, NOLZSS_DNA_FAST_MIN="1", NOLZSS_REC_BUCKET_MIN="1", NOLZSS_TEST_INJECT_PENDING="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_device_batch_merges_and_matches_one_by_one(native):
+    """the device-resident batch gathers its records into runs of independent sequences on the device; counts
+    equal the one-run-per-record path (NOLZSS_DEVICE_MERGE_BELOW is read once per process: the comparison run
+    is nolzss_factorize_device per record), other alphabets fall back to it, empty records count zero"""
+    import torch
+    rng = np.random.default_rng(31)
+    recs = _records(rng, 24, 30000, 200000) + [np.zeros(0, dtype=np.uint8), gen.random_dna(1, 3)]
+    d = [torch.from_numpy(np.ascontiguousarray(r)).cuda() for r in recs]
+    torch.cuda.synchronize()
+    ptrs = [t.data_ptr() if len(r) else 0 for t, r in zip(d, recs)]
+    lens = [len(r) for r in recs]
+    one_by_one = [native.factorize_device(p, n, emit=1)[0] if n else 0 for p, n in zip(ptrs, lens)]
+    m0, s0 = native.debug_batch_counters()
+    for emit in (0, 1):
+        assert native.factorize_batch_device(ptrs, lens, emit=emit) == one_by_one
+    m1, s1 = native.debug_batch_counters()
+    assert m1 - m0 == 2 * (len(recs) - 1)  # everything but the empty record went through merged runs
+    # a record with another alphabet: the whole run falls back to one run per record
+    other = recs[:3] + [np.frombuffer(b"ACGTNACGT" * 50, dtype=np.uint8)]
+    d2 = [torch.from_numpy(np.ascontiguousarray(r)).cuda() for r in other]
+    torch.cuda.synchronize()
+    got = native.factorize_batch_device([t.data_ptr() for t in d2], [len(r) for r in other], emit=0)
+    assert got == [oracle.count_factors(r) for r in other]
