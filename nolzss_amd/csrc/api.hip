@@ -1443,17 +1443,21 @@ bool run_merged_chunk(Context &ctx, const uint8_t *const *texts, const size_t *l
     const size_t c = ids.size();
     size_t n = c - 1;
     for (size_t j : ids) n += lens[j];
-    uint8_t *host = host_stage(ctx, n);
+    // long records go up one by one, straight into their place in the device text; short ones are gathered
+    // in the pinned staging buffer first (a copy call per 4 KiB record would cost more than the gather)
+    const bool direct = n / c >= (size_t(1) << 16);
+    uint8_t *host = direct ? nullptr : host_stage(ctx, n);
     std::vector<uint32_t> seps;
     seps.reserve(c - 1);
     {
         size_t at = 0;
         for (size_t k = 0; k < c; ++k) {
-            std::memcpy(host + at, texts[ids[k]], lens[ids[k]]);
+            if (!direct) std::memcpy(host + at, texts[ids[k]], lens[ids[k]]);
             at += lens[ids[k]];
             if (k + 1 < c) {
                 seps.push_back((uint32_t)at);
-                host[at++] = kBatchSeparator;
+                if (!direct) host[at] = kBatchSeparator;
+                ++at;
             }
         }
     }
@@ -1469,7 +1473,17 @@ bool run_merged_chunk(Context &ctx, const uint8_t *const *texts, const size_t *l
         ~Rewind() { a.rewind(m); }
     } rewind{arena, mark};
     uint8_t *d_text = arena.alloc<uint8_t>(n);
-    HIP_CHECK(hipMemcpyAsync(d_text, host, n, hipMemcpyHostToDevice, s));
+    if (direct) {
+        ProfScope ps(ctx.profiler(), "batch_upload", s, (double)n);
+        size_t at = 0;
+        for (size_t k = 0; k < c; ++k) {
+            HIP_CHECK(hipMemcpyAsync(d_text + at, texts[ids[k]], lens[ids[k]], hipMemcpyHostToDevice, s));
+            at += lens[ids[k]];
+            if (k + 1 < c) HIP_CHECK(hipMemsetAsync(d_text + at++, kBatchSeparator, 1, s));
+        }
+    } else {
+        HIP_CHECK(hipMemcpyAsync(d_text, host, n, hipMemcpyHostToDevice, s));
+    }
     PackedText text;
     void *d_recs = nullptr;
     uint32_t z = 0;
@@ -1701,6 +1715,44 @@ void factorize_many(const uint8_t *const *texts, const size_t *lens, size_t m, c
     const size_t run_bases = with_rc ? chunk_bases / 2 : chunk_bases;
     std::vector<size_t> singles;
     std::vector<std::vector<size_t>> chunks;
+    // Long records (plain mode): runs of about 2^28 bases, each record uploaded straight into the run's device
+    // text; one lane uploads while the other computes.
+    // (NOLZSS_BATCH_MERGE_LONG_BELOW=0: long records one pipeline run each, as before round 2; read per call)
+    const size_t long_below = [] {
+        const char *e = getenv("NOLZSS_BATCH_MERGE_LONG_BELOW");
+        return e ? (size_t)atoll(e) : (size_t(1) << 27);
+    }();
+    const size_t long_run_bases = [] {
+        const char *e = getenv("NOLZSS_BATCH_MERGE_LONG_BASES");
+        const long long v = e ? atoll(e) : 0;
+        return v > 0 ? (size_t)v : (size_t(1) << 28);
+    }();
+    std::vector<size_t> longs;
+    if (!with_rc && below > 0)
+        for (size_t j = 0; j < m; ++j)
+            if (lens[j] >= below && lens[j] < long_below) longs.push_back(j);
+    if (longs.size() >= 2) {
+        size_t total = 0;
+        for (size_t j : longs) total += lens[j] + 1;
+        size_t runs = div_up(total, long_run_bases);
+        if (runs < 2 && total >= (size_t(1) << 27)) runs = 2;
+        const size_t share = div_up(total, runs);
+        std::vector<size_t> cur;
+        size_t cur_bases = 0;
+        for (size_t j : longs) {
+            cur.push_back(j);
+            cur_bases += lens[j] + 1;
+            if (cur_bases >= share) {
+                chunks.push_back(std::move(cur));
+                cur.clear();
+                cur_bases = 0;
+            }
+        }
+        if (!cur.empty()) chunks.push_back(std::move(cur));
+    } else {
+        longs.clear();
+    }
+    const bool merge_longs = !longs.empty();
     {
         // equal shares: as many runs as the limit asks for, each with its part of the bases
         size_t short_bases = 0;
@@ -1713,7 +1765,7 @@ void factorize_many(const uint8_t *const *texts, const size_t *lens, size_t m, c
         for (size_t j = 0; j < m; ++j) {
             if (lens[j] == 0) continue;  // z = 0
             if (lens[j] >= below) {
-                singles.push_back(j);
+                if (!(merge_longs && lens[j] < long_below)) singles.push_back(j);
                 continue;
             }
             cur.push_back(j);

@@ -122,17 +122,30 @@ def test_other_alphabets_fall_back(native):
 
 
 def test_chunks_split_and_mix_with_long_records(native):
-    """a merge limit in the middle of the size range: long records one by one, the others merged"""
+    """a merge limit in the middle of the size range: the records below it merged in runs of their own, the
+    longer ones in runs of long records (uploaded one by one into the run's device text) or, with
+    NOLZSS_BATCH_MERGE_LONG_BELOW=0, one pipeline run each"""
     rng = np.random.default_rng(14)
     recs = _records(rng, 120, 100, 9000)
+    long_ones = sum(1 for r in recs if len(r) >= 4000)
+    assert 0 < long_ones < len(recs)
+    expected = [oracle.factors_array(r) for r in recs]
     merged0, single0 = native.debug_batch_counters()
     with merge_below(4000):
         counts, arrays = native.factorize_batch(recs, want_factors=True)
-    long_ones = sum(1 for r in recs if len(r) >= 4000)
-    assert 0 < long_ones < len(recs)
-    assert native.debug_batch_counters() == (merged0 + len(recs) - long_ones, single0 + long_ones)
-    for j, r in enumerate(recs):
-        assert _same(arrays[j], oracle.factors_array(r)), j
+    assert native.debug_batch_counters() == (merged0 + len(recs), single0)
+    for j in range(len(recs)):
+        assert _same(arrays[j], expected[j]), j
+    os.environ["NOLZSS_BATCH_MERGE_LONG_BELOW"] = "0"
+    try:
+        merged0, single0 = native.debug_batch_counters()
+        with merge_below(4000):
+            counts, arrays = native.factorize_batch(recs, want_factors=True)
+        assert native.debug_batch_counters() == (merged0 + len(recs) - long_ones, single0 + long_ones)
+    finally:
+        os.environ.pop("NOLZSS_BATCH_MERGE_LONG_BELOW", None)
+    for j in range(len(recs)):
+        assert _same(arrays[j], expected[j]), j
 
 
 @pytest.mark.timeout(600)
