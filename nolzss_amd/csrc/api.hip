@@ -156,6 +156,79 @@ void reserve_arena_for(Context &ctx, size_t n, size_t extra = 0) {
     ctx.arena.reserve(least > ctx.arena.capacity() ? least : ctx.arena.capacity());
 }
 
+// pinned upload buffer of the context (kept: pinning costs more than the copy it speeds up)
+uint8_t *host_stage(Context &ctx, size_t bytes) {
+    if (bytes > ctx.h_stage_cap) {
+        if (ctx.h_stage) (void)hipHostFree(ctx.h_stage);
+        ctx.h_stage = nullptr;
+        ctx.h_stage_cap = 0;
+        const size_t cap = (bytes + (size_t(1) << 22)) & ~((size_t(1) << 22) - 1);
+        HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&ctx.h_stage), cap));
+        ctx.h_stage_cap = cap;
+    }
+    return ctx.h_stage;
+}
+
+// ---- device -> host copies into pageable memory ------------------------------------------------
+// A plain hipMemcpy into a fresh malloc'ed block moves 1.25 GB of factor records in ~100 ms: the runtime
+// stages it through pinned memory with one copying thread, which also takes every first-touch page fault of
+// the block.  Large downloads are therefore staged here: a few host threads take 8 MiB chunks in turn, each
+// through its own pinned buffer (host_stage), the DMA of one chunk running while the others are emptied
+// (2^30 bases, host bytes in / factor array out: 265 -> 219 ms; NOLZSS_COPY_THREADS, default 4; 1 = plain
+// hipMemcpyAsync).  Uploads stay plain copies: pageable host memory already goes up at 50 GB/s (1 GiB of text
+// in 19-21 ms either way).
+constexpr size_t kCopyChunk = size_t(8) << 20;
+constexpr size_t kCopyThreshold = size_t(32) << 20;
+int copy_threads() {
+    static const int t = [] {
+        const char *e = getenv("NOLZSS_COPY_THREADS");
+        const long v = e ? atol(e) : 4;
+        return (int)(v < 1 ? 1 : (v > 16 ? 16 : v));
+    }();
+    return t;
+}
+
+// host -> device, ordered on ctx.stream
+void upload_bytes(Context &ctx, void *d_dst, const void *h_src, size_t n) {
+    HIP_CHECK(hipMemcpyAsync(d_dst, h_src, n, hipMemcpyHostToDevice, ctx.stream));
+}
+
+// device -> host, behind everything queued on ctx.stream; the bytes have arrived when this returns
+void download_bytes(Context &ctx, void *h_dst, const void *d_src, size_t n) {
+    const int T = copy_threads();
+    if (n < kCopyThreshold || T <= 1) {
+        HIP_CHECK(hipMemcpyAsync(h_dst, d_src, n, hipMemcpyDeviceToHost, ctx.stream));
+        HIP_CHECK(hipStreamSynchronize(ctx.stream));
+        return;
+    }
+    uint8_t *ring = host_stage(ctx, (size_t)T * kCopyChunk);
+    const size_t chunks = div_up(n, kCopyChunk);
+    std::atomic<size_t> next{0};
+    std::vector<hipError_t> err((size_t)T, hipSuccess);
+    auto work = [&](int t) {
+        hipError_t e = hipSetDevice(ctx.device);
+        hipEvent_t ev = nullptr;
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        uint8_t *buf = ring + (size_t)t * kCopyChunk;
+        while (e == hipSuccess) {
+            const size_t c = next.fetch_add(1);
+            if (c >= chunks) break;
+            const size_t off = c * kCopyChunk, len = n - off < kCopyChunk ? n - off : kCopyChunk;
+            e = hipMemcpyAsync(buf, static_cast<const uint8_t *>(d_src) + off, len, hipMemcpyDeviceToHost, ctx.stream);
+            if (e == hipSuccess) e = hipEventRecord(ev, ctx.stream);
+            if (e == hipSuccess) e = hipEventSynchronize(ev);
+            if (e == hipSuccess) std::memcpy(static_cast<uint8_t *>(h_dst) + off, buf, len);
+        }
+        if (ev) (void)hipEventDestroy(ev);
+        err[(size_t)t] = e;
+    };
+    std::vector<std::thread> threads;
+    for (int t = 1; t < T; ++t) threads.emplace_back(work, t);
+    work(0);
+    for (auto &th : threads) th.join();
+    for (hipError_t e : err) HIP_CHECK(e);
+}
+
 struct DebugOut {
     uint32_t *sa = nullptr, *isa = nullptr, *lcp = nullptr, *lstar = nullptr;
 };
@@ -201,10 +274,11 @@ size_t run_plain(Context &ctx, const uint8_t *d_text, size_t n, size_t start_pos
         nolzss_factor *h = static_cast<nolzss_factor *>(alloc_factor_block(sizeof(nolzss_factor) * (size_t)z));
         if (!h) throw std::bad_alloc();
         ProfScope ps(ctx.profiler(), "factors_d2h", s);
-        hipError_t e = hipMemcpyAsync(h, d_recs, sizeof(nolzss_factor) * (size_t)z, hipMemcpyDeviceToHost, s);
-        if (e != hipSuccess) {
+        try {
+            download_bytes(ctx, h, d_recs, sizeof(nolzss_factor) * (size_t)z);
+        } catch (...) {
             std::free(h);
-            HIP_CHECK(e);
+            throw;
         }
         *out_host = h;
     }
@@ -232,7 +306,7 @@ size_t run_plain_host(Context &ctx, const uint8_t *text, size_t n, size_t start_
     uint8_t *d_text = ctx.arena.alloc<uint8_t>(n);
     {
         ProfScope ps(ctx.profiler(), "text_h2d", ctx.stream);
-        HIP_CHECK(hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, ctx.stream));
+        upload_bytes(ctx, d_text, text, n);
     }
     size_t z;
     try {
@@ -481,18 +555,14 @@ size_t run_rc_host(Context &ctx, const uint8_t *S, size_t m, size_t start_pos, n
     size_t z = 0;
     try {
         uint8_t *d_S = ctx.arena.alloc<uint8_t>(m);
-        HIP_CHECK(hipMemcpyAsync(d_S, S, m, hipMemcpyHostToDevice, ctx.stream));
+        upload_bytes(ctx, d_S, S, m);
         void *d_recs = nullptr;
         z = run_rc_pipeline(ctx, d_S, m, start_pos, out ? &d_recs : nullptr);
         if (out && z) {
             nolzss_factor *h = static_cast<nolzss_factor *>(alloc_factor_block(sizeof(nolzss_factor) * z));
             if (!h) throw std::bad_alloc();
-            hipError_t e = hipMemcpyAsync(h, d_recs, sizeof(nolzss_factor) * z, hipMemcpyDeviceToHost, ctx.stream);
-            if (e != hipSuccess) {
-                std::free(h);
-                HIP_CHECK(e);
-            }
-            *out = h;
+            *out = h;  // (freed below if the download fails)
+            download_bytes(ctx, h, d_recs, sizeof(nolzss_factor) * z);
         }
         HIP_CHECK(hipStreamSynchronize(ctx.stream));
         ctx.prof.collect();
@@ -672,7 +742,7 @@ static void dna_w_rc_common(const uint8_t *text, size_t n, int device, nolzss_fa
     reserve_arena_for(ctx, m, m + n);
     uint8_t *d_T = ctx.arena.alloc<uint8_t>(n);
     uint8_t *d_S = ctx.arena.alloc<uint8_t>(m);
-    HIP_CHECK(hipMemcpyAsync(d_T, text, n, hipMemcpyHostToDevice, ctx.stream));
+    upload_bytes(ctx, d_T, text, n);
     const uint32_t bad = prepare_single_rc_on_device(ctx, d_T, (uint32_t)n, d_S);
     if (bad != 0xffffffffu)  // factorizer.cpp:86-95
         throw std::runtime_error("Invalid nucleotide '" + std::string(1, (char)text[bad]) + "' found in sequence 0");
@@ -681,10 +751,11 @@ static void dna_w_rc_common(const uint8_t *text, size_t n, int device, nolzss_fa
     if (out && count) {
         nolzss_factor *h = static_cast<nolzss_factor *>(alloc_factor_block(sizeof(nolzss_factor) * count));
         if (!h) throw std::bad_alloc();
-        hipError_t e = hipMemcpyAsync(h, d_recs, sizeof(nolzss_factor) * count, hipMemcpyDeviceToHost, ctx.stream);
-        if (e != hipSuccess) {
+        try {
+            download_bytes(ctx, h, d_recs, sizeof(nolzss_factor) * count);
+        } catch (...) {
             std::free(h);
-            HIP_CHECK(e);
+            throw;
         }
         *out = h;
     }
@@ -1408,19 +1479,6 @@ __global__ void batch_rebase_kernel(nolzss_factor *__restrict__ recs, uint32_t z
 // Factorizes records ids[0..c) (all non-empty) in one run.  Returns false, with nothing written, when
 // the records hold anything but A/C/G/T.  Factors of all records arrive in ONE malloc'ed block
 // (appended to `blocks`); fs[id] points into it.
-// pinned upload buffer of the context (kept: pinning costs more than the copy it speeds up)
-uint8_t *host_stage(Context &ctx, size_t bytes) {
-    if (bytes > ctx.h_stage_cap) {
-        if (ctx.h_stage) (void)hipHostFree(ctx.h_stage);
-        ctx.h_stage = nullptr;
-        ctx.h_stage_cap = 0;
-        const size_t cap = (bytes + (size_t(1) << 22)) & ~((size_t(1) << 22) - 1);
-        HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&ctx.h_stage), cap));
-        ctx.h_stage_cap = cap;
-    }
-    return ctx.h_stage;
-}
-
 // host memory for a block of factor records: large blocks on transparent huge pages, where the
 // first touch of the download costs one fault per 2 MiB instead of one per 4 KiB
 void *alloc_factor_block(size_t bytes) {
@@ -1477,7 +1535,7 @@ bool run_merged_chunk(Context &ctx, const uint8_t *const *texts, const size_t *l
         ProfScope ps(ctx.profiler(), "batch_upload", s, (double)n);
         size_t at = 0;
         for (size_t k = 0; k < c; ++k) {
-            HIP_CHECK(hipMemcpyAsync(d_text + at, texts[ids[k]], lens[ids[k]], hipMemcpyHostToDevice, s));
+            upload_bytes(ctx, d_text + at, texts[ids[k]], lens[ids[k]]);
             at += lens[ids[k]];
             if (k + 1 < c) HIP_CHECK(hipMemsetAsync(d_text + at++, kBatchSeparator, 1, s));
         }
@@ -1531,10 +1589,11 @@ bool run_merged_chunk(Context &ctx, const uint8_t *const *texts, const size_t *l
         KERNEL_CHECK();
         block = static_cast<nolzss_factor *>(alloc_factor_block(sizeof(nolzss_factor) * (size_t)z));
         if (!block) throw std::bad_alloc();
-        const hipError_t e = hipMemcpyAsync(block, recs, sizeof(nolzss_factor) * (size_t)z, hipMemcpyDeviceToHost, s);
-        if (e != hipSuccess) {
+        try {
+            download_bytes(ctx, block, recs, sizeof(nolzss_factor) * (size_t)z);
+        } catch (...) {
             std::free(block);
-            HIP_CHECK(e);
+            throw;
         }
     }
     const hipError_t e = hipStreamSynchronize(s);

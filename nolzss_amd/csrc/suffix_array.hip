@@ -359,17 +359,19 @@ __device__ __forceinline__ uint32_t lane_next(uint32_t v, uint32_t edge) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x130, 0xf, 0xf, false);  // wave_shl:1
 }
 
-// kDnaFast (round 0 of the bucketed 2-bit key sort): the key layout is known at compile time -- 34 symbol
-// bits, 6-bit tag, no low bits, no sequence numbers, short suffixes flagged -- which folds the shifts and
-// masks of every item (the kernel is bound by VALU issue: ~1300 instructions per wavefront and 512 suffixes)
-template <bool kRound0, bool kDnaFast>
+// kLayout (round 0 of the bucketed 2-bit key sorts): the key layout is known at compile time, which folds the
+// shifts and masks of every item (the kernel is bound by VALU issue: ~1300 instructions per wavefront and 512
+// suffixes).  1 = plain DNA: 34 symbol bits, 6-bit tag, no low bits, no sequence numbers, short suffixes flagged;
+// 2 = long independent records, bucket = record: 28 symbol bits, 4-bit tag, the record number above bit 32.
+template <bool kRound0, int kLayout>
 __global__ __launch_bounds__(kFuseThreads) void regroup_kernel(RegroupArgs A) {
+    constexpr bool kDnaFast = kLayout != 0;  // (bucketed, compile-time layout)
     const int low_bits = kDnaFast ? 0 : A.low_bits;
-    const int tag_bits = kDnaFast ? KeyLayout<2>::kTagBits : A.tag_bits;
-    const int sym_bits = kDnaFast ? 2 * KeyLayout<2>::kSyms : A.sym_bits;
+    const int tag_bits = kLayout == 1 ? KeyLayout<2>::kTagBits : (kLayout == 2 ? kRecTagBits : A.tag_bits);
+    const int sym_bits = kLayout == 1 ? 2 * KeyLayout<2>::kSyms : (kLayout == 2 ? 2 * kRecSyms : A.sym_bits);
     const int bits_shift = kDnaFast ? 1 : A.bits_shift;
-    const uint32_t short_tag = kDnaFast ? (uint32_t)KeyLayout<2>::kSyms : A.short_tag;
-    const uint32_t seq_shift = kDnaFast ? 0u : A.seq_shift;
+    const uint32_t short_tag = kLayout == 1 ? (uint32_t)KeyLayout<2>::kSyms : (kLayout == 2 ? 0u : A.short_tag);
+    const uint32_t seq_shift = kLayout == 1 ? 0u : (kLayout == 2 ? 32u : A.seq_shift);
     constexpr int kWaves = kFuseThreads / 64;
     constexpr int kSegs = kFuseItems * kWaves;  // 64-element segments of the tile, in element order
     __shared__ uint32_t s_tile;
@@ -1476,10 +1478,14 @@ uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *grp, const 
         const bool fast_layout = kRound0 && keys32 && seg && low_bits == 0 && tag_bits == KeyLayout<2>::kTagBits &&
                                  sym_bits == 2 * KeyLayout<2>::kSyms && bits == 2 && seq_shift == 0 &&
                                  short_tag == (uint32_t)KeyLayout<2>::kSyms;
+        const bool rec_layout = kRound0 && keys32 && seg && low_bits == 0 && tag_bits == kRecTagBits &&
+                                sym_bits == 2 * kRecSyms && bits == 2 && seq_shift == 32 && short_tag == 0;
         if (fast_layout)
-            regroup_kernel<kRound0, kRound0><<<(unsigned)tiles, kFuseThreads, 0, s>>>(A);  // (kDnaFast only exists for round 0)
+            regroup_kernel<kRound0, kRound0 ? 1 : 0><<<(unsigned)tiles, kFuseThreads, 0, s>>>(A);  // (layouts only exist for round 0)
+        else if (rec_layout)
+            regroup_kernel<kRound0, kRound0 ? 2 : 0><<<(unsigned)tiles, kFuseThreads, 0, s>>>(A);
         else
-            regroup_kernel<kRound0, false><<<(unsigned)tiles, kFuseThreads, 0, s>>>(A);
+            regroup_kernel<kRound0, 0><<<(unsigned)tiles, kFuseThreads, 0, s>>>(A);
         KERNEL_CHECK();
         if (want_phases) {
             unsigned long long h[8];
