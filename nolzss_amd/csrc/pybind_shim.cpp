@@ -50,19 +50,41 @@ struct Owned {  // library-owned factor array
     ~Owned() { nolzss_free(f); }
 };
 
+// The list of int tuples is what a Python caller waits for (5*10^7 of them for the 2^30-base benchmark text):
+// built with the C API directly -- py::make_tuple goes through three py::object casts and a std::array per
+// tuple, twice the time.
+inline PyObject *py_u64(uint64_t v) {
+    PyObject *o = PyLong_FromUnsignedLongLong(v);
+    if (!o) throw py::error_already_set();
+    return o;
+}
+
 py::list tuples3(const Owned &o) {  // bindings.cpp:74-76
     py::list out(o.z);
-    for (size_t i = 0; i < o.z; ++i)
-        PyList_SET_ITEM(out.ptr(), (Py_ssize_t)i, py::make_tuple(o.f[i].start, o.f[i].length, o.f[i].ref).release().ptr());
+    for (size_t i = 0; i < o.z; ++i) {
+        PyObject *t = PyTuple_New(3);
+        if (!t) throw py::error_already_set();
+        PyList_SET_ITEM(out.ptr(), (Py_ssize_t)i, t);  // (the list owns it from here, also on an exception)
+        PyTuple_SET_ITEM(t, 0, py_u64(o.f[i].start));
+        PyTuple_SET_ITEM(t, 1, py_u64(o.f[i].length));
+        PyTuple_SET_ITEM(t, 2, py_u64(o.f[i].ref));
+    }
     return out;
 }
 
 py::list tuples4(const Owned &o) {  // bindings.cpp:226: (start, length, ref without the mask, is_rc)
     py::list out(o.z);
-    for (size_t i = 0; i < o.z; ++i)
-        PyList_SET_ITEM(out.ptr(), (Py_ssize_t)i,
-                        py::make_tuple(o.f[i].start, o.f[i].length, o.f[i].ref & ~NOLZSS_RC_MASK,
-                                       (o.f[i].ref & NOLZSS_RC_MASK) != 0).release().ptr());
+    for (size_t i = 0; i < o.z; ++i) {
+        PyObject *t = PyTuple_New(4);
+        if (!t) throw py::error_already_set();
+        PyList_SET_ITEM(out.ptr(), (Py_ssize_t)i, t);
+        PyTuple_SET_ITEM(t, 0, py_u64(o.f[i].start));
+        PyTuple_SET_ITEM(t, 1, py_u64(o.f[i].length));
+        PyTuple_SET_ITEM(t, 2, py_u64(o.f[i].ref & ~NOLZSS_RC_MASK));
+        PyObject *flag = (o.f[i].ref & NOLZSS_RC_MASK) ? Py_True : Py_False;
+        Py_INCREF(flag);
+        PyTuple_SET_ITEM(t, 3, flag);
+    }
     return out;
 }
 
@@ -75,6 +97,22 @@ struct PyFactor {  // py::class_<Factor>, bindings.cpp:44-48
 PYBIND11_MODULE(_noLZSS, m) {
     m.doc() = "Non-overlapping Lempel-Ziv-Storer-Szymanski factorization on MI355X (gfx950): the compiled "
               "module of the reference package, bound to libnolzss_hip.so";
+
+    // (diagnostics) n synthetic factors -> tuples: the cost of the Python-visible result alone
+    m.def("_debug_tuples", [](size_t n, int kind) {
+        Owned o;
+        o.f = static_cast<nolzss_factor *>(std::malloc(sizeof(nolzss_factor) * (n ? n : 1)));
+        if (!o.f) throw std::bad_alloc();
+        o.z = n;
+        for (size_t i = 0; i < n; ++i) o.f[i] = nolzss_factor{i * 20, 1 + i % 40, (i * 2654435761ull) % (i * 20 + 1)};
+        if (kind == 2) {
+            py::list out(o.z);
+            for (size_t i = 0; i < o.z; ++i)
+                PyList_SET_ITEM(out.ptr(), (Py_ssize_t)i, py::make_tuple(o.f[i].start, o.f[i].length, o.f[i].ref).release().ptr());
+            return out;
+        }
+        return kind == 1 ? tuples4(o) : tuples3(o);
+    }, py::arg("n"), py::arg("kind") = 0);
 
     py::class_<PyFactor>(m, "Factor", "A factor: start, length, ref (RC_MASK stripped), is_rc")
         .def(py::init<>())
