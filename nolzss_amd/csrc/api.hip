@@ -1440,6 +1440,23 @@ namespace {
 // (record, suffix), so no match crosses a record, the separators become literal factors, and the
 // records' factor lists are the stretches between them, rebased to the record's start.
 constexpr uint8_t kBatchSeparator = 0x01;
+
+// Runs of long records: for the duration of the run the context carries the plan that keeps the two permutation
+// scatters of the pipeline inside the records (radix_sort.hpp; NOLZSS_NO_RECORD_SCATTER=1 switches it off)
+struct RecordPlanScope {
+    Context &ctx;
+    RecordScatterPlan plan;
+    RecordPlanScope(Context &c, const std::vector<uint32_t> &seps, uint32_t n) : ctx(c) {
+        static const bool off = getenv("NOLZSS_NO_RECORD_SCATTER") != nullptr;
+        if (off || seps.empty()) return;
+        std::vector<uint32_t> terms(seps);
+        terms.push_back(n);
+        if (record_scatter_plan(terms, n, ctx.arena, ctx.stream, plan)) ctx.rec_plan = &plan;
+    }
+    ~RecordPlanScope() { ctx.rec_plan = nullptr; }
+    RecordPlanScope(const RecordPlanScope &) = delete;
+    RecordPlanScope &operator=(const RecordPlanScope &) = delete;
+};
 constexpr size_t kMergeChunkBases = size_t(1) << 25;  // bases per merged run (5.5 Gbases/s on the device from 2^24 up)
 constexpr size_t kMergeLanes = 2;  // runs in flight per device: one gathers / downloads while the other computes
 
@@ -1559,6 +1576,7 @@ bool run_merged_chunk(Context &ctx, const uint8_t *const *texts, const size_t *l
         z = run_rc_pipeline_packed(ctx, text, 0, &d_recs);
     } else {
         if (!pack_independent_text(ctx, d_text, n, seps, text)) return false;
+        RecordPlanScope plan_scope(ctx, seps, (uint32_t)n);
         uint32_t *sa = arena.alloc<uint32_t>(n);
         uint32_t *isa = arena.alloc<uint32_t>(n);
         uint32_t *lcp = arena.alloc<uint32_t>(n + 1);
@@ -1697,6 +1715,7 @@ bool run_merged_chunk_device(Context &ctx, const void *const *d_texts, const siz
     HIP_CHECK(hipStreamSynchronize(s));  // table is a local vector
     PackedText text;
     if (!pack_independent_text(ctx, d_text, n, seps, text)) return false;
+    RecordPlanScope plan_scope(ctx, seps, (uint32_t)n);
     uint32_t *sa = arena.alloc<uint32_t>(n);
     uint32_t *isa = arena.alloc<uint32_t>(n);
     uint32_t *lcp = arena.alloc<uint32_t>(n + 1);

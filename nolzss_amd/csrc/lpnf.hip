@@ -255,7 +255,7 @@ uint32_t build_lstar(Context &ctx, uint32_t n, const uint32_t *sa, const uint32_
         ProfScope ps(ctx.profiler(), "lpf_to_text_order", s);
         uint32_t *idx[2] = {const_cast<uint32_t *>(sa), scratch_idx};
         uint32_t *val[2] = {by_rank, scratch_val};
-        bucketed_scatter(idx, val, n, lstar, n, ctx.arena, s, ctx.profiler(), true);
+        bucketed_scatter(idx, val, n, lstar, n, ctx.arena, s, ctx.profiler(), true, true, ctx.rec_plan);
     }
     uint32_t h[2] = {0, 0};
     read_totals(h);

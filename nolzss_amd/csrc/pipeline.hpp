@@ -16,6 +16,9 @@ struct Context {
     uint32_t *h_pinned = nullptr;  // 64 words of pinned host memory for small read-backs
     uint8_t *h_stage = nullptr;    // pinned host staging for uploads (grow-only, merged batch)
     size_t h_stage_cap = 0;
+    // merged batch of long records (set for the duration of one run): the two permutation scatters of the
+    // pipeline -- rank[sa[r]] and L*[sa[r]] -- stay inside the records (radix_sort.hpp, RecordScatterPlan)
+    const struct RecordScatterPlan *rec_plan = nullptr;
 
     Profiler *profiler() { return prof.enabled() ? &prof : nullptr; }
     // copy `count` (<= 64) device words to host and wait for them

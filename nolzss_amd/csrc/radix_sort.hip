@@ -136,6 +136,19 @@ struct RecordTextSrc {
     __device__ __forceinline__ uint64_t window(size_t) const { return 0; }
 };
 
+// (position, value) pairs of a block-diagonal permutation (RecordScatterPlan): the key is the position
+// inside the record, ext.aux = first position of the tile's record
+struct LocalIdxSrc {
+    const uint32_t *__restrict__ idx;
+    const uint32_t *__restrict__ vals;
+    __device__ __forceinline__ uint32_t key(size_t i, const TileExtent &ext) const { return idx[i] - ext.aux; }
+    __device__ __forceinline__ uint32_t val(size_t i) const { return vals[i]; }
+    __device__ __forceinline__ uint32_t hist_raw(size_t i, int, const TileExtent &ext) const { return idx[i] - ext.aux; }
+    __device__ __forceinline__ uint32_t hist_digit(uint32_t raw, int shift) const { return digit_of(raw, shift); }
+    __device__ __forceinline__ bool digits_from_window(int) const { return false; }
+    __device__ __forceinline__ uint64_t window(size_t) const { return 0; }
+};
+
 template <typename KeyT, typename Src>
 __global__ __launch_bounds__(kThreads) void rs_hist_kernel(Src src, size_t n, int shift,
                                                            uint32_t *__restrict__ tile_hist,
@@ -332,7 +345,7 @@ void radix_pass(Src src, OutT *keys_out, uint32_t *vals_out, size_t n, int shift
         // classes of launches, so that the bandwidth of the large passes can be told from the many
         // small sorts of the doubling rounds: rs_scatter.{text|u64|u32}[.small]
         const bool small = n < (size_t(1) << 24);
-        const char *cls = std::is_same<Src, ArraySrc<KeyT>>::value
+        const char *cls = (std::is_same<Src, ArraySrc<KeyT>>::value || std::is_same<Src, LocalIdxSrc>::value)
                               ? (sizeof(KeyT) == 8 ? (small ? "rs_scatter.u64.small" : "rs_scatter.u64")
                                                    : (small ? "rs_scatter.u32.small" : "rs_scatter.u32"))
                               : "rs_scatter.text";
@@ -421,12 +434,166 @@ __global__ __launch_bounds__(kThreads) void window_scatter_kernel(const IdxT *__
     for (uint32_t t = threadIdx.x; t < len; t += kThreads) out[base + t] = s_out[t];
 }
 
+// the same for the windows of a RecordScatterPlan: window b = list elements [win[3b], +win[3b+2]) -> target
+// elements [win[3b+1], +win[3b+2]); the low window_bits of an index are its place in the window
+__global__ __launch_bounds__(kThreads) void record_window_scatter_kernel(const uint16_t *__restrict__ idx,
+                                                                         const uint32_t *__restrict__ val,
+                                                                         uint32_t *__restrict__ out,
+                                                                         const uint32_t *__restrict__ win,
+                                                                         int window_bits) {
+    __shared__ uint32_t s_out[1 << kWindowBitsMax];
+    const uint32_t W = 1u << window_bits;
+    const size_t base = win[3 * (size_t)blockIdx.x];
+    const size_t obase = win[3 * (size_t)blockIdx.x + 1];
+    const uint32_t len = win[3 * (size_t)blockIdx.x + 2];
+    constexpr int kBatch = 8;
+    for (uint32_t t0 = 0; t0 < len; t0 += kBatch * kThreads) {
+        uint32_t ii[kBatch], vv[kBatch];
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            const uint32_t t = t0 + (uint32_t)j * kThreads + threadIdx.x;
+            ii[j] = t < len ? (uint32_t)idx[base + t] : 0u;
+            vv[j] = t < len ? val[base + t] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            const uint32_t t = t0 + (uint32_t)j * kThreads + threadIdx.x;
+            if (t < len) s_out[ii[j] & (W - 1u)] = vv[j];
+        }
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < len; t += kThreads) out[obase + t] = s_out[t];
+}
+
+__global__ void separator_scatter_kernel(const uint32_t *__restrict__ sep, uint32_t count,
+                                         const uint32_t *__restrict__ idx, const uint32_t *__restrict__ val,
+                                         uint32_t *__restrict__ out, uint32_t *__restrict__ err) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    const uint32_t r = sep[2 * k], p = sep[2 * k + 1];
+    if (idx[r] != p) atomicOr(err, 1u);  // the separator suffix is the first of its record
+    out[p] = val[r];
+}
+
 }  // namespace
 
+bool record_scatter_plan(const std::vector<uint32_t> &h_terms, uint32_t n, Arena &arena, hipStream_t stream,
+                         RecordScatterPlan &plan) {
+    plan = RecordScatterPlan{};
+    const uint32_t nb = (uint32_t)h_terms.size();
+    // (partial tiles and windows cost 4096 / the average record: NOLZSS_REC_BUCKET_MIN, as for the key sort)
+    static const uint64_t rec_min =
+        getenv("NOLZSS_REC_BUCKET_MIN") ? (uint64_t)atoll(getenv("NOLZSS_REC_BUCKET_MIN")) : (uint64_t(1) << 16);
+    if (nb < 2 || h_terms.back() != n || rec_min == 0 || (uint64_t)nb * rec_min > (uint64_t)n) return false;
+    constexpr int wb = kWindowBitsMax;
+    // bucket k = the BASES of record k: ranks [first_k, end_k) hold positions [start_k, start_k + len_k)
+    // (the separator behind a record is the smallest suffix of the record: its first rank)
+    std::vector<uint32_t> tab(5 * ((size_t)nb + 1)), sep(2 * ((size_t)nb - 1));
+    uint32_t *h_first = tab.data(), *h_tile0 = h_first + nb + 1, *h_prev = h_tile0 + nb + 1, *h_next = h_prev + nb + 1,
+             *h_aux = h_next + nb + 1;
+    std::vector<uint32_t> win;
+    uint32_t start = 0, dense = 0;
+    h_tile0[0] = 0;
+    for (uint32_t k = 0; k < nb; ++k) {
+        const uint32_t end = k + 1 < nb ? h_terms[k] + 1 : n;     // end of the record's ranks / positions
+        const uint32_t len = (k + 1 < nb ? h_terms[k] : n) - start;  // bases
+        if (len == 0 || len > (1u << (wb + kRadixBits))) return false;
+        h_first[k] = k + 1 < nb ? start + 1 : start;  // first base rank
+        h_aux[k] = start;
+        h_tile0[k + 1] = h_tile0[k] + (uint32_t)div_up((size_t)len, kTile);
+        h_prev[k] = k ? k - 1 : 0xffffffffu;
+        h_next[k] = k + 1 < nb ? k + 1 : 0xffffffffu;
+        if (k + 1 < nb) {
+            sep[2 * (size_t)k] = start;             // rank of the separator suffix
+            sep[2 * (size_t)k + 1] = h_terms[k];    // its position
+        }
+        for (uint32_t w0 = 0; w0 < len; w0 += 1u << wb) {
+            win.push_back(dense + w0);
+            win.push_back(start + w0);
+            win.push_back(len - w0 < (1u << wb) ? len - w0 : (1u << wb));
+        }
+        dense += len;
+        start = end;
+    }
+    h_first[nb] = n;
+    h_prev[nb] = h_next[nb] = h_aux[nb] = 0;
+    // (the separator ranks lie between the buckets and belong to none: the tile descriptors are written here,
+    // on the host, instead of by seg_desc_kernel, whose buckets follow each other without gaps)
+    const uint32_t num_tiles = h_tile0[nb];
+    std::vector<uint32_t> desc((size_t)num_tiles * kSegDescWords);
+    {
+        uint32_t s0 = 0;
+        for (uint32_t k = 0; k < nb; ++k) {
+            const uint32_t len = (k + 1 < nb ? h_terms[k] : n) - s0;
+            const uint32_t first = h_first[k], t0 = h_tile0[k], nt = h_tile0[k + 1] - t0;
+            for (uint32_t local = 0; local < nt; ++local) {
+                uint32_t *d = desc.data() + (size_t)(t0 + local) * kSegDescWords;
+                const uint32_t f = first + local * (uint32_t)kTile, e = first + len;
+                d[0] = f;
+                d[1] = e - f < (uint32_t)kTile ? e - f : (uint32_t)kTile;
+                d[2] = k;
+                d[3] = t0 * (uint32_t)kBins + local;
+                d[4] = nt;
+                d[5] = first;
+                d[6] = e;
+                d[7] = h_prev[k];
+                d[8] = h_next[k];
+                d[9] = h_aux[k];
+                d[10] = d[11] = 0;
+            }
+            s0 = k + 1 < nb ? h_terms[k] + 1 : n;
+        }
+    }
+    uint32_t *d_desc = arena.alloc<uint32_t>(desc.size() + 4);
+    uint32_t *d_win = arena.alloc<uint32_t>(win.size());
+    uint32_t *d_sep = arena.alloc<uint32_t>(sep.size() + 2);
+    HIP_CHECK(hipMemcpyAsync(d_desc, desc.data(), desc.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(d_win, win.data(), win.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(d_sep, sep.data(), sep.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));  // local vectors
+    plan.seg.desc = d_desc;
+    plan.seg.num_tiles = num_tiles;
+    plan.win = d_win;
+    plan.num_windows = (uint32_t)(win.size() / 3);
+    plan.sep = d_sep;
+    plan.num_seps = nb - 1;
+    plan.n = n;
+    plan.window_bits = wb;
+    return true;
+}
+
 void bucketed_scatter(uint32_t *idx[2], uint32_t *val[2], size_t count, uint32_t *out, uint32_t n_out,
-                      Arena &arena, hipStream_t stream, Profiler *prof, bool keep_input, bool keep_val) {
+                      Arena &arena, hipStream_t stream, Profiler *prof, bool keep_input, bool keep_val,
+                      const RecordScatterPlan *plan) {
     if (count == 0) return;
     const size_t amark = arena.mark();
+    if (plan && plan->seg.desc && count == n_out && n_out == plan->n) {
+        // block-diagonal permutation: one pass by the window inside the record, then the windows
+        uint16_t *idx16 = reinterpret_cast<uint16_t *>(idx[1]);
+        uint32_t *hist = arena.alloc<uint32_t>((size_t)kBins * plan->seg.num_tiles);
+        uint32_t *err = arena.alloc<uint32_t>(1);
+        HIP_CHECK(hipMemsetAsync(err, 0, sizeof(uint32_t), stream));
+        radix_pass<uint32_t, uint16_t>(LocalIdxSrc{idx[0], val[0]}, idx16, val[1], count, plan->window_bits, hist,
+                                       plan->seg.num_tiles, 4.0 * (double)count, 14.0 * (double)count, arena, stream,
+                                       prof, plan->seg);
+        {
+            ProfScope ps(prof, "window_scatter", stream, 10.0 * (double)count);
+            record_window_scatter_kernel<<<plan->num_windows, kThreads, 0, stream>>>(idx16, val[1], out, plan->win,
+                                                                                    plan->window_bits);
+            KERNEL_CHECK();
+            if (plan->num_seps) {
+                separator_scatter_kernel<<<(unsigned)div_up(plan->num_seps, kThreads), kThreads, 0, stream>>>(
+                    plan->sep, plan->num_seps, idx[0], val[0], out, err);
+                KERNEL_CHECK();
+            }
+        }
+        uint32_t h_err = 0;
+        HIP_CHECK(hipMemcpyAsync(&h_err, err, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        arena.rewind(amark);
+        if (h_err) throw HipError("record scatter: a separator suffix is not the first of its record");
+        return;
+    }
     int nbits = 1;
     while (nbits < 32 && (1ull << nbits) < (uint64_t)n_out) ++nbits;
     const bool big = (size_t)n_out * 4 > (size_t(64) << 20) && count > (size_t(1) << 22);

@@ -28,6 +28,7 @@ struct TileExtent {
     size_t hist0;      // index of (bin 0, this tile) in the bin-major histogram table
     uint32_t hstride;  // distance between the bins of this tile in that table
     uint32_t bkt_first, bkt_end, prev_ne, next_ne;  // (segmented only)
+    uint32_t aux;      // (segmented only) one word per bucket for the source of the pass
 };
 
 // tile -> elements; without a SegView tiles are the consecutive kSortTile-element blocks of [0, n)
@@ -42,6 +43,7 @@ __device__ __forceinline__ TileExtent tile_extent(uint32_t tile, size_t n, uint3
         e.bkt_first = 0;
         e.bkt_end = (uint32_t)n;
         e.prev_ne = e.next_ne = 0;
+        e.aux = 0;
         return e;
     }
     const uint4 *d = reinterpret_cast<const uint4 *>(seg.desc + (size_t)tile * kSegDescWords);  // uniform: scalar loads
@@ -55,6 +57,7 @@ __device__ __forceinline__ TileExtent tile_extent(uint32_t tile, size_t n, uint3
     e.bkt_end = b.z;
     e.prev_ne = b.w;
     e.next_ne = c.x;
+    e.aux = c.y;
     return e;
 }
 
@@ -105,7 +108,28 @@ void radix_sort_record_keys(const PackedText &text, const std::vector<uint32_t> 
 // the same size.  With keep_input the input arrays survive (a third pair of buffers is taken
 // from the arena); otherwise they are used as scratch too.  The pointer arrays may be updated.
 // keep_val = false (with keep_input): only idx[0] survives, val[0] is used as a ping-pong buffer too.
+//
+// plan (optional): the target is a text of independent RECORDS and the pairs are (position, value) in suffix-
+// array order of such a text -- a block-diagonal permutation: the ranks of a record hold the positions of that
+// record (record_scatter_plan).  Then ONE segmented radix pass (the record is the bucket, the digit the window
+// inside the record) and the window scatter do it, 28 instead of 48 bytes per pair; idx[0] / val[0] survive,
+// idx[1] / val[1] are the only scratch.
+struct RecordScatterPlan {
+    SegView seg;                    // the base positions of every record as one bucket (ranks = positions)
+    const uint32_t *win = nullptr;  // per window: first list element, first target element, elements
+    uint32_t num_windows = 0;
+    const uint32_t *sep = nullptr;  // per separator: its rank (the first of its record) and its position
+    uint32_t num_seps = 0;
+    uint32_t n = 0;
+    int window_bits = 0;
+};
 void bucketed_scatter(uint32_t *idx[2], uint32_t *val[2], size_t count, uint32_t *out, uint32_t n_out,
-                      Arena &arena, hipStream_t stream, Profiler *prof, bool keep_input, bool keep_val = true);
+                      Arena &arena, hipStream_t stream, Profiler *prof, bool keep_input, bool keep_val = true,
+                      const RecordScatterPlan *plan = nullptr);
+// The plan for a text of n symbols whose records end at h_terms[k] (separator positions, the last entry = n);
+// false when the shape does not allow it (a record longer than 2^22 bases, or too many short ones).  The
+// tables live in the arena (not released here).
+bool record_scatter_plan(const std::vector<uint32_t> &h_terms, uint32_t n, Arena &arena, hipStream_t stream,
+                         RecordScatterPlan &plan);
 
 }  // namespace nolzss

@@ -1848,7 +1848,7 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         const size_t smark = arena.mark();
         uint32_t *idx[2] = {sa, arena.alloc<uint32_t>(n)};
         uint32_t *val[2] = {rank_by_slot, arena.alloc<uint32_t>(n)};
-        bucketed_scatter(idx, val, n, rank, n, arena, s, ctx.profiler(), true, /*keep_val=*/false);
+        bucketed_scatter(idx, val, n, rank, n, arena, s, ctx.profiler(), true, /*keep_val=*/false, ctx.rec_plan);
         arena.rewind(smark);
     };
 
