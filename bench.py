@@ -276,8 +276,12 @@ def run_fasta_shard(job: Job, a, with_file: bool):
     gathered = torch.zeros(job.world * m, dtype=torch.int64, device=job.cdev)
     idx = torch.tensor(mine, dtype=torch.int64, device=job.cdev)
 
+    lib_seconds = [0.0]
+
     def step():
+        t_lib = time.perf_counter()
         zs = native.factorize_batch_device(ptrs, lens, emit=1)
+        lib_seconds[0] += time.perf_counter() - t_lib
         vec.zero_()
         if mine:
             vec[idx] = torch.tensor(zs, dtype=torch.int64, device=job.cdev)
@@ -289,6 +293,7 @@ def run_fasta_shard(job: Job, a, with_file: bool):
     for _ in range(a.fasta_warmup):
         step()
     job.barrier()
+    lib_seconds[0] = 0.0
     t0 = time.perf_counter()
     for _ in range(a.fasta_steps):
         counts = step()
@@ -302,6 +307,7 @@ def run_fasta_shard(job: Job, a, with_file: bool):
                        f"of {m} counts",
            "scaling": "strong", "n_gpus": job.world, "steps": a.fasta_steps, "warmup": a.fasta_warmup,
            "value": total / step_s, "unit": "bases/s", "ms_per_step": step_s * 1e3,
+           "library_call_ms_per_step": lib_seconds[0] / a.fasta_steps * 1e3,
            "records_per_rank": [owners.count(r) for r in range(job.world)],
            "total_factors": int(sum(counts)),
            "pipeline_hbm_frac_per_gpu": ALG_BYTES_PER_BASE * (total / job.world) / step_s / 1e9 / HBM_PEAK_GBS}

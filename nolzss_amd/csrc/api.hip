@@ -1480,6 +1480,26 @@ __global__ void batch_bounds_kernel(const nolzss_factor *__restrict__ recs, uint
     if (lo >= z || recs[lo].start != target || recs[lo].length != 1) atomicOr(err, 1u);
 }
 
+// smallest j with fpos[j] >= the position of separator k (its own literal factor)
+__global__ void batch_bounds_pos_kernel(const uint32_t *__restrict__ fpos, uint32_t z,
+                                        const uint32_t *__restrict__ seps, uint32_t nsep, uint32_t *__restrict__ fidx,
+                                        uint32_t *__restrict__ err) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nsep) return;
+    const uint32_t target = seps[k];
+    uint32_t lo = 0, hi = z;
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (fpos[mid] >= target)
+            hi = mid;
+        else
+            lo = mid + 1;
+    }
+    fidx[k] = lo;
+    // a separator matches nothing: a factor of length 1 starts exactly there
+    if (lo >= z || fpos[lo] != target || (lo + 1 < z && fpos[lo + 1] != target + 1)) atomicOr(err, 1u);
+}
+
 // record-relative coordinates: start and ref minus the first position of the factor's record
 __global__ void batch_rebase_kernel(nolzss_factor *__restrict__ recs, uint32_t z, TermTable terms) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1561,6 +1581,7 @@ bool run_merged_chunk(Context &ctx, const uint8_t *const *texts, const size_t *l
     }
     PackedText text;
     void *d_recs = nullptr;
+    uint32_t *d_fpos = nullptr;
     uint32_t z = 0;
     if (with_rc) {
         // the layout of prepare_multiple_dna_sequences_w_rc (factorizer.cpp:128-169) for any number of
@@ -1585,7 +1606,10 @@ bool run_merged_chunk(Context &ctx, const uint8_t *const *texts, const size_t *l
         const Pyramid Plcp = build_lcp_pyramid(ctx, text, sa, lcp);
         uint32_t *lstar = arena.alloc<uint32_t>(n);
         build_lstar(ctx, (uint32_t)n, sa, isa, lcp, Psa, Plcp, lstar);
-        z = resolve_chain(ctx, (uint32_t)n, 0, lstar, sa, isa, lcp, Psa, Plcp, &d_recs);
+        // counts come from the factor starts; records are built only when the caller wants them, and leave
+        // the factor kernel in record coordinates
+        z = resolve_chain(ctx, (uint32_t)n, 0, lstar, sa, isa, lcp, Psa, Plcp, fs ? &d_recs : nullptr, 0, nullptr,
+                          &d_fpos, fs ? &text.terms : nullptr);
     }
     nolzss_factor *recs = static_cast<nolzss_factor *>(d_recs);
     // where the records' factor lists start and end
@@ -1593,8 +1617,12 @@ bool run_merged_chunk(Context &ctx, const uint8_t *const *texts, const size_t *l
     if (c > 1) {
         uint32_t *d_fidx = arena.alloc<uint32_t>(c);
         HIP_CHECK(hipMemsetAsync(d_fidx + (c - 1), 0, sizeof(uint32_t), s));  // error flag
-        batch_bounds_kernel<<<(unsigned)div_up(c - 1, 256), 256, 0, s>>>(recs, z, text.terms.pos, (uint32_t)(c - 1),
-                                                                         d_fidx, d_fidx + (c - 1));
+        if (with_rc)
+            batch_bounds_kernel<<<(unsigned)div_up(c - 1, 256), 256, 0, s>>>(recs, z, text.terms.pos, (uint32_t)(c - 1),
+                                                                             d_fidx, d_fidx + (c - 1));
+        else
+            batch_bounds_pos_kernel<<<(unsigned)div_up(c - 1, 256), 256, 0, s>>>(d_fpos, z, text.terms.pos,
+                                                                                 (uint32_t)(c - 1), d_fidx, d_fidx + (c - 1));
         KERNEL_CHECK();
         HIP_CHECK(hipMemcpyAsync(fidx.data(), d_fidx, c * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
@@ -1603,8 +1631,10 @@ bool run_merged_chunk(Context &ctx, const uint8_t *const *texts, const size_t *l
     }
     nolzss_factor *block = nullptr;
     if (fs && z) {
-        batch_rebase_kernel<<<(unsigned)div_up(z, 256), 256, 0, s>>>(recs, z, text.terms);
-        KERNEL_CHECK();
+        if (with_rc) {
+            batch_rebase_kernel<<<(unsigned)div_up(z, 256), 256, 0, s>>>(recs, z, text.terms);
+            KERNEL_CHECK();
+        }
         block = static_cast<nolzss_factor *>(alloc_factor_block(sizeof(nolzss_factor) * (size_t)z));
         if (!block) throw std::bad_alloc();
         try {
@@ -1651,25 +1681,6 @@ __global__ __launch_bounds__(256) void gather_records_kernel(const GatherRec *__
         }
         if (blockIdx.x == 0 && threadIdx.x == 0 && k + 1 < c) dst[r.off + r.len] = sep;
     }
-}
-
-// smallest j with fpos[j] >= the position of separator k (its own literal factor)
-__global__ void batch_bounds_pos_kernel(const uint32_t *__restrict__ fpos, uint32_t z,
-                                        const uint32_t *__restrict__ seps, uint32_t nsep, uint32_t *__restrict__ fidx,
-                                        uint32_t *__restrict__ err) {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= nsep) return;
-    const uint32_t target = seps[k];
-    uint32_t lo = 0, hi = z;
-    while (lo < hi) {
-        const uint32_t mid = lo + ((hi - lo) >> 1);
-        if (fpos[mid] >= target)
-            hi = mid;
-        else
-            lo = mid + 1;
-    }
-    fidx[k] = lo;
-    if (lo >= z || fpos[lo] != target) atomicOr(err, 1u);  // a separator matches nothing: a factor starts there
 }
 
 // Records ids[0..c) (device pointers, all non-empty) as ONE run of independent sequences: gathered on the
@@ -1731,7 +1742,7 @@ bool run_merged_chunk_device(Context &ctx, const void *const *d_texts, const siz
     void *d_recs = nullptr;
     uint32_t *d_fpos = nullptr;
     const uint32_t z = resolve_chain(ctx, (uint32_t)n, 0, lstar, sa, isa, lcp, Psa, Plcp, emit ? &d_recs : nullptr, 0,
-                                     nullptr, &d_fpos);
+                                     nullptr, &d_fpos, emit ? &text.terms : nullptr);
     std::vector<uint32_t> fidx(c, z);
     if (c > 1) {
         uint32_t *d_fidx = arena.alloc<uint32_t>(c);
@@ -1739,10 +1750,6 @@ bool run_merged_chunk_device(Context &ctx, const void *const *d_texts, const siz
         batch_bounds_pos_kernel<<<(unsigned)div_up(c - 1, 256), 256, 0, s>>>(d_fpos, z, text.terms.pos, (uint32_t)(c - 1),
                                                                              d_fidx, d_fidx + (c - 1));
         KERNEL_CHECK();
-        if (emit && z) {
-            batch_rebase_kernel<<<(unsigned)div_up(z, 256), 256, 0, s>>>(static_cast<nolzss_factor *>(d_recs), z, text.terms);
-            KERNEL_CHECK();
-        }
         HIP_CHECK(hipMemcpyAsync(fidx.data(), d_fidx, c * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
         if (fidx[c - 1]) throw HipError("merged batch: a separator is not a literal factor");
@@ -1816,7 +1823,7 @@ void factorize_many(const uint8_t *const *texts, const size_t *lens, size_t m, c
     if (longs.size() >= 2) {
         size_t total = 0;
         for (size_t j : longs) total += lens[j] + 1;
-        size_t runs = div_up(total, long_run);
+        size_t runs = div_up(total - longs.size(), long_run);  // (the separators do not count)
         if (runs < 2 && total >= (with_rc ? size_t(1) << 26 : size_t(1) << 27)) runs = 2;
         const size_t share = div_up(total, runs);
         std::vector<size_t> cur;
@@ -2041,12 +2048,16 @@ int nolzss_factorize_batch_device(const void *const *d_texts, const size_t *lens
         std::vector<size_t> order;  // the records that take a pipeline run of their own
         std::vector<std::vector<size_t>> chunks;
         {
-            size_t short_bases = 0;
+            size_t short_bases = 0, short_count = 0;
             for (size_t j = 0; j < m; ++j)
-                if (lens[j] && lens[j] < dev_merge_below) short_bases += lens[j] + 1;
-            // (two runs in flight fill each other's launch and read-back gaps: 2^28 bases go as two runs of
+                if (lens[j] && lens[j] < dev_merge_below) {
+                    short_bases += lens[j] + 1;
+                    ++short_count;
+                }
+            // (the separators do not count: 512 records of 2^22 bases are two runs of 2^30, not three;
+            // two runs in flight fill each other's launch and read-back gaps: 2^28 bases go as two runs of
             // 2^27 rather than one)
-            size_t runs = div_up(short_bases ? short_bases : 1, dev_run_bases);
+            size_t runs = div_up(short_bases > short_count ? short_bases - short_count : 1, dev_run_bases);
             if (runs < 2 && short_bases >= (size_t(1) << 27)) runs = 2;
             const size_t share = div_up(short_bases, runs);
             std::vector<size_t> cur;

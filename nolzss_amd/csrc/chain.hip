@@ -249,14 +249,16 @@ struct FactorRec {
 //   reverse-complement factor (kRC): the reference keeps the smallest T-coordinate END among the
 //     rc-strand suffixes of the node (rc_ends = 2N - SA, factorizer_core.hpp:226-228, 270,
 //     294-296), i.e. the LARGEST SA value in I(L); ref = RC_MASK | (end - L + 1)  (:362-364).
-template <bool kRC>
+// kRebase (merged batch, plain mode): start and ref leave relative to the first position of the factor's
+// record (a separate pass over the records cost 2.3 ms per 7*10^7 factors).
+template <bool kRC, bool kRebase>
 __global__ __launch_bounds__(kThreads) void factor_kernel(const uint32_t *__restrict__ fpos, uint32_t z,
                                                           const uint32_t *__restrict__ lstar,
                                                           const uint32_t *__restrict__ isa,
                                                           const uint32_t *__restrict__ sa,
                                                           const uint32_t *__restrict__ lcp, Pyramid Psa,
                                                           Pyramid Plcp, Pyramid Pmax, uint32_t rcN,
-                                                          FactorRec *__restrict__ out) {
+                                                          FactorRec *__restrict__ out, TermTable terms) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < z; k += stride) {
         const uint32_t i = fpos[k];
@@ -315,6 +317,12 @@ __global__ __launch_bounds__(kThreads) void factor_kernel(const uint32_t *__rest
                 f.ref = (1ull << 63) | (end - L + 1);
             }
         }
+        if (kRebase) {
+            const uint32_t t = term_lower_bound(terms, i);
+            const uint64_t base = t ? (uint64_t)terms.pos[t - 1] + 1 : 0;
+            f.start -= base;
+            f.ref -= base;
+        }
         out[k] = f;
     }
 }
@@ -330,12 +338,14 @@ inline unsigned grid_for(size_t items, unsigned cap = 256u * 16u) {
 // Returns z; if d_factors_out != nullptr the z factor records are left in arena memory (this
 // stage's temporaries are then NOT released: the caller rewinds after copying the records out).
 // d_fpos_out (optional) receives the z factor starts, ascending, under the same rule -- without
-// d_factors_out nothing else is built.
+// d_factors_out nothing else is built.  rebase (optional, plain mode): the terminator table of a text of
+// independent records; start and ref of every factor are then relative to its record.
 // Plain mode: rcN = 0, Pmax unused.  RC mode: n = N (factorized prefix of S), rcN = N and Pmax
 // is the max pyramid over SA.
 uint32_t resolve_chain(Context &ctx, uint32_t n, uint32_t start_pos, const uint32_t *lstar, const uint32_t *sa,
                        const uint32_t *isa, const uint32_t *lcp, const Pyramid &Psa, const Pyramid &Plcp,
-                       void **d_factors_out, uint32_t rcN, const Pyramid *Pmax, uint32_t **d_fpos_out) {
+                       void **d_factors_out, uint32_t rcN, const Pyramid *Pmax, uint32_t **d_fpos_out,
+                       const TermTable *rebase) {
     hipStream_t s = ctx.stream;
     Arena &arena = ctx.arena;
     if (d_factors_out) *d_factors_out = nullptr;
@@ -420,12 +430,17 @@ uint32_t resolve_chain(Context &ctx, uint32_t n, uint32_t start_pos, const uint3
         ProfScope ps(ctx.profiler(), "factor_emit", s);
         emit_positions_kernel<<<num_tiles, 64, 0, s>>>(cbits, tile_count, fpos);
         KERNEL_CHECK();
-        if (rcN)
-            factor_kernel<true><<<grid_for(z), kThreads, 0, s>>>(fpos, z, lstar, isa, sa, lcp, Psa, Plcp, *Pmax,
-                                                                 rcN, recs_tmp);
-        else
-            factor_kernel<false><<<grid_for(z), kThreads, 0, s>>>(fpos, z, lstar, isa, sa, lcp, Psa, Plcp, Psa, 0u,
-                                                                  recs_tmp);
+        if (rcN) {
+            if (rebase) throw HipError("resolve_chain: record-relative output exists in plain mode only");
+            factor_kernel<true, false><<<grid_for(z), kThreads, 0, s>>>(fpos, z, lstar, isa, sa, lcp, Psa, Plcp, *Pmax,
+                                                                        rcN, recs_tmp, TermTable{});
+        } else if (rebase) {
+            factor_kernel<false, true><<<grid_for(z), kThreads, 0, s>>>(fpos, z, lstar, isa, sa, lcp, Psa, Plcp, Psa,
+                                                                        0u, recs_tmp, *rebase);
+        } else {
+            factor_kernel<false, false><<<grid_for(z), kThreads, 0, s>>>(fpos, z, lstar, isa, sa, lcp, Psa, Plcp, Psa,
+                                                                         0u, recs_tmp, TermTable{});
+        }
         KERNEL_CHECK();
     }
     // the caller owns the arena mark: stage temporaries stay allocated until it rewinds

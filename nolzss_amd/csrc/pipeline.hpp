@@ -57,7 +57,7 @@ uint32_t build_lstar(Context &ctx, uint32_t n, const uint32_t *sa, const uint32_
 uint32_t resolve_chain(Context &ctx, uint32_t n, uint32_t start_pos, const uint32_t *lstar, const uint32_t *sa,
                        const uint32_t *isa, const uint32_t *lcp, const Pyramid &Psa, const Pyramid &Plcp,
                        void **d_factors_out, uint32_t rcN = 0, const Pyramid *Pmax = nullptr,
-                       uint32_t **d_fpos_out = nullptr);
+                       uint32_t **d_fpos_out = nullptr, const TermTable *rebase = nullptr);
 
 // ---- reverse-complement mode (rc.hip): whole pipeline over the prepared string S -------------
 uint32_t run_rc_pipeline(Context &ctx, const uint8_t *d_S, size_t m, size_t start_pos, void **d_factors_out);

@@ -95,14 +95,41 @@ constexpr uint32_t kMaxTermScan = 512;
 __global__ __launch_bounds__(kThreads) void find_terminators_kernel(const uint8_t *__restrict__ text, uint32_t n,
                                                                     uint32_t *__restrict__ count,
                                                                     uint32_t *__restrict__ pos_out) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint8_t c = text[i];
+    auto check = [&](uint8_t c, size_t i) {
         if (c != 'A' && c != 'C' && c != 'G' && c != 'T') {
             const uint32_t k = atomicAdd(count, 1u);
             if (k < kMaxTermScan) pos_out[k] = (uint32_t)i;
         }
+    };
+    // 16 bytes per load from the first 16-byte boundary on; a 32-bit word is tested against the four
+    // nucleotides at once with exact per-byte equality masks, and only a word that holds something else is
+    // looked at byte by byte (1.35 -> XX ms per 2^30-base run of the merged batch)
+    const size_t head = (size_t)((16 - (reinterpret_cast<uintptr_t>(text) & 15)) & 15);
+    const size_t h = head < n ? head : n;
+    const size_t vecs = (n - h) / 16;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid < h) check(text[tid], tid);
+    const uint4 *v = reinterpret_cast<const uint4 *>(text + h);
+    auto all_nucleotides = [](uint32_t w) -> bool {
+        // per byte: zero iff the byte equals the pattern; a byte of (x ^ p) is zero <=> haszero
+        auto eq = [](uint32_t x, uint32_t p) -> uint32_t {
+            const uint32_t y = x ^ p;
+            return ~(((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y | 0x7f7f7f7fu);  // 0x80 in every byte that matched
+        };
+        const uint32_t m = eq(w, 0x41414141u) | eq(w, 0x43434343u) | eq(w, 0x47474747u) | eq(w, 0x54545454u);
+        return m == 0x80808080u;
+    };
+    for (size_t k = tid; k < vecs; k += stride) {
+        const uint4 q = v[k];
+        if (all_nucleotides(q.x) && all_nucleotides(q.y) && all_nucleotides(q.z) && all_nucleotides(q.w)) continue;
+        const size_t base = h + k * 16;
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) check((uint8_t)(w[j >> 2] >> (8 * (j & 3))), base + (size_t)j);
     }
+    const size_t tail0 = h + vecs * 16;
+    if (tail0 + tid < n) check(text[tail0 + tid], tail0 + tid);
 }
 
 // ---------------------------------------------------------------------------------------
