@@ -436,7 +436,8 @@ __global__ __launch_bounds__(kThreads) void window_scatter_kernel(const IdxT *__
 
 // the same for the windows of a RecordScatterPlan: window b = list elements [win[3b], +win[3b+2]) -> target
 // elements [win[3b+1], +win[3b+2]); the low window_bits of an index are its place in the window
-__global__ __launch_bounds__(kThreads) void record_window_scatter_kernel(const uint16_t *__restrict__ idx,
+template <typename IdxT>
+__global__ __launch_bounds__(kThreads) void record_window_scatter_kernel(const IdxT *__restrict__ idx,
                                                                          const uint32_t *__restrict__ val,
                                                                          uint32_t *__restrict__ out,
                                                                          const uint32_t *__restrict__ win,
@@ -573,13 +574,14 @@ void bucketed_scatter(uint32_t *idx[2], uint32_t *val[2], size_t count, uint32_t
         uint32_t *hist = arena.alloc<uint32_t>((size_t)kBins * plan->seg.num_tiles);
         uint32_t *err = arena.alloc<uint32_t>(1);
         HIP_CHECK(hipMemsetAsync(err, 0, sizeof(uint32_t), stream));
+        // (32-bit indices out of this pass measured 10 % slower end to end than the low 16 bits)
         radix_pass<uint32_t, uint16_t>(LocalIdxSrc{idx[0], val[0]}, idx16, val[1], count, plan->window_bits, hist,
                                        plan->seg.num_tiles, 4.0 * (double)count, 14.0 * (double)count, arena, stream,
                                        prof, plan->seg);
         {
             ProfScope ps(prof, "window_scatter", stream, 10.0 * (double)count);
-            record_window_scatter_kernel<<<plan->num_windows, kThreads, 0, stream>>>(idx16, val[1], out, plan->win,
-                                                                                    plan->window_bits);
+            record_window_scatter_kernel<uint16_t><<<plan->num_windows, kThreads, 0, stream>>>(idx16, val[1], out, plan->win,
+                                                                                              plan->window_bits);
             KERNEL_CHECK();
             if (plan->num_seps) {
                 separator_scatter_kernel<<<(unsigned)div_up(plan->num_seps, kThreads), kThreads, 0, stream>>>(
@@ -597,25 +599,34 @@ void bucketed_scatter(uint32_t *idx[2], uint32_t *val[2], size_t count, uint32_t
     int nbits = 1;
     while (nbits < 32 && (1ull << nbits) < (uint64_t)n_out) ++nbits;
     const bool big = (size_t)n_out * 4 > (size_t(64) << 20) && count > (size_t(1) << 22);
-    if (big && count == n_out && nbits <= 2 * kRadixBits + kWindowBitsMax) {
-        // idx is a permutation of [0, n_out): two radix passes leave window w = [w*W, (w+1)*W)
-        // exactly at list positions [w*W, (w+1)*W); each window is assembled in LDS and written
-        // out as full lines.
-        const int wb = nbits > 2 * kRadixBits + 10 ? nbits - 2 * kRadixBits : 10;
-        const int shifts[2] = {wb, wb + kRadixBits};
-        // pass 1: buffer 0 -> 1; pass 2: 1 -> 0, or 1 -> a third buffer if the input must survive
+    if (big && count == n_out) {
+        // idx is a permutation of [0, n_out): radix passes by the digits above the window bits leave window
+        // w = [w*W, (w+1)*W) exactly at list positions [w*W, (w+1)*W); each window is assembled in LDS and
+        // written out as full lines.  Two passes reach 2^30 targets; above that a third pass takes the top
+        // bits (few bins, long runs): 17 ms per 2^30 pairs where the windowed partial scatter below needed 29.
+        const bool three = nbits > 2 * kRadixBits + kWindowBitsMax;
+        const int wb = three ? kWindowBitsMax : (nbits > 2 * kRadixBits + 10 ? nbits - 2 * kRadixBits : 10);
+        const int shifts[3] = {wb, wb + kRadixBits, wb + 2 * kRadixBits};
+        // pass 1: buffer 0 -> 1; pass 2: 1 -> 0, or 1 -> a third buffer if the input must survive;
+        // (pass 3: that buffer -> 1)
         radix_sort_pairs(idx, val, count, shifts, 1, arena, stream, prof);
         uint32_t *idx2[2] = {idx[1], keep_input ? arena.alloc<uint32_t>(count) : idx[0]};
         uint32_t *val2[2] = {val[1], (keep_input && keep_val) ? arena.alloc<uint32_t>(count) : val[0]};
-        // second pass (top digit): only the low 16 bits of an index travel on -- the window scatter needs the
+        if (three) {
+            radix_sort_pairs(idx2, val2, count, shifts + 1, 1, arena, stream, prof);
+            std::swap(idx2[0], idx2[1]);
+            std::swap(val2[0], val2[1]);
+        }
+        // last pass (top digit): only the low 16 bits of an index travel on -- the window scatter needs the
         // bits below the window size, and everything above them is the position in the list (6 instead of 8
         // bytes per pair written here and read there)
         uint16_t *idx16 = reinterpret_cast<uint16_t *>(idx2[1]);
         {
             const uint32_t num_tiles = (uint32_t)div_up(count, kTile);
             uint32_t *hist = arena.alloc<uint32_t>((size_t)kBins * num_tiles);
-            radix_pass<uint32_t, uint16_t>(ArraySrc<uint32_t>{idx2[0], val2[0]}, idx16, val2[1], count, shifts[1], hist,
-                                           num_tiles, 4.0 * (double)count, 14.0 * (double)count, arena, stream, prof);
+            radix_pass<uint32_t, uint16_t>(ArraySrc<uint32_t>{idx2[0], val2[0]}, idx16, val2[1], count,
+                                           shifts[three ? 2 : 1], hist, num_tiles, 4.0 * (double)count,
+                                           14.0 * (double)count, arena, stream, prof);
         }
         {
             ProfScope ps(prof, "window_scatter", stream, 10.0 * (double)count);
