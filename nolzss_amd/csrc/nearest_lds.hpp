@@ -186,7 +186,10 @@ __device__ __forceinline__ void build_block_tables(const uint32_t *s_sa, const u
     }
 }
 
-template <int NS, int NP, typename Active, typename ThrGt>
+// kCompact: only some of the ranks search (reverse-complement mode: the ranks of the original strand, half of
+// them) -- they are gathered first, so that round 0 runs over full rows of searching ranks instead of spending
+// its instructions on rows that are half idle.
+template <int NS, int NP, bool kCompact = false, typename Active, typename ThrGt>
 __device__ __forceinline__ void lds_search_wave_blocks(const uint32_t *s_sa, const uint32_t *s_lcp,
                                                        const BlockTables &T, uint32_t n, uint32_t base,
                                                        uint32_t *res_len, uint32_t *res_pos, uint16_t *list0,
@@ -198,22 +201,41 @@ __device__ __forceinline__ void lds_search_wave_blocks(const uint32_t *s_sa, con
     uint32_t cnt = 0;
 
     // ---- round 0: every rank, every search, steps 1..kLdsStep0 --------------------------------
+    uint32_t rows = kLdsPerWave / 64, n_act = kLdsPerWave;
+    if (kCompact) {  // (list1 is free until round A)
+        n_act = 0;
+#pragma unroll
+        for (int row = 0; row < kLdsPerWave / 64; ++row) {
+            const int tl = row * 64 + lane;
+            const int t = w * kLdsPerWave + tl;
+            const bool valid = (uint64_t)base + t < n && active(s_sa[t + kLdsReach]);
+            const uint64_t bal = __ballot(valid);
+            if (valid) list1[n_act + (uint32_t)__popcll(bal & lt)] = (uint16_t)tl;
+            n_act += (uint32_t)__popcll(bal);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        rows = (n_act + 63) / 64;
+    }
 #pragma unroll 1
-    for (int row = 0; row < kLdsPerWave / 64; ++row) {
-        const int tl = row * 64 + lane;
+    for (uint32_t row = 0; row < rows; ++row) {
+        const bool have = !kCompact || row * 64 + lane < n_act;
+        const int tl = kCompact ? (have ? (int)list1[row * 64 + lane] : 0) : (int)(row * 64 + lane);
         const int t = w * kLdsPerWave + tl;
         const uint64_t rr = (uint64_t)base + t;
         const int li = t + kLdsReach;
         const uint32_t i = s_sa[li];
-        const bool valid = rr < n && active(i);
+        const bool valid = kCompact ? have : (rr < n && active(i));
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
             const bool greater = k >= 2, up = (k & 1) == 0;
             uint32_t m = 0xffffffffu, pos = kNoPos;
             int st = 0;
             if (valid) st = lds_scan_round<kLdsStep0>(s_sa, s_lcp, li, 0, greater, up, greater ? thr_gt(i) : i, m, pos);
-            res_len[k * kLdsTile + t] = (st == 0) ? 0u : m;
-            if (k < NP) res_pos[k * kLdsTile + t] = (st == 1) ? pos : kNoPos;
+            if (have) {  // (kCompact: the results of ranks that do not search are never read)
+                res_len[k * kLdsTile + t] = (st == 0) ? 0u : m;
+                if (k < NP) res_pos[k * kLdsTile + t] = (st == 1) ? pos : kNoPos;
+            }
             const bool pending = st == 2;
             const uint64_t bal = __ballot(pending);
             if (pending) list0[cnt + (uint32_t)__popcll(bal & lt)] = (uint16_t)(tl | (k << 8));  // rank in the wave | search << 8

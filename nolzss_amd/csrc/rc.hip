@@ -73,7 +73,7 @@ __global__ __launch_bounds__(kLdsThreads) void rc_tile_kernel(const uint32_t *__
     __syncthreads();
     const int w = threadIdx.x >> 6;
     const uint32_t far_bit = m <= 0x80000000u ? 0x80000000u : 0u;
-    lds_search_wave_blocks<NS, NP>(s_sa, s_lcp, T, m, base, s_len, s_pos, s_list[w][0], s_list[w][1],
+    lds_search_wave_blocks<NS, NP, true>(s_sa, s_lcp, T, m, base, s_len, s_pos, s_list[w][0], s_list[w][1],
                                    [N](uint32_t i) { return i < N; }, [N](uint32_t i) { return 2u * N - i; }, far_bit);
     constexpr int kRows = kLdsPerWave / 64;
     bool far[kRows], exact[kRows];
