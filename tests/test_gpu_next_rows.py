@@ -374,3 +374,41 @@ def test_native_fasta_shards_and_device_batch(pkg, tmp_path):
     torch.cuda.synchronize()
     for emit in (0, 1):
         assert native.factorize_batch_device([t.data_ptr() for t in d], lens, emit=emit) == expected
+
+
+def test_concurrent_calls_with_staged_downloads(pkg):
+    """factor arrays of 32 MiB and more come down through pinned chunks emptied by several host threads
+    (api.hip, download_bytes), and blocks of 256 MiB and more are released by a detached thread: four callers at
+    once, each on its own lane, get what a lone caller gets; results of a 2^24-base random text (1.4 M factors,
+    34 MB of records) are also checked as a tiling with true earlier occurrences"""
+    import threading
+    native = pkg._noLZSS
+    texts = [gen.random_dna((1 << 24) + 1000 * k, 7100 + k) for k in range(4)]
+    alone = [native.factorize_array(t) for t in texts]
+    for t, f in zip(texts, alone):
+        assert len(f) * 24 >= 32 << 20
+        assert int(f["start"][0]) == 0 and int(f["start"][-1] + f["length"][-1]) == len(t)
+        assert np.array_equal(f["start"][1:], f["start"][:-1] + f["length"][:-1])
+        for j in np.random.default_rng(1).integers(0, len(f), size=200):
+            s, l, r = int(f["start"][j]), int(f["length"][j]), int(f["ref"][j])
+            assert r + l <= s or l == 1
+            if r != s:
+                assert np.array_equal(t[s:s + l], t[r:r + l])
+    errors = []
+
+    def worker(k):
+        try:
+            for rep in range(3):
+                j = (k + rep) % len(texts)
+                got = native.factorize_array(texts[j])
+                if not all(np.array_equal(got[c], alone[j][c]) for c in ("start", "length", "ref")):
+                    errors.append((k, rep, j))
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
