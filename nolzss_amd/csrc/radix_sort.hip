@@ -252,9 +252,10 @@ __global__ __launch_bounds__(kThreads) void rs_scatter_kernel(
 #pragma unroll
         for (int b = 0; b < kRadixBits; ++b) {
             const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)d, (unsigned)b, 1u);
-            const uint64_t bal = __ballot(m != 0);
-            diff_lo |= (uint32_t)bal ^ m;
-            diff_hi |= (uint32_t)(bal >> 32) ^ m;
+            const uint64_t bal = __ballot((int)m < 0);
+            // diff |= bal ^ m in one v_bitop3 (truth table 0xde = b | (c ^ a)): four VALU per bit and row
+            diff_lo = __builtin_amdgcn_bitop3_b32(m, diff_lo, (uint32_t)bal, 0xde);
+            diff_hi = __builtin_amdgcn_bitop3_b32(m, diff_hi, (uint32_t)(bal >> 32), 0xde);
         }
         const uint64_t peers = ~(((uint64_t)diff_hi << 32) | diff_lo) & __ballot(valid);
         const uint64_t below = peers & lanemask_lt();
