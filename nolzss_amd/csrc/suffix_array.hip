@@ -1179,11 +1179,11 @@ constexpr int kRefineWords = 4;
 constexpr int kPairCap = 1664;  // pairs per workgroup (192 members in groups of up to ~18 fit); 20 KiB of LDS: 8 workgroups = 32 waves per CU
 
 template <int BITS, bool kTimed>
-__global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void group_refine_kernel(
+__global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(kTimed ? 4 : 8, 8))) void group_refine_kernel(
     const uint32_t *__restrict__ act_slot, const uint32_t *__restrict__ act_grp, uint32_t *sa,
     const uint64_t *__restrict__ words, TermTable terms, uint32_t m, uint32_t h0, uint32_t cap,
     uint32_t *__restrict__ out_lo, uint32_t *__restrict__ lcp_list, uint32_t *__restrict__ min_depth,
-    unsigned long long *__restrict__ phases) {
+    unsigned long long *__restrict__ phases, bool no_stragglers) {
     const bool timed = kTimed && phases != nullptr && (blockIdx.x & 31) == 0 && threadIdx.x == 0;
     unsigned long long ck0 = 0, ck_fetch = 0, ck_cmp = 0, ck_rounds = 0, ck1 = 0, ck2 = 0;
     if (timed) ck0 = __builtin_readcyclecounter();
@@ -1294,6 +1294,8 @@ __global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(
 
     int cur = 0;
     uint32_t depth = h0;
+    constexpr int kStragglers = 64, kStragWindows = kRefineThreads / kStragglers;
+    uint32_t strag_from = 0xffffffffu;
     if (npairs > 0) {
         for (uint32_t h = h0; h < cap; h += kPerRound) {
             if (s_tied[cur][t]) {  // the next kRefineWords words of my suffix, from symbol h
@@ -1388,6 +1390,136 @@ __global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(
             const int busy = __syncthreads_count(any_tie);
             if (timed) { const unsigned long long cc = __builtin_readcyclecounter(); ck_fetch += cb - (ck2 ? ck2 : ck1); ck_cmp += cc - cb; ck2 = cc; ck_rounds += 1; (void)ca; }
             if (busy == 0 || (h >= h0 + kPerRound && busy > kRefineThreads / 4)) break;
+            if (!no_stragglers && busy <= kStragglers / 2) {  // few tied pairs left: the rounds below
+                strag_from = h + kPerRound;
+                break;
+            }
+        }
+    }
+
+
+    // STRAGGLERS.  A workgroup stays as long as its deepest tie: after the first rounds a handful of members
+    // is left, and every further round costs them a round trip to the text plus the barriers (phase clocks:
+    // ~4 k cycles per round whatever the number of pairs; six rounds on average).  Once at most kStragglers
+    // members are tied they are numbered, and the whole workgroup fetches for them: wavefront q takes window q
+    // of every straggler, so ONE round trip brings kStragWindows windows each, compared in LDS one after the
+    // other.  (s_tied[cur] holds the straggler's number + 1, s_goff its text position: no LDS is added.  The
+    // loop is kept apart from the one above: woven into it, the common rounds ran 12-20 % slower.)
+    static_assert(kStragWindows * kStragglers == kRefineThreads, "one fetching thread per straggler and window");
+    if (strag_from < cap) {  // (workgroup-uniform)
+        uint4 *s_flat = &s_w[0][0];
+        for (uint32_t h = strag_from; h < cap;) {
+            uint32_t nq = (cap - h + kPerRound - 1) / kPerRound;
+            nq = nq < (uint32_t)kStragWindows ? nq : (uint32_t)kStragWindows;
+            const bool tied = s_tied[cur][t] != 0;
+            const uint64_t tb = __ballot(tied);
+            if (lane == 0) s_wtot[w] = (uint32_t)__popcll(tb);
+            __syncthreads();
+            uint32_t sidx = (uint32_t)__popcll(tb & lt), ntied = 0;
+#pragma unroll
+            for (int k = 0; k < kRefineWaves; ++k) {
+                if (k < w) sidx += s_wtot[k];
+                ntied += s_wtot[k];
+            }
+            // (more members than fit -- a wavefront held several tied pairs per lane: their ties stay for the
+            // doubling rounds, like ties at the cap)
+            if (ntied > (uint32_t)kStragglers) break;
+            if (tied) {
+                s_tied[cur][t] = (uint8_t)(sidx + 1);
+                s_goff[sidx] = my_pos;
+            }
+            __syncthreads();
+            {
+                const uint32_t q = (uint32_t)t / kStragglers, i = (uint32_t)t % kStragglers;
+                // (a window behind the end of the text is never compared: its pair is decided where the
+                // shorter suffix ends; the packed text is padded for windows that START inside it)
+                if (i < ntied && q < nq && (uint64_t)s_goff[i] + h + (uint64_t)q * kPerRound <= (uint64_t)terms.end) {
+                    const uint64_t bit = ((uint64_t)s_goff[i] + h + (uint64_t)q * kPerRound) * BITS;
+                    const uint64_t *src = words + (bit >> 6);
+                    uint32_t r[kW32 + 2];
+#pragma unroll
+                    for (int k = 0; k <= kRefineWords; ++k) {
+                        const uint64_t v = src[k];
+                        r[2 * k] = (uint32_t)(v >> 32);
+                        r[2 * k + 1] = (uint32_t)v;
+                    }
+                    const uint32_t skip = (bit & 32) ? 0xffffffffu : 0u;
+                    const uint32_t o = (uint32_t)bit & 31;
+                    uint32_t qq[kW32 + 1], win[kW32];
+#pragma unroll
+                    for (int k = 0; k <= kW32; ++k) qq[k] = (r[k + 1] & skip) | (r[k] & ~skip);
+#pragma unroll
+                    for (int k = 0; k < kW32; ++k) win[k] = o ? __builtin_amdgcn_alignbit(qq[k], qq[k + 1], 32 - o) : qq[k];
+#pragma unroll
+                    for (int c = 0; c < kChunks; ++c)
+                        s_flat[((size_t)q * kChunks + c) * kStragglers + i] = make_uint4(win[4 * c], win[4 * c + 1], win[4 * c + 2], win[4 * c + 3]);
+                }
+            }
+            s_tied[cur ^ 1][t] = 0;
+            __syncthreads();
+            uint32_t kept = 0;
+            bool any_tie = false;
+            for (uint32_t c0 = 0; c0 < cnt; c0 += 64) {
+                const bool have = c0 + lane < cnt;
+                const uint32_t item = have ? s_pair[seg0 + c0 + lane] : 0u;
+                const int x = (int)(item & 0xffffu), u = (int)(item >> 16);
+                bool tie = have;
+                if (have) {
+                    const uint32_t sx = (uint32_t)s_tied[cur][x] - 1u, su = (uint32_t)s_tied[cur][u] - 1u;
+                    uint32_t hq = h;
+#pragma unroll 1
+                    for (uint32_t q = 0; q < nq; ++q, hq += kPerRound) {
+                        const uint32_t rem_x = s_lim[x] - hq, rem_u = s_lim[u] - hq;
+                        uint32_t valid = rem_x < rem_u ? rem_x : rem_u;
+                        valid = valid < kPerRound ? valid : kPerRound;
+                        uint4 p[kChunks], y[kChunks];
+#pragma unroll
+                        for (int c = 0; c < kChunks; ++c) {
+                            p[c] = s_flat[((size_t)q * kChunks + c) * kStragglers + sx];
+                            y[c] = s_flat[((size_t)q * kChunks + c) * kStragglers + su];
+                        }
+                        uint32_t xd = 0, yd = 0, wi = (uint32_t)kW32;
+#pragma unroll
+                        for (int c = kChunks - 1; c >= 0; --c) {
+                            const uint32_t px[4] = {p[c].x, p[c].y, p[c].z, p[c].w};
+                            const uint32_t yx[4] = {y[c].x, y[c].y, y[c].z, y[c].w};
+#pragma unroll
+                            for (int i = 3; i >= 0; --i) {
+                                const bool diff = px[i] != yx[i];
+                                xd = diff ? px[i] : xd;
+                                yd = diff ? yx[i] : yd;
+                                wi = diff ? (uint32_t)(4 * c + i) : wi;
+                            }
+                        }
+                        uint32_t d = wi == (uint32_t)kW32 ? kPerRound : wi * kPer32 + (uint32_t)__clz((int)(xd ^ yd)) / BITS;
+                        bool u_smaller = yd < xd;
+                        if (d >= valid) {
+                            if (valid == kPerRound) continue;  // equal windows: on to the next one
+                            d = valid;  // a terminator is reached: nearer one first, then lower index
+                            u_smaller = rem_u != rem_x ? rem_u < rem_x : s_term[u] < s_term[x];
+                        }
+                        const int loser = u_smaller ? x : u;
+                        atomicAdd(&s_cls[loser], 1u);
+                        atomicMax(&s_best[loser], hq + d);
+                        tie = false;
+                        break;
+                    }
+                    if (tie) {
+                        s_tied[cur ^ 1][x] = 1;
+                        s_tied[cur ^ 1][u] = 1;
+                    }
+                }
+                const uint64_t bal = __ballot(tie);
+                if (tie) s_pair[seg0 + kept + (uint32_t)__popcll(bal & lt)] = item;
+                kept += (uint32_t)__popcll(bal);
+                any_tie |= tie;
+            }
+            cnt = kept;
+            cur ^= 1;
+            depth = h + nq * kPerRound;
+            if (timed) ck_rounds += 1;
+            if (__syncthreads_count(any_tie) == 0) break;
+            h += nq * kPerRound;
         }
     }
 
@@ -1896,6 +2028,7 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
             ProfScope ps(ctx.profiler(), "sa_direct_sort", s);
             const unsigned g = (unsigned)div_up(m, kRefineTile);
             static const bool want_rphases = getenv("NOLZSS_REFINE_PHASES") != nullptr;
+            static const bool no_strag = getenv("NOLZSS_NO_STRAGGLERS") != nullptr;  // (A/B switch)
             unsigned long long *rphases = nullptr;
             if (want_rphases) {
                 rphases = arena.alloc<unsigned long long>(8);
@@ -1903,16 +2036,16 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
             }
             switch (text.bits) {
             case 2:
-                if (rphases) group_refine_kernel<2, true><<<g, kRefineThreads, 0, s>>>(slot, grp, sa, text.words, text.terms, m, (uint32_t)h, cap, out_lo, lcp_list, d_min_depth, rphases);
-                else group_refine_kernel<2, false><<<g, kRefineThreads, 0, s>>>(slot, grp, sa, text.words, text.terms, m, (uint32_t)h, cap, out_lo, lcp_list, d_min_depth, nullptr);
+                if (rphases) group_refine_kernel<2, true><<<g, kRefineThreads, 0, s>>>(slot, grp, sa, text.words, text.terms, m, (uint32_t)h, cap, out_lo, lcp_list, d_min_depth, rphases, no_strag);
+                else group_refine_kernel<2, false><<<g, kRefineThreads, 0, s>>>(slot, grp, sa, text.words, text.terms, m, (uint32_t)h, cap, out_lo, lcp_list, d_min_depth, nullptr, no_strag);
                 break;
             case 4:
-                if (rphases) group_refine_kernel<4, true><<<g, kRefineThreads, 0, s>>>(slot, grp, sa, text.words, text.terms, m, (uint32_t)h, cap, out_lo, lcp_list, d_min_depth, rphases);
-                else group_refine_kernel<4, false><<<g, kRefineThreads, 0, s>>>(slot, grp, sa, text.words, text.terms, m, (uint32_t)h, cap, out_lo, lcp_list, d_min_depth, nullptr);
+                if (rphases) group_refine_kernel<4, true><<<g, kRefineThreads, 0, s>>>(slot, grp, sa, text.words, text.terms, m, (uint32_t)h, cap, out_lo, lcp_list, d_min_depth, rphases, no_strag);
+                else group_refine_kernel<4, false><<<g, kRefineThreads, 0, s>>>(slot, grp, sa, text.words, text.terms, m, (uint32_t)h, cap, out_lo, lcp_list, d_min_depth, nullptr, no_strag);
                 break;
             default:
-                if (rphases) group_refine_kernel<8, true><<<g, kRefineThreads, 0, s>>>(slot, grp, sa, text.words, text.terms, m, (uint32_t)h, cap, out_lo, lcp_list, d_min_depth, rphases);
-                else group_refine_kernel<8, false><<<g, kRefineThreads, 0, s>>>(slot, grp, sa, text.words, text.terms, m, (uint32_t)h, cap, out_lo, lcp_list, d_min_depth, nullptr);
+                if (rphases) group_refine_kernel<8, true><<<g, kRefineThreads, 0, s>>>(slot, grp, sa, text.words, text.terms, m, (uint32_t)h, cap, out_lo, lcp_list, d_min_depth, rphases, no_strag);
+                else group_refine_kernel<8, false><<<g, kRefineThreads, 0, s>>>(slot, grp, sa, text.words, text.terms, m, (uint32_t)h, cap, out_lo, lcp_list, d_min_depth, nullptr, no_strag);
                 break;
             }
             KERNEL_CHECK();
