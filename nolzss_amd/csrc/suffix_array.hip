@@ -1243,8 +1243,9 @@ __global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(
         if (starts_here && !large) {
             my_gs = (int)sz;
             my_j = (int)j;
-            my_term = term_lower_bound(terms, my_pos);
-            my_lim = terms.pos[my_term] - my_pos;
+            // (one segment: no table look-up, and above all no load between my position and my first window)
+            my_term = terms.count == 1 ? 0u : term_lower_bound(terms, my_pos);
+            my_lim = (terms.count == 1 ? terms.end : terms.pos[my_term]) - my_pos;
         }
     }
     __syncthreads();  // everybody has read the sizes
