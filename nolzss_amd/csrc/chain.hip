@@ -51,7 +51,7 @@ __global__ __launch_bounds__(kThreads) void chain_exit_kernel(const uint32_t *__
 #pragma unroll
     for (int j = 0; j < kPerThread; ++j) {
         const uint32_t p = base + j * kThreads + tid;
-        ls[j] = (p < n) ? lstar[p] : 0u;
+        ls[j] = lstar[p < n ? p : n - 1u];  // (no branch around the load: guarded, each one was waited for on its own)
     }
 #pragma unroll
     for (int j = 0; j < kPerThread; ++j) {
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(64) void chain_mark_kernel(const uint32_t *__restri
 #pragma unroll
         for (int j = 0; j < kBatch; ++j) {
             const uint32_t p = base + (uint32_t)(j0 + j) * 64u + lane;
-            ls[j] = (p < n) ? lstar[p] : 0u;
+            ls[j] = lstar[p < n ? p : n - 1u];
         }
 #pragma unroll
         for (int j = 0; j < kBatch; ++j) {

@@ -75,37 +75,41 @@ inline uint32_t xcd_grid(uint32_t num_tiles) {
     return (uint32_t)div_up(chunks, 8) * 8 * kXcdChunk;
 }
 
-// where a pass reads its pairs from: arrays, or (first pass of the suffix sort) the packed text
+// where a pass reads its pairs from: arrays, or (first pass of the suffix sort) the packed text.
+// Every source splits a key into load() -- nothing but the loads -- and key_of() / hist_digit_of() -- the
+// arithmetic: the kernels issue the loads of a whole tile first.  (With the arithmetic inside the load loop
+// the compiler waited for every load on its own, `s_waitcnt vmcnt(0)` sixteen times per thread: the passes
+// that compute their keys ran 1.4 x slower than the passes that only read them.)
 template <typename KeyT> struct ArraySrc {
+    using Raw = KeyT;
     const KeyT *__restrict__ keys;
     const uint32_t *__restrict__ vals;
-    __device__ __forceinline__ KeyT key(size_t idx, const TileExtent &) const { return keys[idx]; }
+    __device__ __forceinline__ Raw load(size_t idx, const TileExtent &) const { return keys[idx]; }
+    __device__ __forceinline__ KeyT key_of(Raw raw, size_t, const TileExtent &) const { return raw; }
+    __device__ __forceinline__ uint32_t hist_digit_of(Raw raw, size_t, int shift, const TileExtent &) const { return digit_of(raw, shift); }
     __device__ __forceinline__ uint32_t val(size_t idx) const { return vals[idx]; }
-    // histogram passes: what to load, and the digit of what was loaded (kept apart so that all loads
-    // of a tile are issued before the first digit is needed)
-    __device__ __forceinline__ KeyT hist_raw(size_t idx, int, const TileExtent &) const { return keys[idx]; }
-    __device__ __forceinline__ uint32_t hist_digit(KeyT raw, int shift) const { return digit_of(raw, shift); }
     __device__ __forceinline__ bool digits_from_window(int) const { return false; }
     __device__ __forceinline__ uint64_t window(size_t) const { return 0; }
 };
 template <int BITS> struct TextSrc {
+    using Raw = SymWords;
     const uint64_t *__restrict__ words;
     TermTable terms;
     bool segmented;
     bool digit_from_text = true;  // MSD histogram digit straight from the packed text (no terminators in the text)
-    __device__ __forceinline__ uint64_t key(size_t idx, const TileExtent &) const {
-        return initial_key<BITS>(words, terms, segmented, (uint32_t)idx);
+    __device__ __forceinline__ Raw load(size_t idx, const TileExtent &) const { return sym_words<BITS>(words, idx); }
+    __device__ __forceinline__ uint64_t key_of(const Raw &raw, size_t idx, const TileExtent &) const {
+        return initial_key_of<BITS>(sym_word_of<BITS>(raw, idx), terms, segmented, (uint32_t)idx);
     }
     __device__ __forceinline__ uint32_t val(size_t idx) const { return (uint32_t)idx; }
     // histogram passes only need the digit; the top 8 bits of a plain key are the first 8 / BITS
     // symbols, straight from the packed text (no length tag, no terminator search)
-    __device__ __forceinline__ uint64_t hist_raw(size_t idx, int shift, const TileExtent &ext) const {
+    __device__ __forceinline__ uint32_t hist_digit_of(const Raw &raw, size_t idx, int shift, const TileExtent &ext) const {
         constexpr int kKeyBits = KeyLayout<BITS>::kSyms * BITS + KeyLayout<BITS>::kTagBits;
         if (!segmented && digit_from_text && shift == kKeyBits - kRadixBits)
-            return sym_word<BITS>(words, idx) >> (64 - kKeyBits);
-        return key(idx, ext);
+            return digit_of(sym_word_of<BITS>(raw, idx) >> (64 - kKeyBits), shift);
+        return digit_of(key_of(raw, idx, ext), shift);
     }
-    __device__ __forceinline__ uint32_t hist_digit(uint64_t raw, int shift) const { return digit_of(raw, shift); }
     // the most significant digits of 16 CONSECUTIVE suffixes are 8-bit windows of one 64-bit piece of a
     // 2-bit text: a histogram thread can take 16 neighbours with two loads instead of 16 strided
     // elements with 32
@@ -119,10 +123,12 @@ template <int BITS> struct TextSrc {
 // the tile's own text positions, the key [kRecSyms bases][4-bit length tag] of a suffix needs the end of its
 // record -- the terminator of the tile's bucket, one scalar load per tile instead of a table search per suffix.
 struct RecordTextSrc {
+    using Raw = SymWords;
     const uint64_t *__restrict__ words;
     const uint32_t *__restrict__ term_pos;  // terminator of record k (the separator behind it; n for the last one)
-    __device__ __forceinline__ uint32_t key(size_t idx, const TileExtent &ext) const {
-        const uint64_t w = sym_word<2>(words, idx);
+    __device__ __forceinline__ Raw load(size_t idx, const TileExtent &) const { return sym_words<2>(words, idx); }
+    __device__ __forceinline__ uint32_t key_of(const Raw &raw, size_t idx, const TileExtent &ext) const {
+        const uint64_t w = sym_word_of<2>(raw, idx);
         const uint32_t lim = term_pos[ext.bucket] - (uint32_t)idx;
         const uint32_t tag = lim < (uint32_t)kRecSyms ? lim : (uint32_t)kRecSyms;
         uint32_t sym = (uint32_t)(w >> (64 - kRecSyms * 2));
@@ -130,21 +136,22 @@ struct RecordTextSrc {
         return (sym << kRecTagBits) | tag;
     }
     __device__ __forceinline__ uint32_t val(size_t idx) const { return (uint32_t)idx; }
-    __device__ __forceinline__ uint32_t hist_raw(size_t idx, int, const TileExtent &ext) const { return key(idx, ext); }
-    __device__ __forceinline__ uint32_t hist_digit(uint32_t raw, int shift) const { return digit_of(raw, shift); }
+    __device__ __forceinline__ uint32_t hist_digit_of(const Raw &raw, size_t idx, int shift, const TileExtent &ext) const {
+        return digit_of(key_of(raw, idx, ext), shift);
+    }
     __device__ __forceinline__ bool digits_from_window(int) const { return false; }
     __device__ __forceinline__ uint64_t window(size_t) const { return 0; }
 };
-
 // (position, value) pairs of a block-diagonal permutation (RecordScatterPlan): the key is the position
 // inside the record, ext.aux = first position of the tile's record
 struct LocalIdxSrc {
+    using Raw = uint32_t;
     const uint32_t *__restrict__ idx;
     const uint32_t *__restrict__ vals;
-    __device__ __forceinline__ uint32_t key(size_t i, const TileExtent &ext) const { return idx[i] - ext.aux; }
+    __device__ __forceinline__ Raw load(size_t i, const TileExtent &) const { return idx[i]; }
+    __device__ __forceinline__ uint32_t key_of(Raw raw, size_t, const TileExtent &ext) const { return raw - ext.aux; }
+    __device__ __forceinline__ uint32_t hist_digit_of(Raw raw, size_t, int shift, const TileExtent &ext) const { return digit_of(raw - ext.aux, shift); }
     __device__ __forceinline__ uint32_t val(size_t i) const { return vals[i]; }
-    __device__ __forceinline__ uint32_t hist_raw(size_t i, int, const TileExtent &ext) const { return idx[i] - ext.aux; }
-    __device__ __forceinline__ uint32_t hist_digit(uint32_t raw, int shift) const { return digit_of(raw, shift); }
     __device__ __forceinline__ bool digits_from_window(int) const { return false; }
     __device__ __forceinline__ uint64_t window(size_t) const { return 0; }
 };
@@ -178,17 +185,19 @@ __global__ __launch_bounds__(kThreads) void rs_hist_kernel(Src src, size_t n, in
             if (local0 + (uint32_t)j < ext.count)
                 atomicAdd(&hist[(uint32_t)((w >> (64 - kRadixBits - 2 * j)) & (uint64_t)(kBins - 1)) * kCopies + copy], 1u);
     } else {
-        // all loads first: the compiler does not move loads across the LDS atomics
-        KeyT k[kKeysPerThread];
+        // all loads first: the compiler does not move loads across the LDS atomics (elements past the end of
+        // the tile load its first element again: no branch around a load, nothing waits in between)
+        typename Src::Raw k[kKeysPerThread];
 #pragma unroll
         for (int j = 0; j < kKeysPerThread; ++j) {
             const uint32_t local = (uint32_t)j * kThreads + threadIdx.x;
-            k[j] = local < ext.count ? (KeyT)src.hist_raw(ext.first + local, shift, ext) : KeyT(0);
+            k[j] = src.load(ext.first + (local < ext.count ? local : 0u), ext);
         }
 #pragma unroll
         for (int j = 0; j < kKeysPerThread; ++j) {
             const uint32_t local = (uint32_t)j * kThreads + threadIdx.x;
-            if (local < ext.count) atomicAdd(&hist[src.hist_digit(k[j], shift) * kCopies + copy], 1u);
+            if (local < ext.count)
+                atomicAdd(&hist[src.hist_digit_of(k[j], ext.first + local, shift, ext) * kCopies + copy], 1u);
         }
     }
     __syncthreads();
@@ -226,12 +235,28 @@ __global__ __launch_bounds__(kThreads) void rs_scatter_kernel(
     // all loads of the tile go out before anything is ranked (the ranking below goes through
     // volatile LDS counters, which the compiler will not move loads across: interleaved, every row
     // would wait for its own round trip to HBM)
+    // (a source that computes its keys keeps eight raw elements in flight at a time: sixteen would not fit
+    // the registers next to the keys)
+    constexpr int kBatch = sizeof(typename Src::Raw) > sizeof(KeyT) ? 8 : kKeysPerThread;
+#pragma unroll
+    for (int r0 = 0; r0 < kKeysPerThread; r0 += kBatch) {
+        typename Src::Raw raw[kBatch];
+#pragma unroll
+        for (int r = 0; r < kBatch; ++r) {
+            const uint32_t local = (uint32_t)w * kWaveSpan + (uint32_t)(r0 + r) * 64 + lane;
+            raw[r] = src.load(base + (local < ext.count ? local : 0u), ext);  // (past the end: the first element again)
+        }
+#pragma unroll
+        for (int r = 0; r < kBatch; ++r) {
+            const uint32_t local = (uint32_t)w * kWaveSpan + (uint32_t)(r0 + r) * 64 + lane;
+            const bool valid = local < ext.count;
+            key[r0 + r] = valid ? (KeyT)src.key_of(raw[r], base + local, ext) : KeyT(0);
+        }
+    }
 #pragma unroll
     for (int row = 0; row < kKeysPerThread; ++row) {
         const uint32_t local = (uint32_t)w * kWaveSpan + (uint32_t)row * 64 + lane;
-        const bool valid = local < ext.count;
-        key[row] = valid ? (KeyT)src.key(base + local, ext) : KeyT(0);
-        val[row] = valid ? src.val(base + local) : 0;
+        val[row] = local < ext.count ? src.val(base + local) : 0;
     }
     // rank inside the wavefront: rows of 64 keys in input order (keeps the sort stable).  The lowest
     // lane of every digit group adds the group's size to the wave's counter with ONE returning LDS
@@ -422,8 +447,9 @@ __global__ __launch_bounds__(kThreads) void window_scatter_kernel(const IdxT *__
 #pragma unroll
         for (int j = 0; j < kBatch; ++j) {
             const uint32_t t = t0 + (uint32_t)j * kThreads + threadIdx.x;
-            ii[j] = t < len ? (uint32_t)idx[base + t] : 0u;
-            vv[j] = t < len ? val[base + t] : 0u;
+            const size_t at = base + (t < len ? t : 0u);  // (no branch around the loads)
+            ii[j] = (uint32_t)idx[at];
+            vv[j] = val[at];
         }
 #pragma unroll
         for (int j = 0; j < kBatch; ++j) {
@@ -454,8 +480,9 @@ __global__ __launch_bounds__(kThreads) void record_window_scatter_kernel(const I
 #pragma unroll
         for (int j = 0; j < kBatch; ++j) {
             const uint32_t t = t0 + (uint32_t)j * kThreads + threadIdx.x;
-            ii[j] = t < len ? (uint32_t)idx[base + t] : 0u;
-            vv[j] = t < len ? val[base + t] : 0u;
+            const size_t at = base + (t < len ? t : 0u);  // (no branch around the loads)
+            ii[j] = (uint32_t)idx[at];
+            vv[j] = val[at];
         }
 #pragma unroll
         for (int j = 0; j < kBatch; ++j) {
@@ -502,7 +529,14 @@ bool record_scatter_plan(const std::vector<uint32_t> &h_terms, uint32_t n, Arena
         if (len == 0 || len > (1u << (wb + kRadixBits))) return false;
         h_first[k] = k + 1 < nb ? start + 1 : start;  // first base rank
         h_aux[k] = start;
-        h_tile0[k + 1] = h_tile0[k] + (uint32_t)div_up((size_t)len, kTile);
+        {
+            // tiles behind the first one start at multiples of 64 elements: a wavefront's 64-lane loads are
+            // then aligned to their 256 bytes (a bucket starts wherever its record does; unaligned, every row
+            // of a tile touches three lines instead of two and the pass ran 1.4 x slower)
+            const uint32_t f0 = k + 1 < nb ? start + 1 : start;
+            const uint32_t c0 = (uint32_t)kTile - f0 % 64u;
+            h_tile0[k + 1] = h_tile0[k] + (len <= c0 ? 1u : 1u + (uint32_t)div_up((size_t)(len - c0), kTile));
+        }
         h_prev[k] = k ? k - 1 : 0xffffffffu;
         h_next[k] = k + 1 < nb ? k + 1 : 0xffffffffu;
         if (k + 1 < nb) {
@@ -528,11 +562,13 @@ bool record_scatter_plan(const std::vector<uint32_t> &h_terms, uint32_t n, Arena
         for (uint32_t k = 0; k < nb; ++k) {
             const uint32_t len = (k + 1 < nb ? h_terms[k] : n) - s0;
             const uint32_t first = h_first[k], t0 = h_tile0[k], nt = h_tile0[k + 1] - t0;
+            const uint32_t c0 = (uint32_t)kTile - first % 64u;  // elements of the first tile (see above)
             for (uint32_t local = 0; local < nt; ++local) {
                 uint32_t *d = desc.data() + (size_t)(t0 + local) * kSegDescWords;
-                const uint32_t f = first + local * (uint32_t)kTile, e = first + len;
+                const uint32_t f = local == 0 ? first : first + c0 + (local - 1) * (uint32_t)kTile, e = first + len;
                 d[0] = f;
-                d[1] = e - f < (uint32_t)kTile ? e - f : (uint32_t)kTile;
+                const uint32_t room = local == 0 ? c0 : (uint32_t)kTile;
+                d[1] = e - f < room ? e - f : room;
                 d[2] = k;
                 d[3] = t0 * (uint32_t)kBins + local;
                 d[4] = nt;

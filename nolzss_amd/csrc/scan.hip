@@ -21,12 +21,21 @@ __global__ __launch_bounds__(kThreads) void reduce_tiles_kernel(const uint32_t *
     Op op;
     const size_t base = (size_t)blockIdx.x * kTile;
     uint32_t acc = Op::identity();
+    // every load first (elements past the end load the last one again and are not counted): with the
+    // accumulation inside the guarded load the compiler waited for each load on its own
+    uint32_t v[kRows][kItemsPerThread];
 #pragma unroll
     for (int row = 0; row < kRows; ++row) {
-        size_t idx = base + ((size_t)row * kThreads + threadIdx.x) * kItemsPerThread;
+        const size_t idx = base + ((size_t)row * kThreads + threadIdx.x) * kItemsPerThread;
+#pragma unroll
+        for (int e = 0; e < kItemsPerThread; ++e) v[row][e] = in[idx + e < n ? idx + e : n - 1];
+    }
+#pragma unroll
+    for (int row = 0; row < kRows; ++row) {
+        const size_t idx = base + ((size_t)row * kThreads + threadIdx.x) * kItemsPerThread;
 #pragma unroll
         for (int e = 0; e < kItemsPerThread; ++e)
-            if (idx + e < n) acc = op(acc, in[idx + e]);
+            if (idx + e < n) acc = op(acc, v[row][e]);
     }
     acc = wave_reduce(acc, op);
     if (lane_id() == 0) lds[threadIdx.x >> 6] = acc;

@@ -160,10 +160,10 @@ __device__ __forceinline__ int suffix_compare(const uint64_t *__restrict__ w, co
 // [kSegSyms symbols][5-bit tag][8-bit terminator index] for segmented texts: a suffix that meets a
 // terminator inside the key window gets a key of its own, so every group left after the sort
 // consists of suffixes that agree on kSegSyms real nucleotides.
+// (w = the 64 text bits at suffix i, sym_word: callers that want every load of a tile in flight before the
+// first key is assembled fetch the two words themselves)
 template <int BITS>
-__device__ __forceinline__ uint64_t initial_key(const uint64_t *__restrict__ words, const TermTable &terms,
-                                                bool segmented, uint32_t i) {
-    const uint64_t w = sym_word<BITS>(words, i);
+__device__ __forceinline__ uint64_t initial_key_of(uint64_t w, const TermTable &terms, bool segmented, uint32_t i) {
     // (one segment: no search and, above all, no load that the key would have to wait for behind its text
     // window -- the first radix pass generates 2^30 keys)
     const uint32_t k = terms.count == 1 ? 0u : term_lower_bound(terms, i);
@@ -193,6 +193,25 @@ __device__ __forceinline__ uint64_t initial_key(const uint64_t *__restrict__ wor
     // symbols behind a terminator belong to the next segment (zero behind the end of the text)
     if (tag < (uint32_t)K) sym &= ~((1ull << (BITS * (K - (int)tag))) - 1ull);
     return (sym << TAG) | tag;
+}
+
+template <int BITS>
+__device__ __forceinline__ uint64_t initial_key(const uint64_t *__restrict__ words, const TermTable &terms,
+                                                bool segmented, uint32_t i) {
+    return initial_key_of<BITS>(sym_word<BITS>(words, i), terms, segmented, i);
+}
+
+// the two words behind sym_word, and the window assembled from them
+struct SymWords {
+    uint64_t a, b;
+};
+template <int BITS> __device__ __forceinline__ SymWords sym_words(const uint64_t *__restrict__ w, uint64_t pos) {
+    const uint64_t wi = (pos * BITS) >> 6;
+    return SymWords{w[wi], w[wi + 1]};
+}
+template <int BITS> __device__ __forceinline__ uint64_t sym_word_of(const SymWords &x, uint64_t pos) {
+    const int o = (int)((pos * BITS) & 63);
+    return o ? ((x.a << o) | (x.b >> (64 - o))) : x.a;
 }
 
 }  // namespace nolzss
