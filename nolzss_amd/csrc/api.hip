@@ -1690,10 +1690,16 @@ __global__ __launch_bounds__(256) void gather_records_kernel(const GatherRec *__
     for (uint32_t k = blockIdx.y; k < c; k += gridDim.y) {
         const GatherRec r = recs[k];
         for (uint64_t p0 = (uint64_t)blockIdx.x * 4096; p0 < r.len; p0 += (uint64_t)gridDim.x * 4096) {
+            uint8_t b[16];  // (all loads first, none behind a branch: bytes past the end read the last byte again)
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const uint64_t p = p0 + (uint64_t)j * 256 + threadIdx.x;
-                if (p < r.len) dst[r.off + p] = r.src[p];
+                b[j] = r.src[p < r.len ? p : r.len - 1];
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const uint64_t p = p0 + (uint64_t)j * 256 + threadIdx.x;
+                if (p < r.len) dst[r.off + p] = b[j];
             }
         }
         if (blockIdx.x == 0 && threadIdx.x == 0 && k + 1 < c) dst[r.off + r.len] = sep;
