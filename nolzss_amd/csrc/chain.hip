@@ -258,11 +258,16 @@ __global__ __launch_bounds__(kThreads) void factor_kernel(const uint32_t *__rest
                                                           const uint32_t *__restrict__ sa,
                                                           const uint32_t *__restrict__ lcp, Pyramid Psa,
                                                           Pyramid Plcp, Pyramid Pmax, uint32_t rcN,
-                                                          FactorRec *__restrict__ out, TermTable terms) {
+                                                          FactorRec *__restrict__ out, TermTable terms, uint32_t n) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < z; k += stride) {
         const uint32_t i = fpos[k];
-        const uint32_t code = lstar[i];
+        // the factors tile the text: the length is the distance to the next factor (a coalesced read) -- the
+        // length code itself is needed only to tell a literal from a match of one symbol, and for the
+        // reverse-complement flag
+        const uint32_t nxt = k + 1 < z ? fpos[k + 1] : n;
+        uint32_t code = nxt - i;
+        if (kRC || code == 1u) code = lstar[i];
         const uint32_t L = code & kLenMask;
         const bool is_rc = kRC && (code >> 31);
         FactorRec f;
@@ -433,13 +438,13 @@ uint32_t resolve_chain(Context &ctx, uint32_t n, uint32_t start_pos, const uint3
         if (rcN) {
             if (rebase) throw HipError("resolve_chain: record-relative output exists in plain mode only");
             factor_kernel<true, false><<<grid_for(z), kThreads, 0, s>>>(fpos, z, lstar, isa, sa, lcp, Psa, Plcp, *Pmax,
-                                                                        rcN, recs_tmp, TermTable{});
+                                                                        rcN, recs_tmp, TermTable{}, n);
         } else if (rebase) {
             factor_kernel<false, true><<<grid_for(z), kThreads, 0, s>>>(fpos, z, lstar, isa, sa, lcp, Psa, Plcp, Psa,
-                                                                        0u, recs_tmp, *rebase);
+                                                                        0u, recs_tmp, *rebase, n);
         } else {
             factor_kernel<false, false><<<grid_for(z), kThreads, 0, s>>>(fpos, z, lstar, isa, sa, lcp, Psa, Plcp, Psa,
-                                                                         0u, recs_tmp, TermTable{});
+                                                                         0u, recs_tmp, TermTable{}, n);
         }
         KERNEL_CHECK();
     }

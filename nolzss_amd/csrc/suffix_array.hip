@@ -67,13 +67,23 @@ __global__ __launch_bounds__(kThreads) void presence_kernel(const uint8_t *__res
     if (((uintptr_t)text & 15) == 0) {
         const uint4 *v = reinterpret_cast<const uint4 *>(text);
         const size_t nv = n / 16;
-        for (size_t i = tid; i < nv; i += stride) {
-            const uint4 x = v[i];
-            const uint32_t wds[4] = {x.x, x.y, x.z, x.w};
+        // four loads in flight per thread (a piece past the end reads the last piece again: marking a byte
+        // twice changes nothing)
+        for (size_t i = tid; i < nv; i += 4 * stride) {
+            uint4 x[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int u = 0; u < 4; ++u) {
+                const size_t q = i + (size_t)u * stride;
+                x[u] = v[q < nv ? q : nv - 1];
+            }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) mark_byte(m, (wds[k] >> (8 * e)) & 255u);
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t wds[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) mark_byte(m, (wds[k] >> (8 * e)) & 255u);
+            }
         }
         for (size_t i = nv * 16 + tid; i < n; i += stride) mark_byte(m, text[i]);
     } else {
