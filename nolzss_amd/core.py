@@ -1,84 +1,78 @@
-"""User-facing factorize API (mirror of the reference's noLZSS.core for the hot path,
-reference: src/noLZSS/core.py:25-107): validate, then call the native module."""
+"""The user-facing factorize API of the hot path, written once for both import names.
+
+`bind(native)` builds the seven functions of the reference's `noLZSS.core` (reference:
+src/noLZSS/core.py:25-257 -- names, argument meaning, error behaviour) over a native module:
+`nolzss_amd.core` binds them to the ctypes mirror `nolzss_amd._noLZSS`, `noLZSS.core` to the compiled
+pybind11 module `noLZSS._noLZSS`.  Both native modules call the same C ABI (include/nolzss_hip.h).
+"""
 from pathlib import Path
 from typing import List, Tuple, Union
 
-from ._noLZSS import (
-    factorize as _factorize,
-    factorize_file as _factorize_file,
-    count_factors as _count_factors,
-    count_factors_file as _count_factors_file,
-    write_factors_binary_file as _write_factors_binary_file,
-    factorize_w_reference as _factorize_w_reference,
-    factorize_w_reference_file as _factorize_w_reference_file,
-)
 from .utils import validate_input
 
+__all__ = ["factorize", "factorize_file", "count_factors", "count_factors_file", "write_factors_binary_file",
+           "factorize_w_reference", "factorize_w_reference_file"]
 
-def factorize(data: Union[str, bytes], validate: bool = True) -> List[Tuple[int, int, int]]:
-    """reference: core.py:25-43"""
-    if validate:
-        data = validate_input(data)
-    return _factorize(data)
-
-
-def factorize_file(filepath: Union[str, Path], reserve_hint: int = 0) -> List[Tuple[int, int, int]]:
-    """reference: core.py:46-65 (FileNotFoundError before the extension is touched)"""
-    filepath = Path(filepath)
-    if not filepath.exists():
-        raise FileNotFoundError(f"File not found: {filepath}")
-    return _factorize_file(str(filepath), reserve_hint)
+Factors = List[Tuple[int, int, int]]
+Text = Union[str, bytes]
+PathLike = Union[str, Path]
 
 
-def count_factors(data: Union[str, bytes], validate: bool = True) -> int:
-    """reference: core.py:68-86"""
-    if validate:
-        data = validate_input(data)
-    return _count_factors(data)
+def _existing(filepath: PathLike) -> str:
+    p = Path(filepath)
+    if not p.exists():  # before the extension is touched (reference: core.py:61-63, 102-104)
+        raise FileNotFoundError(f"File not found: {p}")
+    return str(p)
 
 
-def count_factors_file(filepath: Union[str, Path], validate: bool = True) -> int:
-    """reference: core.py:89-107"""
-    filepath = Path(filepath)
-    if not filepath.exists():
-        raise FileNotFoundError(f"File not found: {filepath}")
-    return _count_factors_file(str(filepath))
+def _writable(filepath: PathLike) -> str:
+    p = Path(filepath)
+    p.parent.mkdir(parents=True, exist_ok=True)  # reference: core.py:130-131, 254-255
+    return str(p)
 
 
-def write_factors_binary_file(data: Union[str, bytes], output_filepath: Union[str, Path]) -> None:
-    """reference: core.py:110-132.  Kept bug-for-bug: the reference hands the validated *data*
-    to a native parameter that is an input FILE PATH (bindings.cpp:180-187), so `data` must name
-    a file (README.md:65 passes paths)."""
-    data = validate_input(data)
-    output_filepath = Path(output_filepath)
-    output_filepath.parent.mkdir(parents=True, exist_ok=True)
-    _write_factors_binary_file(data, str(output_filepath))
+def bind(native) -> dict:
+    """the functions of `__all__` over `native` (a module with the reference's `_noLZSS` surface)"""
+
+    def checked(data: Text, validate: bool):
+        return validate_input(data) if validate else data
+
+    def factorize(data: Text, validate: bool = True) -> Factors:
+        """(start, length, ref) of every factor of `data` (reference: core.py:25-43)"""
+        return native.factorize(checked(data, validate))
+
+    def count_factors(data: Text, validate: bool = True) -> int:
+        """number of factors of `data` (reference: core.py:68-86)"""
+        return native.count_factors(checked(data, validate))
+
+    def factorize_file(filepath: PathLike, reserve_hint: int = 0) -> Factors:
+        """factors of the bytes of a file (reference: core.py:46-65)"""
+        return native.factorize_file(_existing(filepath), reserve_hint)
+
+    def count_factors_file(filepath: PathLike, validate: bool = True) -> int:
+        """number of factors of the bytes of a file (reference: core.py:89-107; `validate` is unused there too)"""
+        return native.count_factors_file(_existing(filepath))
+
+    def write_factors_binary_file(data: Text, output_filepath: PathLike, validate: bool = True) -> None:
+        """Kept from the reference (core.py:110-132 against bindings.cpp:180-187): the validated `data` goes to a
+        parameter of the native function that is an input FILE PATH, so `data` must name a file (README.md:65)."""
+        native.write_factors_binary_file(checked(data, validate), _writable(output_filepath))
+
+    def factorize_w_reference(reference_seq: Text, target_seq: Text, validate: bool = True) -> Factors:
+        """the target factorized against reference + '\\x01' + target, positions absolute in that string
+        (reference: core.py:164-207)"""
+        return native.factorize_w_reference(checked(reference_seq, validate), checked(target_seq, validate))
+
+    def factorize_w_reference_file(reference_seq: Text, target_seq: Text, output_path: PathLike,
+                                   validate: bool = True) -> int:
+        """the same into a v2 binary factor file; returns the number of factors (reference: core.py:210-257)"""
+        return native.factorize_w_reference_file(checked(reference_seq, validate), checked(target_seq, validate),
+                                                 _writable(output_path))
+
+    fns = locals()
+    return {name: fns[name] for name in __all__}
 
 
-def factorize_w_reference(reference_seq: Union[str, bytes], target_seq: Union[str, bytes],
-                          validate: bool = True) -> List[Tuple[int, int, int]]:
-    """reference: core.py:164-207 -- target factorized against reference + '\\x01' + target;
-    start positions are absolute in the combined string."""
-    if validate:
-        reference_seq = validate_input(reference_seq)
-        target_seq = validate_input(target_seq)
-    if isinstance(reference_seq, bytes):
-        reference_seq = reference_seq.decode("ascii")
-    if isinstance(target_seq, bytes):
-        target_seq = target_seq.decode("ascii")
-    return _factorize_w_reference(reference_seq, target_seq)
+from . import _noLZSS as _mirror  # noqa: E402
 
-
-def factorize_w_reference_file(reference_seq: Union[str, bytes], target_seq: Union[str, bytes],
-                               output_path: Union[str, Path], validate: bool = True) -> int:
-    """reference: core.py:210-257"""
-    if validate:
-        reference_seq = validate_input(reference_seq)
-        target_seq = validate_input(target_seq)
-    if isinstance(reference_seq, bytes):
-        reference_seq = reference_seq.decode("ascii")
-    if isinstance(target_seq, bytes):
-        target_seq = target_seq.decode("ascii")
-    output_path = Path(output_path)
-    output_path.parent.mkdir(parents=True, exist_ok=True)
-    return _factorize_w_reference_file(reference_seq, target_seq, str(output_path))
+globals().update(bind(_mirror))

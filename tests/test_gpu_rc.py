@@ -34,6 +34,13 @@ def test_rc_forward_preferred_on_tie(native):
     assert native.factorize_dna_w_rc(v["input"].encode())[v["index"]] == tuple(v["factor"])
 
 
+def test_doc_example_follows_the_code(native):
+    """docs/RC_ALGORITHM.md:298-323 (ATCGATCG): the GPU path gives what the code of the reference gives
+    (trace in kats.json), not the simplified table of the doc."""
+    v = KATS["reference_doc_example_contradicted_by_the_code"][0]
+    assert native.factorize_dna_w_rc(v["input"].encode()) == [tuple(f) for f in v["code_trace"]]
+
+
 def _mixed(rng, n, p_copy=0.5, maxlen=40):
     s = ""
     while len(s) < n:

@@ -37,6 +37,19 @@ def test_rc_forward_preferred_on_tie():
     assert got[v["index"]] == tuple(v["factor"])
 
 
+def test_doc_example_the_code_contradicts():
+    """docs/RC_ALGORITHM.md:298-323 tabulates ATCGATCG as four literals + (4,4,0); a node-by-node trace of
+    factorizer_core.hpp:256-352 (kept with the vector in kats.json) gives an RC factor at 3, as in the
+    reference's own test vector ATGCAT.  The oracle and both brute-force models follow the code."""
+    v = KATS["reference_doc_example_contradicted_by_the_code"][0]
+    expected = [tuple(f) for f in v["code_trace"]]
+    assert oracle.factorize_dna_w_rc(_text(v)) == expected
+    assert bf.rc_factorize(v["input"]) == expected
+    assert expected != [tuple(f) for f in v["doc_table"]]
+    # the plain-mode parse of the same text is what the doc table shows
+    assert oracle.factorize(_text(v)) == [tuple(f[:3]) for f in v["doc_table"]]
+
+
 def _gen(rng, kind, n):
     if kind == 0:
         return "".join(rng.choice("ACGT") for _ in range(n))
