@@ -3,6 +3,7 @@
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py --gpus N ...       (WORLD_SIZE unset: starts its own N ranks as child processes)
 
 Headline workload (BASELINE.json config 3, the configuration the metric is quoted on): one 2^30-base
 synthetic DNA string (sigma = 4, 40 % copied blocks with 1 % substitutions, generator and seed in
@@ -16,6 +17,8 @@ pack -> suffix array -> LCP -> L* -> chain -> all z factor records (start, lengt
 Beside `value` the same JSON line carries
   * "stopwatches" (N = 1): the three clocks of SURVEY.md 8d -- C ABI host buffer -> host factor array,
     count_factors from a host buffer, and the Python-visible noLZSS.factorize() (tuple list) on a prefix;
+  * "rc256m": BASELINE config 5 on one GPU per rank (factorize_dna_w_rc of 2^28 bases resident in HBM, SURVEY.md
+    8d's 84 B/base, stage table, its own cpu_baseline);
   * "fasta512": BASELINE config 4, the multi-sequence FASTA shard (512 records x 4 Mi bases, generator of
     config 2 with seeds 0x4000 + k) dealt over the N ranks by the longest-processing-time-first plan, one
     all-gather of the 512 factor counts -- STRONG scaling (total work fixed), records resident in HBM when
@@ -25,6 +28,8 @@ Beside `value` the same JSON line carries
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import tempfile
 import time
@@ -32,18 +37,40 @@ from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 
 import numpy as np
-import torch
-import torch.distributed as dist
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
-import gen  # noqa: E402
-from nolzss_amd import _noLZSS as native  # noqa: E402
+import gen  # noqa: E402  (NumPy generators of the synthetic inputs; no device code)
+
+# torch, torch.distributed and the library are imported by main() AFTER the decision to start the ranks as
+# child processes: the parent of a self-launched run never touches the GPU (and never execs).
+torch = dist = native = None
+
+
+def late_imports():
+    global torch, dist, native
+    import torch as _torch
+    import torch.distributed as _dist
+    from nolzss_amd import _noLZSS as _native
+    torch, dist, native = _torch, _dist, _native
+
+
+def self_launch(a, argv) -> int:
+    """`python bench.py --gpus N` outside a launcher: start the N ranks as child processes through
+    torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1) and relay their output; rank 0
+    prints the JSON line to the stdout this process shares with them."""
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + list(argv)
+    return subprocess.run(cmd).returncode
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured copy
 ALG_BYTES_PER_BASE = 50.0  # SURVEY.md 8d, plain mode: compulsory traffic of the whole pipeline
+ALG_BYTES_PER_BASE_RC = 84.0  # SURVEY.md 8d, reverse-complement mode (arrays over |S| = 2n + 2)
 # rs_scatter_kernel: 2 * (sizeof(key) + 4) algorithmic bytes per (key, value) pair per launch
 # (24 B for the u64-key sorts, 16 B for the u32-key partition passes); the library sums them.
 DOMINANT = "rs_scatter"
@@ -109,28 +136,39 @@ class Job:
     def __init__(self, a):
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
+        if self.world != a.gpus:
+            raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={self.world} (start it without WORLD_SIZE and it "
+                             "launches its own ranks, or give torch.distributed.run the same number)")
         self.local_rank = 0 if a.same_device else int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(self.local_rank)
         self.backend = a.backend
-        if self.world > 1:
+        # --force-collectives: a one-rank run still opens the process group and issues every collective of the
+        # multi-rank path (the RCCL code path on a one-GPU box)
+        self.collectives = self.world > 1 or a.force_collectives
+        if self.collectives:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.world == 1:
+                with socket.socket() as sock:
+                    sock.bind(("127.0.0.1", 0))
+                    os.environ.setdefault("MASTER_PORT", str(sock.getsockname()[1]))
+                os.environ.setdefault("RANK", "0")
+                os.environ.setdefault("WORLD_SIZE", "1")
             if a.backend == "nccl":
                 dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
             else:
                 dist.init_process_group("gloo")
-        assert self.world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={self.world}"
         self.dev = torch.device("cuda", self.local_rank)
         self.cdev = self.dev if a.backend == "nccl" else torch.device("cpu")
         native.set_device(self.local_rank)
 
     def barrier(self):
-        if self.world > 1:
+        if self.collectives:
             dist.barrier()
         torch.cuda.synchronize()
 
     def max_over_ranks(self, seconds: float) -> float:
         t = torch.tensor([seconds], dtype=torch.float64, device=self.cdev)
-        if self.world > 1:
+        if self.collectives:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -145,7 +183,7 @@ def run_single_sequence(job: Job, a):
 
     def step():
         z, _ = native.factorize_device(d_text.data_ptr(), n, emit=1)
-        if job.world > 1:  # the only collective: per-sequence factor counts
+        if job.collectives:  # the only collective: per-sequence factor counts
             mine[0] = z
             dist.all_gather_into_tensor(counts, mine)
         return z
@@ -229,6 +267,67 @@ def run_single_sequence(job: Job, a):
     return out, text, z
 
 
+def cpu_baseline_rc(text: np.ndarray, sample: int):
+    """The oracle in reverse-complement mode (prepare + nolzss_multiple_dna_w_rc restated, single thread)
+    on a bounded prefix of the rc256m text."""
+    import oracle_lib as oracle  # checker only: never on the measured path
+    sample = min(sample, len(text))
+    t0 = time.perf_counter()
+    S, _, _ = oracle.prepare_multiple_dna_w_rc([text[:sample].tobytes()])
+    z = oracle.count_factors_multiple_dna_w_rc(S)
+    dt = time.perf_counter() - t0
+    return {"value": sample / dt, "unit": "bases/s", "cores": 1, "kind": "port",
+            "sample": f"first {sample} bases of the rank-0 rc256m text (+ their reverse complement), count_factors, "
+                      f"{dt:.1f} s, z={z}"}
+
+
+def run_rc(job: Job, a):
+    """BASELINE config 5 on one GPU per rank: factorize_dna_w_rc of a 2^28-base text (generator of config 3, seed
+    0x5EED0005 + rank) resident in HBM: prepared string T s0 rc(T) s1 built on the device, suffix array of its
+    2^29 + 2 symbols, forward and reverse-complement candidates, selection, all records built in HBM.  RC mode does
+    not shard: every rank factorizes its own genome, weak scaling."""
+    n = 1 << a.rc_log2n
+    text = gen.repeat_dna(n, seed=0x5EED0005 + job.rank)
+    d_text = torch.from_numpy(text).to(job.dev)
+    for _ in range(a.rc_warmup):
+        native.factorize_dna_w_rc_device(d_text.data_ptr(), n, emit=1)
+    native.profile_enable(True)
+    native.profile_reset()
+    job.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.rc_steps):
+        z, _ = native.factorize_dna_w_rc_device(d_text.data_ptr(), n, emit=1)
+    job.barrier()
+    elapsed = time.perf_counter() - t0
+    stats = native.profile_report()
+    native.profile_enable(False)
+    elapsed = job.max_over_ranks(elapsed)
+    t1 = time.perf_counter()
+    z2 = native.count_factors_dna_w_rc(text)  # host bytes in (upload + kernels), count out
+    host_dt = time.perf_counter() - t1
+    assert z2 == z
+    del d_text
+    torch.cuda.empty_cache()
+    if job.rank != 0:
+        return None, text
+    step_s = elapsed / a.rc_steps
+    nested = {"rs_hist", "rs_scan", "bucket_scatter", "window_scatter"} | {k for k in stats if k.startswith(DOMINANT)}
+    out = {"workload": f"rc256m: factorize_dna_w_rc of one 2^{a.rc_log2n}-base synthetic DNA text per GPU (sigma=4, 40% "
+                       "copied blocks, 1% substitutions, seed 0x5EED0005 + rank) with its reverse-complement strand "
+                       f"(|S| = 2^{a.rc_log2n + 1} + 2 symbols), text resident in HBM, records built in HBM",
+           "scaling": "weak", "n_gpus": job.world, "steps": a.rc_steps, "warmup": a.rc_warmup,
+           "value": float(n) * job.world / step_s, "unit": "bases/s", "ms_per_step": step_s * 1e3,
+           "factors_per_sequence": int(z),
+           "pipeline_hbm": {"algorithmic_bytes_per_base": ALG_BYTES_PER_BASE_RC,
+                            "achieved_GBps_per_gpu": ALG_BYTES_PER_BASE_RC * n / step_s / 1e9,
+                            "frac_of_peak_per_gpu": ALG_BYTES_PER_BASE_RC * n / step_s / 1e9 / HBM_PEAK_GBS},
+           "count_factors_host_ms": host_dt * 1e3,
+           "stages_ms_per_step": {k: v[1] / a.rc_steps for k, v in sorted(stats.items(), key=lambda kv: -kv[1][1])
+                                  if k not in nested},
+           "kernels_ms_per_step": {k: stats[k][1] / a.rc_steps for k in sorted(nested) if k in stats}}
+    return out, text
+
+
 def stopwatches(text: np.ndarray, z: int, py_log2: int):
     """SURVEY.md 8d: (i) C ABI host-in / host-out, (i') count_factors, (iii) Python-visible tuples;
     (ii) kernel-only is `value`.  One warm call each (the arena is already reserved)."""
@@ -285,7 +384,7 @@ def run_fasta_shard(job: Job, a, with_file: bool):
         vec.zero_()
         if mine:
             vec[idx] = torch.tensor(zs, dtype=torch.int64, device=job.cdev)
-        if job.world > 1:
+        if job.collectives:
             dist.all_gather_into_tensor(gathered, vec)
             return gathered.view(job.world, m).sum(dim=0)
         return vec.clone()
@@ -364,11 +463,22 @@ def main():
     ap.add_argument("--fasta-record-log2", type=int, default=22)
     ap.add_argument("--fasta-steps", type=int, default=2)
     ap.add_argument("--fasta-warmup", type=int, default=1)
+    ap.add_argument("--no-rc", action="store_true", help="skip the rc256m side measurement (BASELINE config 5)")
+    ap.add_argument("--rc-log2n", type=int, default=28)
+    ap.add_argument("--rc-steps", type=int, default=3)
+    ap.add_argument("--rc-warmup", type=int, default=1)
+    ap.add_argument("--rc-cpu-sample-log2", type=int, default=24)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="collective backend for N > 1 (nccl = RCCL over xGMI; gloo only for rehearsals)")
+                    help="collective backend (nccl = RCCL over xGMI; gloo only for rehearsals)")
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal on a one-GPU box: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="with one rank: open the process group and issue every collective of the multi-rank path anyway")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: the N ranks are child processes of this one, which stays off the GPU
+        sys.exit(self_launch(a, sys.argv[1:]))
+    late_imports()
     job = Job(a)
 
     if a.workload == "fasta512":
@@ -387,15 +497,25 @@ def main():
     else:
         out, text, z = run_single_sequence(job, a)
         fa = None if a.no_fasta else run_fasta_shard(job, a, with_file=False)
+        rc, rc_text = (None, None) if a.no_rc else run_rc(job, a)
         if job.rank == 0:
+            if job.collectives:
+                out["collectives"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                                      "forced_on_one_rank": bool(a.force_collectives and job.world == 1)}
             if fa is not None:
                 out["fasta512"] = fa
+            if rc is not None:
+                out["rc256m"] = rc
             if job.world == 1 and not a.no_stopwatches:  # the host-side clocks run on the one-GPU run only
                 out["stopwatches"] = stopwatches(text, z, a.python_sample_log2)
-            if job.world == 1 and not a.no_cpu_baseline:  # the CPU leg runs on rank 0 of the one-GPU run only
+            if job.world == 1 and not a.no_cpu_baseline:  # the CPU legs run on rank 0 of the one-GPU run only
                 out["cpu_baseline"] = cpu_baseline(text, 1 << a.cpu_sample_log2)
+                if fa is not None:
+                    fa["cpu_baseline"] = cpu_baseline_fasta(a)
+                if rc is not None:
+                    rc["cpu_baseline"] = cpu_baseline_rc(rc_text, 1 << a.rc_cpu_sample_log2)
             print(json.dumps(out), flush=True)
-    if job.world > 1:
+    if job.collectives:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -100,6 +100,12 @@ int nolzss_factorize_dna_w_rc(const uint8_t *text, size_t n, int device, nolzss_
                               size_t *z);
 /* reference: noLZSS::count_factors_dna_w_rc, factorizer.cpp:559-561; bindings.cpp:276-295 */
 int nolzss_count_factors_dna_w_rc(const uint8_t *text, size_t n, int device, size_t *z);
+/* noLZSS::factorize_dna_w_rc (factorizer.cpp:519-523) with the text already resident in device memory: the
+ * counterpart of nolzss_factorize_device for the reverse-complement mode (same `stream` and `emit` meaning; the
+ * prepared string T s0 rc(T) s1 of factorizer.cpp:54-172 is built on the device).  Used by bench.py (BASELINE
+ * config 5 with the input in HBM when the clock starts). */
+int nolzss_factorize_dna_w_rc_device(const void *d_text, size_t n, int device, void *stream, int emit,
+                                     nolzss_factor **out_host, size_t *z);
 
 /* ---- reference + target factorization (the chain simply starts at start_pos) */
 /* reference: noLZSS::factorize_w_reference, factorizer.cpp:940-955; bindings.cpp:868-880.

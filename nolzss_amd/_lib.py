@@ -89,6 +89,7 @@ def _load():
     lib.nolzss_count_factors_multiple_dna_w_rc.argtypes = [vp, sz, sz, C.c_int, szp]
     lib.nolzss_factorize_dna_w_rc.argtypes = [vp, sz, C.c_int, vpp, szp]
     lib.nolzss_count_factors_dna_w_rc.argtypes = [vp, sz, C.c_int, szp]
+    lib.nolzss_factorize_dna_w_rc_device.argtypes = [vp, sz, C.c_int, vp, C.c_int, vpp, szp]
     lib.nolzss_factorize_w_reference.argtypes = [vp, sz, vp, sz, C.c_int, vpp, szp]
     lib.nolzss_factorize_dna_w_reference_seq.argtypes = [C.c_char_p, sz, C.c_char_p, sz, C.c_int, vpp, szp]
     lib.nolzss_write_factors_binary_file.argtypes = [C.c_char_p, C.c_char_p, C.c_int, szp]
@@ -163,6 +164,7 @@ EXPORTED_SYMBOLS = [
     "nolzss_debug_batch_counters", "nolzss_factorize_batch_dna_w_rc",
     "nolzss_debug_trim_arenas", "nolzss_debug_parse_fasta",
     "nolzss_read_nucleotide_fasta", "nolzss_free_nucleotide_fasta", "nolzss_debug_parse_nucleotide_fasta", "nolzss_debug_lpt_plan", "nolzss_factorize_batch_device",
+    "nolzss_factorize_dna_w_rc_device",
 ]
 
 

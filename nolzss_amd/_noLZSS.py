@@ -280,6 +280,16 @@ def factorize_dna_w_rc(data):
     return _tuples4(factorize_dna_w_rc_array(data))
 
 
+def factorize_dna_w_rc_device(data_ptr: int, n: int, stream: int = 0, emit: int = 2):
+    """Extension (bench.py, BASELINE config 5): factorize_dna_w_rc of a text that is already in HBM
+    (data_ptr = device address).  emit 0: count only; 1: factor records built in HBM, no download;
+    2: download them.  Returns (z, factor array or None)."""
+    out, z = C.c_void_p(), C.c_size_t()
+    check(lib.nolzss_factorize_dna_w_rc_device(data_ptr, n, _default_device, stream or None, emit,
+                                               C.byref(out) if emit == 2 else None, C.byref(z)))
+    return z.value, (_take(out, z.value) if emit == 2 else None)
+
+
 def count_factors_dna_w_rc(data) -> int:
     """reference: bindings.cpp:276-295"""
     p, n, keep = _as_buffer(data)

@@ -231,6 +231,18 @@ void download_bytes(Context &ctx, void *h_dst, const void *d_src, size_t n) {
     for (hipError_t e : err) HIP_CHECK(e);
 }
 
+// The library's own stream is non-blocking: order it behind the work already queued on the legacy default
+// stream (where torch's default stream and plain hipMemcpyAsync(.., 0) producers of a device-resident text
+// run).  Producers on other non-blocking streams must be synchronised by the caller or pass their stream.
+void order_behind_default_stream(Context &ctx) {
+    hipEvent_t ev = nullptr;
+    HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, nullptr);
+    if (e == hipSuccess) e = hipStreamWaitEvent(ctx.stream, ev, 0);
+    (void)hipEventDestroy(ev);
+    HIP_CHECK(e);
+}
+
 struct DebugOut {
     uint32_t *sa = nullptr, *isa = nullptr, *lcp = nullptr, *lstar = nullptr;
 };
@@ -669,18 +681,7 @@ int nolzss_factorize_device(const void *d_text, size_t n, size_t start_pos, int 
         if (emit == 2 && !out_host) throw std::invalid_argument("emit = 2 needs out_host");
         check_text_args(d_text, n, start_pos);
         Session ses(device, stream);
-        if (!stream) {
-            // The library's own stream is non-blocking: order it behind the work already queued on the
-            // legacy default stream (where torch's default stream and plain hipMemcpyAsync(.., 0) producers
-            // of d_text run).  Producers on other non-blocking streams must be synchronised by the caller
-            // or pass their stream.
-            hipEvent_t ev = nullptr;
-            HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-            hipError_t e = hipEventRecord(ev, nullptr);
-            if (e == hipSuccess) e = hipStreamWaitEvent(ses.ctx().stream, ev, 0);
-            (void)hipEventDestroy(ev);
-            HIP_CHECK(e);
-        }
+        if (!stream) order_behind_default_stream(ses.ctx());
         reserve_arena_for(ses.ctx(), n);
         *z = run_plain(ses.ctx(), static_cast<const uint8_t *>(d_text), n, start_pos,
                        emit == 2 ? out_host : nullptr, nullptr, emit == 1);
@@ -744,28 +745,39 @@ int nolzss_count_factors_multiple_dna_w_rc(const uint8_t *S, size_t S_len, size_
 }
 
 // noLZSS::factorize_dna_w_rc: one sequence; the prepared string is built on the device so that only
-// the n input bytes cross PCIe
-static void dna_w_rc_common(const uint8_t *text, size_t n, int device, nolzss_factor **out, size_t *z,
-                            int lane = 0) {
+// the n input bytes cross PCIe.  `d_resident` (optional) is the text already in device memory: nothing is
+// uploaded then and `text` is not read.
+// emit 0: count; 1: records built in HBM and left there; 2: records downloaded into *out.
+static void dna_w_rc_common(const uint8_t *text, const uint8_t *d_resident, size_t n, int device, void *stream, int emit,
+                            nolzss_factor **out, size_t *z, int lane = 0) {
     *z = 0;
     if (out) *out = nullptr;
     if (n == 0) return;  // factorizer_core.hpp:143
-    if (!text) throw std::invalid_argument("text pointer is null");
+    if (!text && !d_resident) throw std::invalid_argument("text pointer is null");
     const size_t m = 2 * n + 2;
     if (m > kMaxText) throw std::invalid_argument("text too long: the device pipeline uses 32-bit indices");
     if (!rc_guards(m, 0)) return;
-    Session ses(device, nullptr, lane);
+    Session ses(device, stream, lane);
     Context &ctx = ses.ctx();
-    reserve_arena_for(ctx, m, m + n);
-    uint8_t *d_T = ctx.arena.alloc<uint8_t>(n);
+    if (d_resident && !stream) order_behind_default_stream(ctx);
+    reserve_arena_for(ctx, m, m + (d_resident ? 0 : n));
+    const uint8_t *d_T = d_resident;
+    if (!d_resident) {
+        uint8_t *up = ctx.arena.alloc<uint8_t>(n);
+        upload_bytes(ctx, up, text, n);
+        d_T = up;
+    }
     uint8_t *d_S = ctx.arena.alloc<uint8_t>(m);
-    upload_bytes(ctx, d_T, text, n);
     const uint32_t bad = prepare_single_rc_on_device(ctx, d_T, (uint32_t)n, d_S);
-    if (bad != 0xffffffffu)  // factorizer.cpp:86-95
-        throw std::runtime_error("Invalid nucleotide '" + std::string(1, (char)text[bad]) + "' found in sequence 0");
+    if (bad != 0xffffffffu) {  // factorizer.cpp:86-95
+        uint8_t c = 0;
+        if (text) c = text[bad];
+        else HIP_CHECK(hipMemcpy(&c, d_T + bad, 1, hipMemcpyDeviceToHost));
+        throw std::runtime_error("Invalid nucleotide '" + std::string(1, (char)c) + "' found in sequence 0");
+    }
     void *d_recs = nullptr;
-    const size_t count = run_rc_pipeline(ctx, d_S, m, 0, out ? &d_recs : nullptr);
-    if (out && count) {
+    const size_t count = run_rc_pipeline(ctx, d_S, m, 0, emit ? &d_recs : nullptr);
+    if (emit == 2 && count) {
         nolzss_factor *h = static_cast<nolzss_factor *>(alloc_factor_block(sizeof(nolzss_factor) * count));
         if (!h) throw std::bad_alloc();
         try {
@@ -791,14 +803,25 @@ static void dna_w_rc_common(const uint8_t *text, size_t n, int device, nolzss_fa
 int nolzss_factorize_dna_w_rc(const uint8_t *text, size_t n, int device, nolzss_factor **out, size_t *z) {
     return guarded([&] {
         if (!out || !z) throw std::invalid_argument("output pointer is null");
-        dna_w_rc_common(text, n, device, out, z);
+        dna_w_rc_common(text, nullptr, n, device, nullptr, 2, out, z);
     });
 }
 
 int nolzss_count_factors_dna_w_rc(const uint8_t *text, size_t n, int device, size_t *z) {
     return guarded([&] {
         if (!z) throw std::invalid_argument("output pointer is null");
-        dna_w_rc_common(text, n, device, nullptr, z);
+        dna_w_rc_common(text, nullptr, n, device, nullptr, 0, nullptr, z);
+    });
+}
+
+int nolzss_factorize_dna_w_rc_device(const void *d_text, size_t n, int device, void *stream, int emit,
+                                     nolzss_factor **out_host, size_t *z) {
+    return guarded([&] {
+        if (!z) throw std::invalid_argument("output pointer is null");
+        if (emit < 0 || emit > 2) throw std::invalid_argument("emit must be 0, 1 or 2");
+        if (emit == 2 && !out_host) throw std::invalid_argument("emit = 2 needs out_host");
+        if (n && !d_text) throw std::invalid_argument("text pointer is null");
+        dna_w_rc_common(nullptr, static_cast<const uint8_t *>(d_text), n, device, stream, emit, out_host, z);
     });
 }
 
@@ -911,7 +934,7 @@ int nolzss_write_factors_binary_file_dna_w_rc(const char *in_path, const char *o
         const FileBytes data = read_file(in_path);
         nolzss_factor *f = nullptr;
         size_t count = 0;
-        dna_w_rc_common(data.data(), data.size(), device, &f, &count);
+        dna_w_rc_common(data.data(), nullptr, data.size(), device, nullptr, 2, &f, &count);
         std::unique_ptr<nolzss_factor, decltype(&std::free)> hold(f, &std::free);
         // one empty sequence name, num_sequences = 1 (factorizer.cpp:621-629)
         write_v2_file(out_path, f, count, 1, 0, data.size(), std::string(1, '\0'));
@@ -1960,7 +1983,7 @@ void factorize_many(const uint8_t *const *texts, const size_t *lens, size_t m, c
                 if (k >= plan[d].size()) break;
                 const size_t j = plan[d][k];
                 if (with_rc)
-                    dna_w_rc_common(texts[j], lens[j], devices[d], fs ? &fs[j] : nullptr, &zs[j], (int)lane);
+                    dna_w_rc_common(texts[j], nullptr, lens[j], devices[d], nullptr, fs ? 2 : 0, fs ? &fs[j] : nullptr, &zs[j], (int)lane);
                 else
                     zs[j] = run_plain_host(ses->ctx(), texts[j], lens[j], 0, fs ? &fs[j] : nullptr, nullptr);
                 ++g_single_records;

@@ -135,10 +135,11 @@ def shard_nucleotide_fasta(filepath: Union[str, Path], want_factors: bool = Fals
     import torch
     import torch.distributed as dist
 
-    world = dist.get_world_size() if dist.is_initialized() else 1
-    rank = dist.get_rank() if dist.is_initialized() else 0
+    grouped = dist.is_initialized()  # (a process group of one rank still takes the collective path)
+    world = dist.get_world_size() if grouped else 1
+    rank = dist.get_rank() if grouped else 0
     ids, _, counts_mine, owners, arrays = _factorize_file_records(filepath, None, want_factors, rank, world)
-    if world > 1:
+    if grouped:
         use_cuda = dist.get_backend() == "nccl"
         dev = torch.device("cuda", torch.cuda.current_device()) if use_cuda else torch.device("cpu")
         mine_vec = torch.tensor(counts_mine, dtype=torch.int64, device=dev)  # zero for records of other ranks

@@ -1,4 +1,8 @@
+import os
+import shutil
+import subprocess
 import sys
+import tempfile
 from pathlib import Path
 
 import pytest
@@ -11,3 +15,68 @@ for p in (str(ROOT), str(ROOT / "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "fullsize_oracle(mode): needs the oracle's result for a BASELINE configuration "
+                                       "at full size; the child process is started when the session begins")
+
+
+class _FullsizeOracles:
+    """The oracle at the full size of BASELINE configs 3 and 5 takes minutes on one core: one child process
+    per configuration (tests/fullsize_oracle.py) is started as soon as the selected tests are known and works
+    while the rest of the suite runs; the tests that need a result wait for it."""
+
+    def __init__(self):
+        self.dir = None
+        self.children = {}
+
+    def start(self, modes):
+        base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+        self.dir = Path(tempfile.mkdtemp(prefix="nolzss_fullsize_", dir=base))
+        for mode in sorted(modes):
+            out = self.dir / mode
+            out.mkdir()
+            log = open(out / "log.txt", "wb")
+            self.children[mode] = subprocess.Popen(
+                [sys.executable, str(ROOT / "tests" / "fullsize_oracle.py"), mode, str(out)],
+                stdout=log, stderr=subprocess.STDOUT, cwd=str(ROOT))
+
+    def result(self, mode, timeout_s):
+        import numpy as np
+        child = self.children[mode]
+        out = self.dir / mode
+        try:
+            child.wait(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            child.kill()
+            pytest.fail(f"the oracle child for '{mode}' did not finish within {timeout_s} s")
+        if not (out / "done").exists():
+            reason = (out / "error").read_text() if (out / "error").exists() else (out / "log.txt").read_text()
+            pytest.fail(f"the oracle child for '{mode}' failed (exit {child.returncode}): {reason[-2000:]}")
+        return {k: np.load(out / f"{k}.npy") for k in ("start", "length", "ref")}, (out / "done").read_text().strip()
+
+    def stop(self):
+        for child in self.children.values():
+            if child.poll() is None:
+                child.kill()
+                child.wait()
+        if self.dir is not None:
+            shutil.rmtree(self.dir, ignore_errors=True)
+
+
+_oracles = _FullsizeOracles()
+
+
+def pytest_collection_finish(session):
+    if session.config.option.collectonly:
+        return
+    modes = {m.args[0] for item in session.items for m in item.iter_markers("fullsize_oracle")}
+    if modes:
+        _oracles.start(modes)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    _oracles.stop()
+
+
+@pytest.fixture
+def oracle_children():
+    return _oracles

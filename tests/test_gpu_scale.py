@@ -1,6 +1,6 @@
 """GPU parity at the BASELINE.json sizes: exact against the oracle where the oracle finishes in
-seconds (config 2, FASTA records, a 4 Mi RC case), size-independent properties at full size
-(config 3: 2^30 bases; config 5: 2^28 bases + RC strand)."""
+seconds (config 2, FASTA records, a 4 Mi RC case), size-independent properties at the maximum sizes.
+Configs 3 and 5 at their full size, every factor against the oracle: tests/test_zz_gpu_fullsize_exact.py."""
 import numpy as np
 import pytest
 
@@ -56,25 +56,6 @@ def test_config2_random_64Mi_exact(native):
     for k in ("start", "length", "ref"):
         assert np.array_equal(got[k], exp[k]), k
     assert native.count_factors(text) == len(exp)
-
-
-@pytest.mark.timeout(1200)
-def test_config3_repeat_1Gi_properties_and_prefix_exact(native):
-    """BASELINE config 3: 2^30 bases, 40 % copied blocks.  Tiling + sampled true-match checks on
-    the full result; the factors that end inside the first 2^24 bases are compared one by one with
-    the oracle run on that prefix (a greedy parse of a prefix is a prefix of the parse)."""
-    n = 1 << 30
-    text = gen.repeat_dna(n)
-    f = native.factorize_array(text)
-    _check_tiling(f, n)
-    _check_matches(text, f, 50_000, np.random.default_rng(1))
-    P = 1 << 24
-    exp = oracle.factors_array(text[:P])
-    cut = int(np.searchsorted(f["start"] + f["length"], P, side="right"))
-    assert cut > 500_000 and cut <= len(exp)
-    for k in ("start", "length", "ref"):
-        assert np.array_equal(f[k][:cut], exp[k][:cut]), k
-    assert native.count_factors(text) == len(f)
 
 
 @pytest.mark.timeout(900)
@@ -158,19 +139,6 @@ def test_rc_4Mi_exact(native):
     assert len(got) == len(exp)
     for k in ("start", "length", "ref"):
         assert np.array_equal(got[k], exp[k]), k
-
-
-@pytest.mark.timeout(1200)
-def test_config5_rc_256Mi_properties(native):
-    """BASELINE config 5 size: 2^28 bases + RC strand.  Tiling, sampled (reverse-complement)
-    true-match checks, and count == len."""
-    n = 1 << 28
-    text = gen.repeat_dna(n, seed=0x5EED0005)
-    f = native.factorize_dna_w_rc_array(text)
-    _check_tiling(f, n)
-    _check_matches(text, f, 50_000, np.random.default_rng(2), rc_mode=True)
-    assert (f["ref"] >> np.uint64(63)).any(), "no reverse-complement factor at all?"
-    assert native.count_factors_dna_w_rc(text) == len(f)
 
 
 def _fib(n):

@@ -1,0 +1,71 @@
+"""BASELINE configs 3 and 5 at their stated sizes, EVERY factor against the oracle.
+
+The oracle needs minutes for 2^30 bases on one core (SA-IS + Kasai + LCP-interval tree + the reference's
+walk), so tests/conftest.py starts one child process per configuration (tests/fullsize_oracle.py) when the
+session begins; this file sorts last, the children work while the rest of the GPU suite runs, and each test
+waits for its result.  What only exists at scale -- far queues at high ranks, the third radix pass of the
+permutation scatters, 16-bit window indices, look-back across 260 000 tiles -- is pinned here by the
+optimality and leftmost-reference of all 5.2 * 10^7 (plain) / 1.35 * 10^7 (reverse complement) records."""
+import numpy as np
+import pytest
+
+import fullsize_oracle
+from test_gpu_scale import _check_matches, _check_tiling
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def native():
+    from nolzss_amd import _noLZSS
+    assert _noLZSS.device_count() >= 1, "no MI355X visible"
+    return _noLZSS
+
+
+def _assert_equal(got, exp, what):
+    assert len(got) == len(exp["start"]), (what, len(got), len(exp["start"]))
+    for k in ("start", "length", "ref"):
+        if not np.array_equal(got[k], exp[k]):
+            bad = int(np.flatnonzero(got[k] != exp[k])[0])
+            lo = max(0, bad - 2)
+            pytest.fail(f"{what}: first difference in '{k}' at factor {bad}: got "
+                        f"{[tuple(int(x) for x in r) for r in got[lo:bad + 3]]}, oracle "
+                        f"{list(zip(*(exp[c][lo:bad + 3].tolist() for c in ('start', 'length', 'ref'))))}")
+
+
+@pytest.mark.timeout(2400)
+@pytest.mark.fullsize_oracle("plain")
+def test_config3_repeat_1Gi_every_factor(native, oracle_children):
+    """BASELINE config 3: 2^30 bases, 40 % copied blocks: tiling, sampled true-match checks, count == len,
+    and all records equal to the oracle's."""
+    n = 1 << 30
+    text = fullsize_oracle.text_of("plain")
+    assert len(text) == n
+    f = native.factorize_array(text)
+    _check_tiling(f, n)
+    _check_matches(text, f, 50_000, np.random.default_rng(1))
+    assert native.count_factors(text) == len(f)
+    del text
+    exp, note = oracle_children.result("plain", timeout_s=2000)
+    _assert_equal(f, exp, f"config 3 ({note})")
+    assert len(f) > 40_000_000
+
+
+@pytest.mark.timeout(2400)
+@pytest.mark.fullsize_oracle("rc")
+def test_config5_rc_256Mi_every_factor(native, oracle_children):
+    """BASELINE config 5 size: 2^28 bases + reverse-complement strand: tiling, sampled (reverse-complement)
+    true-match checks, count == len, and all records (with the RC flag in `ref`) equal to the oracle's."""
+    n = 1 << 28
+    text = fullsize_oracle.text_of("rc")
+    assert len(text) == n
+    f = native.factorize_dna_w_rc_array(text)
+    _check_tiling(f, n)
+    _check_matches(text, f, 50_000, np.random.default_rng(2), rc_mode=True)
+    assert (f["ref"] >> np.uint64(63)).any(), "no reverse-complement factor at all?"
+    assert native.count_factors_dna_w_rc(text) == len(f)
+    del text
+    exp, note = oracle_children.result("rc", timeout_s=2000)
+    _assert_equal(f, exp, f"config 5 ({note})")
+    assert len(f) > 10_000_000
+
