@@ -5,10 +5,12 @@ import fails loudly, and if no MI355X is visible every compute call raises (the 
 returns NOLZSS_ERR_DEVICE).  Nothing in this package computes factors on the CPU.
 """
 import ctypes as C
+import os
 from pathlib import Path
 
 _PKG = Path(__file__).resolve().parent
-LIB_PATH = _PKG / "libnolzss_hip.so"
+# NOLZSS_LIB: another build of the same library (A/B measurements of compile-time variants, tools/ab_variant.sh)
+LIB_PATH = Path(os.environ["NOLZSS_LIB"]).resolve() if os.environ.get("NOLZSS_LIB") else _PKG / "libnolzss_hip.so"
 
 OK, ERR_INVALID_ARGUMENT, ERR_RUNTIME, ERR_NOMEM, ERR_DEVICE, ERR_IO, ERR_UNSUPPORTED = range(7)
 

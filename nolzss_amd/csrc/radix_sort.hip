@@ -31,18 +31,16 @@
 namespace nolzss {
 namespace {
 
-constexpr int kThreads = 256;
+constexpr int kKeysPerThread = 16;  // 12 and 8 measured within 3 % of this on MI355X
+constexpr int kTile = kSortTile;    // part of the SegView contract
+constexpr int kThreads = kTile / kKeysPerThread;  // 256 (4096-pair tiles) or 512 (8192)
 constexpr int kWaves = kThreads / 64;
-#ifndef NOLZSS_KPT
-#define NOLZSS_KPT 16
-#endif
-constexpr int kKeysPerThread = NOLZSS_KPT;  // 12 and 8 measured within 3 % of this on MI355X
-constexpr int kTile = kThreads * kKeysPerThread;  // 4096
-static_assert(kTile == kSortTile, "tile size is part of the SegView contract");
 constexpr int kBins = 1 << kRadixBits;
 constexpr int kWaveSpan = 64 * kKeysPerThread;  // 1024 keys per wavefront, 16 rows of 64
+// blocks per CU the scatter kernel is compiled for: 3 x 256 or 2 x 512 threads (128 VGPRs at most for the latter)
+constexpr int kScatterWavesPerSimd = kThreads == 256 ? 1 : 4;  // (1 = no register cap: the 256-thread form as it always was)
 
-static_assert(kBins == kThreads, "one thread per bin in the offset phase");
+static_assert(kThreads % kBins == 0, "the first kBins threads own one bin each in the offset phase");
 
 // 8-bit digit of a key at a bit offset that is a multiple of 8: the digit never straddles the two
 // halves of a 64-bit key, so one v_bfe_u32 on the right half does it (a variable 64-bit shift costs
@@ -165,8 +163,7 @@ __global__ __launch_bounds__(kThreads) void rs_hist_kernel(Src src, size_t n, in
     // LDS atomic to the same few addresses, which the LDS executes one after the other
     constexpr int kCopies = 4;
     __shared__ __align__(16) uint32_t hist[kBins * kCopies];
-#pragma unroll
-    for (int c = 0; c < kCopies; ++c) hist[c * kBins + threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < kBins * kCopies; i += kThreads) hist[i] = 0;
     // XCD-contiguous tile ranges, as in the scatter kernel: the table is bin-major, so the 256 counts of a
     // tile go to 256 different lines, each shared with the 15 neighbouring tiles -- written from one XCD
     // those 4-byte writes merge in its L2; dealt round-robin over the XCDs every one of them reached HBM
@@ -201,18 +198,21 @@ __global__ __launch_bounds__(kThreads) void rs_hist_kernel(Src src, size_t n, in
         }
     }
     __syncthreads();
-    const uint4 c4 = reinterpret_cast<const uint4 *>(hist)[threadIdx.x];
-    tile_hist[ext.hist0 + (size_t)threadIdx.x * ext.hstride] = c4.x + c4.y + c4.z + c4.w;
+    if (threadIdx.x < kBins) {
+        const uint4 c4 = reinterpret_cast<const uint4 *>(hist)[threadIdx.x];
+        tile_hist[ext.hist0 + (size_t)threadIdx.x * ext.hstride] = c4.x + c4.y + c4.z + c4.w;
+    }
 }
 
 template <typename KeyT, typename OutT, typename Src>
-__global__ __launch_bounds__(kThreads) void rs_scatter_kernel(
+__global__ __launch_bounds__(kThreads, kScatterWavesPerSimd) void rs_scatter_kernel(
     Src src, OutT *__restrict__ keys_out, uint32_t *__restrict__ vals_out, size_t n, int shift,
     const uint32_t *__restrict__ tile_base, uint32_t num_tiles, SegView seg) {
     const uint32_t tile = xcd_tile(blockIdx.x, num_tiles);
     if (tile == 0xffffffffu) return;
     const TileExtent ext = tile_extent(tile, n, num_tiles, seg);
-    __shared__ uint64_t s_stage[kTile];  // keys, then values, take turns here
+    // keys, then values, take turns here
+    __shared__ __align__(16) unsigned char s_stage[(size_t)kTile * (sizeof(KeyT) > 4 ? sizeof(KeyT) : 4)];
     KeyT *s_keys = reinterpret_cast<KeyT *>(s_stage);
     uint32_t *s_vals = reinterpret_cast<uint32_t *>(s_stage);
     __shared__ uint32_t s_whist[kWaves * kBins];
@@ -223,8 +223,7 @@ __global__ __launch_bounds__(kThreads) void rs_scatter_kernel(
     const int w = tid >> 6;
     const int lane = tid & 63;
 
-#pragma unroll
-    for (int k = 0; k < kWaves; ++k) s_whist[k * kBins + tid] = 0;
+    for (int i = tid; i < kWaves * kBins; i += kThreads) s_whist[i] = 0;
     __syncthreads();
 
     const size_t base = ext.first;
@@ -295,24 +294,27 @@ __global__ __launch_bounds__(kThreads) void rs_scatter_kernel(
     }
     __syncthreads();
 
-    // thread = bin: turn per-wave counts into tile-local start positions
+    // thread = bin (the first kBins threads): turn per-wave counts into tile-local start positions
     {
         const int d = tid;
+        const bool owner = tid < kBins;
         uint32_t c[kWaves], total = 0;
 #pragma unroll
         for (int k = 0; k < kWaves; ++k) {
-            c[k] = s_whist[k * kBins + d];
+            c[k] = owner ? s_whist[k * kBins + d] : 0u;
             total += c[k];
         }
         uint32_t tile_total;
         const uint32_t bin_start = block_scan_exclusive<kWaves>(total, OpAdd<uint32_t>(), s_scan, tile_total);
-        uint32_t run = bin_start;
+        if (owner) {
+            uint32_t run = bin_start;
 #pragma unroll
-        for (int k = 0; k < kWaves; ++k) {
-            s_whist[k * kBins + d] = run;
-            run += c[k];
+            for (int k = 0; k < kWaves; ++k) {
+                s_whist[k * kBins + d] = run;
+                run += c[k];
+            }
+            s_glob[d] = tile_base[ext.hist0 + (size_t)d * ext.hstride] - bin_start;
         }
-        s_glob[d] = tile_base[ext.hist0 + (size_t)d * ext.hstride] - bin_start;
     }
     __syncthreads();
 
@@ -376,6 +378,10 @@ void radix_pass(Src src, OutT *keys_out, uint32_t *vals_out, size_t n, int shift
                                                    : (small ? "rs_scatter.u32.small" : "rs_scatter.u32"))
                               : "rs_scatter.text";
         ProfScope ps(prof, cls, stream, scatter_bytes);
+        // (Round 3, NOLZSS_SORT_TILE=8192: tiles of 8192 pairs on 512 threads -- bin runs of a full 128-byte line.  The
+        // kernel needs 134 VGPRs and two such workgroups per CU allow 128: 14 registers spilled (72 in the text
+        // pass); u32 passes 3857 -> 3017 GB/s, text pass 1811 -> 1314, histograms + scans 10.8 -> 9.0 ms per step,
+        // step 118.7 -> 129.3 ms, profiles/r03_ab_tile8k.txt.  4096 stays.)
         // (Round 2 tried 512 threads with 8 keys each -- 75 instead of 139 VGPRs, 24 instead of 12 wavefronts
         // per CU -- and separate LDS buffers for keys and values: the u32 passes stayed at 3.9 TB/s at 2^30
         // pairs either way.  The pass is bound by its scattered 64-byte write runs, not by latency hiding.)

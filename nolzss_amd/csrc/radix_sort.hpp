@@ -8,7 +8,13 @@
 namespace nolzss {
 
 constexpr int kRadixBits = 8;
-constexpr int kSortTile = 4096;  // elements per tile of the radix kernels (and of the regroup kernel)
+// elements per tile of the radix kernels: 16 per thread, 256 or 512 threads.  8192 doubles the length of the 256
+// bin runs a tile writes (32 elements = one full 128-byte line per array on average instead of half a line).
+#ifndef NOLZSS_SORT_TILE
+#define NOLZSS_SORT_TILE 4096
+#endif
+constexpr int kSortTile = NOLZSS_SORT_TILE;
+static_assert(kSortTile == 4096 || kSortTile == 8192, "16 keys per thread on 256 or 512 threads");
 
 // A sorted-by-bucket view of an array for SEGMENTED passes: 256 buckets (the values of a leading
 // digit that an earlier pass partitioned by), each cut into tiles that never straddle a bucket.

@@ -422,8 +422,23 @@ __global__ __launch_bounds__(kFuseThreads) void regroup_kernel(RegroupArgs A) {
     if (timed) clk[1] = __builtin_readcyclecounter();
     const uint32_t tile = s_tile;
     const uint32_t m = A.m;
-    static_assert(kFuseTile == kSortTile, "the regroup tiles are the tiles of the segmented sort");
-    const TileExtent ext = tile_extent(tile, m, A.num_tiles, A.seg);
+    // the regroup tiles are the tiles of the segmented sort, or kSubTiles equal pieces of each (a piece behind
+    // the end of a partial sort tile is empty)
+    static_assert(kSortTile % kFuseTile == 0, "a sort tile is a whole number of regroup tiles");
+    constexpr uint32_t kSubTiles = kSortTile / kFuseTile;
+    TileExtent ext;
+    if (A.seg.desc == nullptr) {
+        ext = tile_extent(0, m, 1, A.seg);
+        ext.first = (size_t)tile * kFuseTile;
+        ext.count = (uint32_t)((m - ext.first < (size_t)kFuseTile) ? (m - ext.first) : (size_t)kFuseTile);
+    } else {
+        ext = tile_extent(tile / kSubTiles, m, A.num_tiles / kSubTiles, A.seg);
+        const uint32_t off = (tile % kSubTiles) * (uint32_t)kFuseTile;
+        const uint32_t skip = off < ext.count ? off : ext.count;
+        ext.first += skip;
+        ext.count -= skip;
+        ext.count = ext.count < (uint32_t)kFuseTile ? ext.count : (uint32_t)kFuseTile;
+    }
     const size_t tile_base = ext.first;
     const int lane = lane_id();
     const int w = threadIdx.x >> 6;
@@ -1616,7 +1631,7 @@ uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *grp, const 
     const size_t pmark = ctx.arena.mark();
     // doubling boundaries read range minima of the LCP values decided so far
     const Pyramid Plcp = plcp ? *plcp : Pyramid{};
-    const size_t tiles = seg ? seg->num_tiles : div_up(m, kFuseTile);
+    const size_t tiles = seg ? (size_t)seg->num_tiles * (kSortTile / kFuseTile) : div_up(m, kFuseTile);
     uint32_t total[2] = {0, 0};
     {
         const double bytes = kRound0 ? 20.0 * m : 28.0 * m;  // view (+ vals) in, (sa +) rank + lcp out (+ survivors)
