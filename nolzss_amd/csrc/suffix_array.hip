@@ -19,6 +19,7 @@
 // appended terminator does.
 #include "pipeline.hpp"
 #include "pyramid.hpp"
+#include "queues.hpp"
 #include "radix_sort.hpp"
 #include "scan.hpp"
 
@@ -1583,6 +1584,8 @@ __global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(
     }
 }
 
+#include "group_sort.hpp"
+
 __global__ __launch_bounds__(kThreads) void gather_large_kernel(const uint32_t *__restrict__ large_flag,
                                                                 const uint32_t *__restrict__ idx,
                                                                 const uint32_t *__restrict__ act_grp,
@@ -2099,6 +2102,76 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
             if (depth != 0xffffffffu && depth > h) h = depth;
         }
         if (trace) fprintf(stderr, "[nolzss]   direct round (cap %u symbols): %u still tied, on at least %llu symbols\n", cap, m, (unsigned long long)h);
+    }
+
+    // ---- second direct round: what little is left is sorted group by group, by the text (group_sort.hpp) ----
+    // (NOLZSS_NO_DIRECT2: A/B switch; NOLZSS_DIRECT2_MAX: largest share of the text, 1 / this, that takes it --
+    // a text with more ties than that is repetitive, and the passes below are made for those)
+    static const bool no_direct2 = getenv("NOLZSS_NO_DIRECT2") != nullptr;
+    static const uint32_t direct2_div = getenv("NOLZSS_DIRECT2_MAX") ? (uint32_t)atoi(getenv("NOLZSS_DIRECT2_MAX")) : 64u;
+    if (!no_direct2 && m > 0 && h < n && !independent && direct2_div > 0 && m <= n / direct2_div + 1024u) {
+        const uint32_t *slot = act_slot[a_cur], *grp = act_grp[a_cur];
+        const size_t d2_mark = arena.mark();
+        uint32_t *out_lo = arena.alloc<uint32_t>(m);
+        uint32_t *lcp_list = arena.alloc<uint32_t>(m);
+        uint32_t *d_min_depth = arena.alloc<uint32_t>(1);
+        HIP_CHECK(hipMemsetAsync(d_min_depth, 0xff, sizeof(uint32_t), s));
+        const unsigned dir_blocks = (unsigned)div_up(m, kThreads);
+        ShardQueue q_mid0, q_mid, q_big;
+        q_mid0.cap = q_mid.cap = q_big.cap = (uint32_t)shard_queue_cap(dir_blocks, kThreads);
+        uint32_t *qcounts = arena.alloc<uint32_t>(3 * kQShards * kQPad);
+        ShardQueue *queues[3] = {&q_mid0, &q_mid, &q_big};
+        for (int k = 0; k < 3; ++k) {
+            queues[k]->items = arena.alloc<uint32_t>((size_t)kQShards * q_big.cap);
+            queues[k]->items2 = arena.alloc<uint32_t>((size_t)kQShards * q_big.cap);
+            queues[k]->counts = qcounts + (size_t)k * kQShards * kQPad;
+        }
+        HIP_CHECK(hipMemsetAsync(qcounts, 0, 3 * kQShards * kQPad * sizeof(uint32_t), s));
+        {
+            ProfScope ps(ctx.profiler(), "sa_direct_sort2", s);
+            group_dir_kernel<<<dir_blocks, kThreads, 0, s>>>(slot, grp, m, (uint32_t)h, out_lo, lcp_list, q_mid0, q_mid, q_big, d_min_depth);
+            KERNEL_CHECK();
+            // small groups by tiles of the list; the larger ones from the queues (the consumers read the shard
+            // counts on the device: no read-back in between)
+            constexpr int kSmallN = 2 * (int)kGroupSortSmall, kMid0N = (int)kGroupSortMid0, kMidN = (int)kGroupSortMid,
+                          kBigN = (int)kGroupSortMax;
+            const unsigned tiles = (unsigned)div_up(m, kGroupSortSmall);
+            const unsigned ym = (unsigned)std::min<size_t>(64, std::max<size_t>(1, div_up(m, (size_t)kQShards * 64)));
+            const unsigned yb = (unsigned)std::min<size_t>(16, std::max<size_t>(1, div_up(m, (size_t)kQShards * 256)));
+            const uint32_t h32 = (uint32_t)h;
+#define NOLZSS_GROUP_SORT(B)                                                                                                \
+    group_sort_kernel<B, 64, kSmallN, true><<<tiles, 64, 0, s>>>(q_mid, slot, grp, m, sa, text.words, text.terms, h32,    \
+                                                                  out_lo, lcp_list, d_min_depth);                           \
+    group_sort_kernel<B, 64, kMid0N, false><<<dim3(kQShards, ym), 64, 0, s>>>(q_mid0, slot, grp, m, sa, text.words,        \
+                                                                              text.terms, h32, out_lo, lcp_list,           \
+                                                                              d_min_depth);                                \
+    group_sort_kernel<B, 64, kMidN, false><<<dim3(kQShards, ym), 64, 0, s>>>(q_mid, slot, grp, m, sa, text.words,          \
+                                                                             text.terms, h32, out_lo, lcp_list,            \
+                                                                             d_min_depth);                                 \
+    group_sort_kernel<B, 256, kBigN, false><<<dim3(kQShards, yb), 256, 0, s>>>(q_big, slot, grp, m, sa, text.words,        \
+                                                                               text.terms, h32, out_lo, lcp_list,          \
+                                                                               d_min_depth)
+            switch (text.bits) {
+            case 2: NOLZSS_GROUP_SORT(2); break;
+            case 4: NOLZSS_GROUP_SORT(4); break;
+            default: NOLZSS_GROUP_SORT(8); break;
+            }
+#undef NOLZSS_GROUP_SORT
+            KERNEL_CHECK();
+        }
+        const uint32_t before = m;
+        m = regroup<false>(ctx, nullptr, grp, out_lo, nullptr, slot, m, n, sa, rank, act_slot[a_cur ^ 1],
+                           act_grp[a_cur ^ 1], nullptr, nullptr, nullptr, d_total, lcp,
+                           0, 0, 0, lcp_list, 0, (uint32_t)h, rank_by_slot, nullptr, nullptr, nullptr, 0u,
+                           /*sa_is_current=*/true);
+        a_cur ^= 1;
+        if (m > 0) {
+            uint32_t depth = 0;
+            ctx.read_back(d_min_depth, &depth, 1);
+            if (depth != 0xffffffffu && depth > h) h = depth;
+        }
+        arena.rewind(d2_mark);
+        if (trace) fprintf(stderr, "[nolzss]   second direct round: %u of %u finished, %u still tied, on at least %llu symbols\n", before - m, before, m, (unsigned long long)h);
     }
     write_all_ranks();
 
