@@ -266,7 +266,8 @@ size_t run_plain(Context &ctx, const uint8_t *d_text, size_t n, size_t start_pos
     uint32_t *sa = arena.alloc<uint32_t>(n);
     uint32_t *isa = arena.alloc<uint32_t>(n);
     uint32_t *lcp = arena.alloc<uint32_t>(n + 1);
-    build_suffix_array(ctx, text, sa, isa, lcp);
+    bool isa_deferred = false;
+    build_suffix_array(ctx, text, sa, isa, lcp, &isa_deferred);
     Pyramid Psa, Plcp;
     {
         ProfScope ps(ctx.profiler(), "pyramids", s);
@@ -274,7 +275,7 @@ size_t run_plain(Context &ctx, const uint8_t *d_text, size_t n, size_t start_pos
         Plcp = build_lcp_pyramid(ctx, text, sa, lcp);
     }
     uint32_t *lstar = arena.alloc<uint32_t>(n);
-    build_lstar(ctx, (uint32_t)n, sa, isa, lcp, Psa, Plcp, lstar);
+    build_lstar(ctx, (uint32_t)n, sa, isa, lcp, Psa, Plcp, lstar, isa_deferred ? isa : nullptr);
     if (dbg) {
         copy_out(ctx, dbg->sa, sa, n);
         copy_out(ctx, dbg->isa, isa, n);  // (1-based on the device; nolzss_debug_arrays subtracts the one)

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(kThreads) void lpnf_fallback_kernel(ShardQueue exac
 }  // namespace
 
 uint32_t build_lstar(Context &ctx, uint32_t n, const uint32_t *sa, const uint32_t *isa, const uint32_t *lcp,
-                     const Pyramid &Psa, const Pyramid &Plcp, uint32_t *lstar) {
+                     const Pyramid &Psa, const Pyramid &Plcp, uint32_t *lstar, uint32_t *isa_fill) {
     hipStream_t s = ctx.stream;
     const size_t mark = ctx.arena.mark();
     const unsigned tiles = (unsigned)div_up(n, kLdsTile);
@@ -218,7 +218,7 @@ uint32_t build_lstar(Context &ctx, uint32_t n, const uint32_t *sa, const uint32_
     uint32_t *by_rank = ctx.arena.alloc<uint32_t>(n);
     uint32_t *far_aux = ctx.arena.alloc<uint32_t>(n);
     uint32_t *scratch_idx = ctx.arena.alloc<uint32_t>(n);
-    uint32_t *scratch_val = ctx.arena.alloc<uint32_t>(n);
+    uint32_t *scratch_val = ctx.arena.alloc<uint32_t>(isa_fill ? 2 * (size_t)n : (size_t)n);  // (two values per pair: radix_sort.hpp)
     HIP_CHECK(hipMemsetAsync(qcounts, 0, 2 * kQShards * kQPad * sizeof(uint32_t), s));
     const uint32_t *h_ptrs[2] = {exact_q.counts, far_q.counts};
     HIP_CHECK(hipMemcpyAsync(count_ptrs, h_ptrs, sizeof h_ptrs, hipMemcpyHostToDevice, s));
@@ -251,11 +251,12 @@ uint32_t build_lstar(Context &ctx, uint32_t n, const uint32_t *sa, const uint32_
         }
     }
     {
-        // lstar[sa[r]] = by_rank[r]: rank order -> text order (a permutation scatter)
+        // lstar[sa[r]] = by_rank[r]: rank order -> text order (a permutation scatter); with isa_fill the same
+        // permutation writes isa[sa[r]] = r + 1
         ProfScope ps(ctx.profiler(), "lpf_to_text_order", s);
         uint32_t *idx[2] = {const_cast<uint32_t *>(sa), scratch_idx};
         uint32_t *val[2] = {by_rank, scratch_val};
-        bucketed_scatter(idx, val, n, lstar, n, ctx.arena, s, ctx.profiler(), true, true, ctx.rec_plan);
+        bucketed_scatter(idx, val, n, lstar, n, ctx.arena, s, ctx.profiler(), true, true, ctx.rec_plan, isa_fill);
     }
     uint32_t h[2] = {0, 0};
     read_totals(h);

@@ -41,7 +41,12 @@ bool pack_independent_text(Context &ctx, const uint8_t *d_text, size_t n, const 
 // lcp[0] = 0, lcp[r] = lcp(suffix sa[r-1], suffix sa[r]), lcp[n] = 0 (n + 1 u32).  All
 // caller-allocated.  LCP entries between suffixes that round 0 already separates come straight
 // from the sort keys; only the others compare packed text.  Returns the doubling rounds run.
-int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint32_t *isa, uint32_t *lcp);
+// isa_deferred (optional): the caller can do without isa[] until the factor-length codes have been brought into
+// text order -- if the direct rounds finish the suffix array (no doubling round needs rank[]), isa[] is then NOT
+// written here and *isa_deferred = true: the caller hands isa to the permutation of the codes, which delivers it
+// as a second value (build_lstar's isa_fill; radix_sort.hpp, bucketed_scatter with out2).
+int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint32_t *isa, uint32_t *lcp,
+                       bool *isa_deferred = nullptr);
 // The range-minimum pyramid over lcp[0..n]; checks on the way that the construction left no boundary
 // undecided (and compares those suffixes in the text if it did).
 Pyramid build_lcp_pyramid(Context &ctx, const PackedText &text, const uint32_t *sa, uint32_t *lcp);
@@ -50,8 +55,9 @@ struct Pyramid;
 
 // ---- stage 4: per-position factor length codes (lpnf.hip) ---------------------------------
 // lstar[i] = L*[i] (0 = literal).  Returns the number of positions that needed the exact search.
+// isa_fill (optional): isa[] has not been written yet (build_suffix_array, isa_deferred): it is filled here.
 uint32_t build_lstar(Context &ctx, uint32_t n, const uint32_t *sa, const uint32_t *isa, const uint32_t *lcp,
-                     const Pyramid &Psa, const Pyramid &Plcp, uint32_t *lstar);
+                     const Pyramid &Psa, const Pyramid &Plcp, uint32_t *lstar, uint32_t *isa_fill = nullptr);
 
 // ---- stage 5: greedy cursor + factor records (chain.hip) ------------------------------------
 uint32_t resolve_chain(Context &ctx, uint32_t n, uint32_t start_pos, const uint32_t *lstar, const uint32_t *sa,

@@ -89,6 +89,33 @@ template <typename KeyT> struct ArraySrc {
     __device__ __forceinline__ bool digits_from_window(int) const { return false; }
     __device__ __forceinline__ uint64_t window(size_t) const { return 0; }
 };
+// (target position, value) pairs in list order that carry a SECOND value: the list position itself + 1 (the rank
+// of the suffix in the pipeline's 1-based convention).  The two values travel as ONE 64-bit value (first value in
+// the low half): two output streams per pass, the value stream in runs of a full 128-byte line, where three
+// streams of 4-byte values ran at 2.8 TB/s.  The permutation that brings the factor-length codes into text order
+// delivers the inverse suffix array on the way (bucketed_scatter with out2).
+struct RankSrc {
+    using Raw = uint32_t;
+    const uint32_t *__restrict__ keys;
+    const uint32_t *__restrict__ vals;
+    __device__ __forceinline__ Raw load(size_t idx, const TileExtent &) const { return keys[idx]; }
+    __device__ __forceinline__ uint32_t key_of(Raw raw, size_t, const TileExtent &) const { return raw; }
+    __device__ __forceinline__ uint32_t hist_digit_of(Raw raw, size_t, int shift, const TileExtent &) const { return digit_of(raw, shift); }
+    __device__ __forceinline__ uint64_t val(size_t idx) const { return (uint64_t)vals[idx] | ((uint64_t)((uint32_t)idx + 1u) << 32); }
+    __device__ __forceinline__ bool digits_from_window(int) const { return false; }
+    __device__ __forceinline__ uint64_t window(size_t) const { return 0; }
+};
+struct PairSrc {
+    using Raw = uint32_t;
+    const uint32_t *__restrict__ keys;
+    const uint64_t *__restrict__ vals;
+    __device__ __forceinline__ Raw load(size_t idx, const TileExtent &) const { return keys[idx]; }
+    __device__ __forceinline__ uint32_t key_of(Raw raw, size_t, const TileExtent &) const { return raw; }
+    __device__ __forceinline__ uint32_t hist_digit_of(Raw raw, size_t, int shift, const TileExtent &) const { return digit_of(raw, shift); }
+    __device__ __forceinline__ uint64_t val(size_t idx) const { return vals[idx]; }
+    __device__ __forceinline__ bool digits_from_window(int) const { return false; }
+    __device__ __forceinline__ uint64_t window(size_t) const { return 0; }
+};
 template <int BITS> struct TextSrc {
     using Raw = SymWords;
     const uint64_t *__restrict__ words;
@@ -204,17 +231,17 @@ __global__ __launch_bounds__(kThreads) void rs_hist_kernel(Src src, size_t n, in
     }
 }
 
-template <typename KeyT, typename OutT, typename Src>
+template <typename KeyT, typename OutT, typename Src, typename ValT = uint32_t>
 __global__ __launch_bounds__(kThreads, kScatterWavesPerSimd) void rs_scatter_kernel(
-    Src src, OutT *__restrict__ keys_out, uint32_t *__restrict__ vals_out, size_t n, int shift,
+    Src src, OutT *__restrict__ keys_out, ValT *__restrict__ vals_out, size_t n, int shift,
     const uint32_t *__restrict__ tile_base, uint32_t num_tiles, SegView seg) {
     const uint32_t tile = xcd_tile(blockIdx.x, num_tiles);
     if (tile == 0xffffffffu) return;
     const TileExtent ext = tile_extent(tile, n, num_tiles, seg);
     // keys, then values, take turns here
-    __shared__ __align__(16) unsigned char s_stage[(size_t)kTile * (sizeof(KeyT) > 4 ? sizeof(KeyT) : 4)];
+    __shared__ __align__(16) unsigned char s_stage[(size_t)kTile * (sizeof(KeyT) > sizeof(ValT) ? sizeof(KeyT) : sizeof(ValT))];
     KeyT *s_keys = reinterpret_cast<KeyT *>(s_stage);
-    uint32_t *s_vals = reinterpret_cast<uint32_t *>(s_stage);
+    ValT *s_vals = reinterpret_cast<ValT *>(s_stage);
     __shared__ uint32_t s_whist[kWaves * kBins];
     __shared__ uint32_t s_glob[kBins];
     __shared__ uint32_t s_scan[kWaves];
@@ -228,7 +255,7 @@ __global__ __launch_bounds__(kThreads, kScatterWavesPerSimd) void rs_scatter_ker
 
     const size_t base = ext.first;
     KeyT key[kKeysPerThread];
-    uint32_t val[kKeysPerThread];
+    ValT val[kKeysPerThread];
     uint32_t lrank[kKeysPerThread];
 
     // all loads of the tile go out before anything is ranked (the ranking below goes through
@@ -356,8 +383,8 @@ __global__ __launch_bounds__(kThreads, kScatterWavesPerSimd) void rs_scatter_ker
 }
 
 // one pass: histogram, scan, scatter
-template <typename KeyT, typename OutT, typename Src>
-void radix_pass(Src src, OutT *keys_out, uint32_t *vals_out, size_t n, int shift, uint32_t *hist, uint32_t num_tiles,
+template <typename KeyT, typename OutT, typename Src, typename ValT = uint32_t>
+void radix_pass(Src src, OutT *keys_out, ValT *vals_out, size_t n, int shift, uint32_t *hist, uint32_t num_tiles,
                 double hist_bytes, double scatter_bytes, Arena &arena, hipStream_t stream, Profiler *prof,
                 const SegView &seg = SegView{}) {
     {
@@ -373,7 +400,8 @@ void radix_pass(Src src, OutT *keys_out, uint32_t *vals_out, size_t n, int shift
         // classes of launches, so that the bandwidth of the large passes can be told from the many
         // small sorts of the doubling rounds: rs_scatter.{text|u64|u32}[.small]
         const bool small = n < (size_t(1) << 24);
-        const char *cls = (std::is_same<Src, ArraySrc<KeyT>>::value || std::is_same<Src, LocalIdxSrc>::value)
+        const char *cls = (std::is_same<Src, ArraySrc<KeyT>>::value || std::is_same<Src, LocalIdxSrc>::value ||
+                           std::is_same<Src, RankSrc>::value || std::is_same<Src, PairSrc>::value)
                               ? (sizeof(KeyT) == 8 ? (small ? "rs_scatter.u64.small" : "rs_scatter.u64")
                                                    : (small ? "rs_scatter.u32.small" : "rs_scatter.u32"))
                               : "rs_scatter.text";
@@ -386,8 +414,8 @@ void radix_pass(Src src, OutT *keys_out, uint32_t *vals_out, size_t n, int shift
         // per CU -- and separate LDS buffers for keys and values: the u32 passes stayed at 3.9 TB/s at 2^30
         // pairs either way.  The pass is bound by its scattered 64-byte write runs, not by latency hiding.)
         const uint32_t grid = xcd_grid(num_tiles);
-        rs_scatter_kernel<KeyT, OutT, Src><<<grid, kThreads, 0, stream>>>(src, keys_out, vals_out, n, shift, hist,
-                                                                          num_tiles, seg);
+        rs_scatter_kernel<KeyT, OutT, Src, ValT><<<grid, kThreads, 0, stream>>>(src, keys_out, vals_out, n, shift, hist,
+                                                                                num_tiles, seg);
         KERNEL_CHECK();
     }
 }
@@ -432,6 +460,16 @@ __global__ __launch_bounds__(kThreads) void plain_scatter_kernel(const uint32_t 
     }
 }
 
+// out2[idx[k]] = k + 1 (small inputs: the second value of bucketed_scatter's out2 form, written directly)
+__global__ __launch_bounds__(kThreads) void plain_rank_scatter_kernel(const uint32_t *__restrict__ idx, size_t count,
+                                                                      uint32_t *__restrict__ out2, uint32_t n_out) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < count; k += stride) {
+        const uint32_t i = idx[k];
+        if (i < n_out) out2[i] = (uint32_t)k + 1u;
+    }
+}
+
 constexpr int kWindowBitsMax = 14;  // 2^14 entries = 64 KiB of LDS
 
 // permutation scatter, final step: the pairs of window w sit at list positions [w*W, (w+1)*W)
@@ -465,6 +503,46 @@ __global__ __launch_bounds__(kThreads) void window_scatter_kernel(const IdxT *__
     }
     __syncthreads();
     for (uint32_t t = threadIdx.x; t < len; t += kThreads) out[base + t] = s_out[t];
+}
+
+// the same for pairs that carry two values in one 64-bit word (low half -> out, high half -> out2): both windows
+// are assembled side by side in 128 KiB of LDS by one workgroup of 1024 threads per CU
+constexpr int kWindow2Threads = 1024;
+__global__ __launch_bounds__(kWindow2Threads) void window_scatter2_kernel(const uint16_t *__restrict__ idx,
+                                                                          const uint64_t *__restrict__ val,
+                                                                          uint32_t *__restrict__ out,
+                                                                          uint32_t *__restrict__ out2, uint32_t n_out,
+                                                                          int window_bits) {
+    __shared__ uint32_t s_out[2 << kWindowBitsMax];
+    const uint32_t W = 1u << window_bits;
+    uint32_t *s_a = s_out, *s_b = s_out + W;
+    const size_t base = (size_t)blockIdx.x << window_bits;
+    const uint32_t len = (uint32_t)((n_out - base < (size_t)W) ? (n_out - base) : (size_t)W);
+    constexpr int kBatch = 4;
+    for (uint32_t t0 = 0; t0 < len; t0 += kBatch * kWindow2Threads) {
+        uint32_t ii[kBatch];
+        uint64_t vv[kBatch];
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            const uint32_t t = t0 + (uint32_t)j * kWindow2Threads + threadIdx.x;
+            const size_t at = base + (t < len ? t : 0u);  // (no branch around the loads)
+            ii[j] = (uint32_t)idx[at];
+            vv[j] = val[at];
+        }
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            const uint32_t t = t0 + (uint32_t)j * kWindow2Threads + threadIdx.x;
+            if (t < len) {
+                s_a[ii[j] & (W - 1u)] = (uint32_t)vv[j];
+                s_b[ii[j] & (W - 1u)] = (uint32_t)(vv[j] >> 32);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < len; t += kWindow2Threads) {
+        out[base + t] = s_a[t];
+        out2[base + t] = s_b[t];
+    }
 }
 
 // the same for the windows of a RecordScatterPlan: window b = list elements [win[3b], +win[3b+2]) -> target
@@ -608,9 +686,50 @@ bool record_scatter_plan(const std::vector<uint32_t> &h_terms, uint32_t n, Arena
 
 void bucketed_scatter(uint32_t *idx[2], uint32_t *val[2], size_t count, uint32_t *out, uint32_t n_out,
                       Arena &arena, hipStream_t stream, Profiler *prof, bool keep_input, bool keep_val,
-                      const RecordScatterPlan *plan) {
+                      const RecordScatterPlan *plan, uint32_t *out2) {
     if (count == 0) return;
     const size_t amark = arena.mark();
+    {
+        int nb = 1;
+        while (nb < 32 && (1ull << nb) < (uint64_t)n_out) ++nb;
+        const bool big_perm = (size_t)n_out * 4 > (size_t(64) << 20) && count > (size_t(1) << 22) && count == n_out &&
+                              nb <= 2 * kRadixBits + kWindowBitsMax && !(plan && plan->seg.desc);
+        if (out2 && big_perm) {
+            // The permutation with TWO values per pair: out[idx[k]] = val[k] and out2[idx[k]] = k + 1.  The list
+            // position is generated by the first pass and travels along as a second value: 20 + 22 + 18 bytes
+            // per pair where two permutations of their own take 2 * (16 + 14 + 10) -- and, above all, the second
+            // one no longer has to exist before the first (suffix_array.hip: rank[] is not written at all when
+            // the direct rounds finish the suffix array).  The two values travel as one 64-bit word (RankSrc).
+            const int wb = nb > 2 * kRadixBits + 10 ? nb - 2 * kRadixBits : 10;
+            const uint32_t num_tiles = (uint32_t)div_up(count, kTile);
+            uint32_t *hist = arena.alloc<uint32_t>((size_t)kBins * num_tiles);
+            uint32_t *idx_b = keep_input ? arena.alloc<uint32_t>(count) : idx[0];
+            uint64_t *packed1 = reinterpret_cast<uint64_t *>(val[1]);  // (val[1] holds 2 * count words in this form)
+            uint64_t *packed2 = arena.alloc<uint64_t>(count);
+            radix_pass<uint32_t, uint32_t, RankSrc, uint64_t>(RankSrc{idx[0], val[0]}, idx[1], packed1, count, wb, hist,
+                                                              num_tiles, 4.0 * (double)count, 20.0 * (double)count, arena,
+                                                              stream, prof);
+            uint16_t *idx16 = reinterpret_cast<uint16_t *>(idx_b);
+            radix_pass<uint32_t, uint16_t, PairSrc, uint64_t>(PairSrc{idx[1], packed1}, idx16, packed2, count,
+                                                              wb + kRadixBits, hist, num_tiles, 4.0 * (double)count,
+                                                              22.0 * (double)count, arena, stream, prof);
+            {
+                ProfScope ps(prof, "window_scatter", stream, 18.0 * (double)count);
+                const uint32_t W = 1u << wb;
+                window_scatter2_kernel<<<(unsigned)div_up(n_out, W), kWindow2Threads, 0, stream>>>(idx16, packed2, out, out2,
+                                                                                                 n_out, wb);
+                KERNEL_CHECK();
+            }
+            arena.rewind(amark);
+            return;
+        }
+        if (out2) {  // small inputs and the other shapes: the second value by a scatter of its own
+            ProfScope ps(prof, "bucket_scatter", stream, 8.0 * (double)count);
+            const unsigned g = (unsigned)std::min<size_t>(div_up(count, kThreads), 256u * 16u);
+            plain_rank_scatter_kernel<<<g, kThreads, 0, stream>>>(idx[0], count, out2, n_out);
+            KERNEL_CHECK();
+        }
+    }
     if (plan && plan->seg.desc && count == n_out && n_out == plan->n) {
         // block-diagonal permutation: one pass by the window inside the record, then the windows
         uint16_t *idx16 = reinterpret_cast<uint16_t *>(idx[1]);

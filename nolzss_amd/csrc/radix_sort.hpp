@@ -129,9 +129,12 @@ struct RecordScatterPlan {
     uint32_t n = 0;
     int window_bits = 0;
 };
+// out2 (optional): a second target, out2[idx[k]] = k + 1 -- for the pairs (sa[r], code[r]) of the pipeline that is
+// the inverse suffix array in its 1-based form, delivered by the same permutation.  val[1] must then hold
+// 2 * count words (the pairs travel with 64-bit values).
 void bucketed_scatter(uint32_t *idx[2], uint32_t *val[2], size_t count, uint32_t *out, uint32_t n_out,
                       Arena &arena, hipStream_t stream, Profiler *prof, bool keep_input, bool keep_val = true,
-                      const RecordScatterPlan *plan = nullptr);
+                      const RecordScatterPlan *plan = nullptr, uint32_t *out2 = nullptr);
 // The plan for a text of n symbols whose records end at h_terms[k] (separator positions, the last entry = n);
 // false when the shape does not allow it (a record longer than 2^22 bases, or too many short ones).  The
 // tables live in the arena (not released here).

@@ -291,7 +291,8 @@ uint32_t run_rc_pipeline_packed(Context &ctx, const PackedText &text, size_t sta
     uint32_t *sa = arena.alloc<uint32_t>(m);
     uint32_t *isa = arena.alloc<uint32_t>(m);
     uint32_t *lcp = arena.alloc<uint32_t>((size_t)m + 1);
-    build_suffix_array(ctx, text, sa, isa, lcp);
+    bool isa_deferred = false;
+    build_suffix_array(ctx, text, sa, isa, lcp, &isa_deferred);
     Pyramid Pmin, Pmax, Plcp;
     {
         ProfScope ps(ctx.profiler(), "pyramids", s);
@@ -317,7 +318,7 @@ uint32_t run_rc_pipeline_packed(Context &ctx, const PackedText &text, size_t sta
         uint32_t *totals = arena.alloc<uint32_t>(2);  // [0] exact-search queue, [1] far queue
         uint32_t *by_rank = arena.alloc<uint32_t>(m);
         uint32_t *scratch_idx = arena.alloc<uint32_t>(m);
-        uint32_t *scratch_val = arena.alloc<uint32_t>(m);
+        uint32_t *scratch_val = arena.alloc<uint32_t>(isa_deferred ? 2 * (size_t)m : (size_t)m);  // (two values per pair: radix_sort.hpp)
         HIP_CHECK(hipMemsetAsync(qcounts, 0, 2 * kQShards * kQPad * sizeof(uint32_t), s));
         const uint32_t *h_ptrs[2] = {exact_q.counts, far_q.counts};
         HIP_CHECK(hipMemcpyAsync(count_ptrs, h_ptrs, sizeof h_ptrs, hipMemcpyHostToDevice, s));
@@ -336,7 +337,8 @@ uint32_t run_rc_pipeline_packed(Context &ctx, const PackedText &text, size_t sta
             ProfScope ps(ctx.profiler(), "rc_to_text_order", s);
             uint32_t *idx[2] = {sa, scratch_idx};
             uint32_t *val[2] = {by_rank, scratch_val};
-            bucketed_scatter(idx, val, m, code, m, arena, s, ctx.profiler(), true);
+            // (isa_deferred: the same permutation writes isa[sa[r]] = r + 1)
+            bucketed_scatter(idx, val, m, code, m, arena, s, ctx.profiler(), true, true, nullptr, isa_deferred ? isa : nullptr);
         }
         uint32_t h[2] = {0, 0};
         read_totals(h);

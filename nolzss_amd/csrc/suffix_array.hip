@@ -1868,7 +1868,9 @@ __global__ __launch_bounds__(kThreads) void lcp_finish_kernel(const uint64_t *__
     }
 }
 
-int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint32_t *isa, uint32_t *lcp) {
+int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint32_t *isa, uint32_t *lcp,
+                       bool *isa_deferred) {
+    if (isa_deferred) *isa_deferred = false;
     const uint32_t n = text.n;
     hipStream_t s = ctx.stream;
     Arena &arena = ctx.arena;
@@ -2172,6 +2174,21 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         }
         arena.rewind(d2_mark);
         if (trace) fprintf(stderr, "[nolzss]   second direct round: %u of %u finished, %u still tied, on at least %llu symbols\n", before - m, before, m, (unsigned long long)h);
+    }
+    // Nothing is tied any more: no round below needs rank[].  A caller that can wait gets it from the permutation
+    // that brings the factor-length codes into text order (pipeline.hpp) -- one full random permutation per
+    // factorization instead of two.  (Texts of more than 2^30 symbols keep the rank scatter: the two-value form of
+    // the permutation has two partition passes.  NOLZSS_NO_DEFER_ISA: A/B switch.)
+    static const bool no_defer = getenv("NOLZSS_NO_DEFER_ISA") != nullptr;
+    // (the two-value permutation takes 8 n bytes more than the one it replaces: 57 n at the peak of the
+    // candidate stage; an arena that settled for less keeps the rank scatter)
+    const bool room = arena.capacity() >= 60 * (size_t)n + (size_t(64) << 20);
+    if (m == 0 && isa_deferred && !no_defer && !independent && n <= (1u << 30) && room) {
+        *isa_deferred = true;
+        if (trace) fprintf(stderr, "[nolzss]   suffix array finished by the direct rounds: rank[] is left to the permutation of the codes\n");
+        HIP_CHECK(hipMemsetAsync(lcp + n, 0, sizeof(uint32_t), s));
+        arena.rewind(mark);
+        return 0;
     }
     write_all_ranks();
 
