@@ -374,7 +374,8 @@ struct RegroupArgs {
     uint32_t *rank_val;       // (when rank_by_slot == nullptr) new rank of the elements whose rank changes ...
     uint32_t *chg_idx;        // ... and their suffix starts, appended in any order; chg_count counts them
     uint32_t *chg_count;
-    uint32_t *rank_by_slot;   // rank per slot
+    uint32_t *rank_by_slot;   // non-null: the rounds before rank[] exists (no list of changed ranks is kept)
+    int store_ranks;          // ... and the rank of every slot is stored there
     uint32_t *lcp;
     int sym_bits, tag_bits, bits, low_bits;  // round 0 key layout
     int bits_shift;                          // log2(bits): a division by a run-time value costs ~20 instructions per item
@@ -635,7 +636,9 @@ __global__ __launch_bounds__(kFuseThreads) void regroup_kernel(RegroupArgs A) {
         if (!in) continue;
         // (round 0: the key sort left the suffixes in sa itself; direct round: group_refine_kernel did)
         if (!kRound0 && !A.sa_is_current) A.sa[slot[k]] = A.vals[a];
-        if (A.rank_by_slot) A.rank_by_slot[slot[k]] = head_of + 1u;  // rank[] itself is written later, in one pass
+        // (A.rank_by_slot != nullptr: rank[] is written later, in one pass -- or never: build_suffix_array, which then
+        // asks for no store here; should ranks be needed after all, they are recovered from the LCP array)
+        if (A.rank_by_slot && A.store_ranks) A.rank_by_slot[slot[k]] = head_of + 1u;
         if ((kmask[k] >> lane) & 1ull) {  // surviving elements keep their slot, learn their group head
             const uint32_t kk = xsum + s_seg_sum[k * kWaves + w] + (uint32_t)__popcll(kmask[k] & lt);
             A.new_slot[kk] = slot[k];
@@ -847,6 +850,14 @@ __global__ __launch_bounds__(kThreads) void compact_active_kernel(const uint32_t
         }
 }
 
+// out[q] = q + 1 where a group starts at slot q (its LCP entry is decided), else 0
+__global__ __launch_bounds__(kThreads) void head_flags_kernel(const uint32_t *__restrict__ lcp, uint32_t n,
+                                                              uint32_t *__restrict__ out) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += stride)
+        out[q] = lcp[q] < kLcpPendingMin ? (uint32_t)q + 1u : 0u;
+}
+
 // secondary key of a doubling round: rank of the suffix h symbols further on (0 past the end)
 __global__ __launch_bounds__(kThreads) void round_keys_kernel(const uint32_t *__restrict__ act_slot,
                                                               uint32_t m, const uint32_t *__restrict__ sa,
@@ -894,15 +905,42 @@ __device__ __forceinline__ void lower_min(uint32_t *p, uint32_t v) {
 constexpr uint32_t kPerNone = 0xffffffffu;   // gq: no distance seen yet
 constexpr uint32_t kPerBad = 0x80000000u;    // gq: flag "leave this group alone" (positions are below 2^31 here)
 
-// members of groups with more than `limit` members (the list is in slot order: a member's index inside its
-// group is slot - head): one atomic per workgroup
+// count[0] += members beyond the first `limit` of their group, count[1] += groups with more than `limit` members
+// (the list is in slot order: a member's index inside its group is slot - head): one atomic pair per workgroup
 __global__ __launch_bounds__(kThreads) void per_count_large_kernel(const uint32_t *__restrict__ act_slot,
                                                                    const uint32_t *__restrict__ act_grp, uint32_t m,
                                                                    uint32_t limit, uint32_t *__restrict__ count) {
+    uint32_t mine = 0, groups = 0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x; a < m; a += stride) {
+        const uint32_t j = act_slot[a] - act_grp[a];
+        mine += j >= limit ? 1u : 0u;
+        groups += j == limit ? 1u : 0u;
+    }
+    mine = wave_reduce(mine, OpAdd<uint32_t>());
+    groups = wave_reduce(groups, OpAdd<uint32_t>());
+    __shared__ uint32_t s_part[2][kThreads / 64];
+    if (lane_id() == 0) {
+        s_part[0][threadIdx.x >> 6] = mine;
+        s_part[1][threadIdx.x >> 6] = groups;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        uint32_t t = 0;
+        for (int i = 0; i < kThreads / 64; ++i) t += s_part[threadIdx.x][i];
+        if (t) atomicAdd(count + threadIdx.x, t);
+    }
+}
+
+// members of groups whose smallest distance between neighbours is at most `limit` (the candidates of the periodic
+// pass): one atomic per workgroup
+__global__ __launch_bounds__(kThreads) void per_candidates_kernel(const uint64_t *__restrict__ keys, uint32_t m,
+                                                                  const uint32_t *__restrict__ gq, uint32_t limit,
+                                                                  uint32_t *__restrict__ count) {
     uint32_t mine = 0;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x; a < m; a += stride)
-        mine += (act_slot[a] - act_grp[a] >= limit) ? 1u : 0u;
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride)
+        mine += gq[(uint32_t)(keys[j] >> 32)] <= limit ? 1u : 0u;
     mine = wave_reduce(mine, OpAdd<uint32_t>());
     __shared__ uint32_t s_part[kThreads / 64];
     if (lane_id() == 0) s_part[threadIdx.x >> 6] = mine;
@@ -1629,7 +1667,7 @@ uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *grp, const 
                  const uint32_t *lcp_list = nullptr, int low_bits = 0, uint32_t dbl_h = 0,
                  uint32_t *rank_by_slot = nullptr, const Pyramid *plcp = nullptr, const uint32_t *keys32 = nullptr,
                  const SegView *seg = nullptr, uint32_t short_tag = 0, bool sa_is_current = false,
-                 uint32_t seq_shift = 0) {
+                 uint32_t seq_shift = 0, bool store_ranks = true) {
     hipStream_t s = ctx.stream;
     const size_t pmark = ctx.arena.mark();
     // doubling boundaries read range minima of the LCP values decided so far
@@ -1647,7 +1685,7 @@ uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *grp, const 
         A.seq_shift = seq_shift;
         A.sa_is_current = sa_is_current ? 1 : 0;
         A.keys = keys; A.keys32 = keys32; A.seg = seg ? *seg : SegView{}; A.num_tiles = (uint32_t)tiles; A.grp = grp; A.lo = lo; A.vals = vals; A.act_slot = act_slot; A.m = m;
-        A.sa = sa; A.rank_val = rank_val; A.rank_by_slot = rank_by_slot; A.lcp = lcp;
+        A.sa = sa; A.rank_val = rank_val; A.rank_by_slot = rank_by_slot; A.store_ranks = store_ranks ? 1 : 0; A.lcp = lcp;
         A.chg_idx = scratch_idx; A.chg_count = d_total + 2;
         HIP_CHECK(hipMemsetAsync(d_total + 2, 0, sizeof(uint32_t), s));
         A.sym_bits = sym_bits; A.tag_bits = tag_bits; A.bits = bits; A.low_bits = low_bits;
@@ -1917,6 +1955,16 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         key_passes = (kb + kRadixBits - 1) / kRadixBits;
         if (key_passes > 8) key_passes = 8;
     }
+    // Can the caller be left without rank[] if the direct rounds finish the suffix array (see below)?  The regroup
+    // kernels then do not store the rank of every slot either (nobody would read it; if doubling rounds turn out
+    // to be needed, write_all_ranks recovers it from the LCP array).
+    // (the two-value permutation takes 8 n bytes more than the one it replaces: 57 n at the peak of the candidate
+    // stage; an arena that settled for less keeps the rank scatter.  Texts of more than 2^30 symbols keep it too:
+    // the two-value form has two partition passes.  NOLZSS_NO_DEFER_ISA: A/B switch.)
+    static const bool no_defer = getenv("NOLZSS_NO_DEFER_ISA") != nullptr;
+    const bool can_defer = isa_deferred && !no_defer && text.terms.seq_shift == 0 && n <= (1u << 30) &&
+                           arena.capacity() >= 60 * (size_t)n + (size_t(64) << 20);
+    const bool store_ranks = !can_defer;
     uint32_t *act_slot[2] = {arena.alloc<uint32_t>(n), arena.alloc<uint32_t>(n)};
     uint32_t *act_grp[2] = {arena.alloc<uint32_t>(n), arena.alloc<uint32_t>(n)};
     uint32_t *rank_by_slot = arena.alloc<uint32_t>(n);
@@ -2014,7 +2062,7 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
                                // (mirrored independent sequences have two terminators each: a short suffix
                                // can tie with its copy at the other one)
                                (dna_fast || (independent && text.terms.mirror)) ? (uint32_t)k_syms : 0u, false,
-                               rec_fast ? 32u : text.terms.seq_shift);
+                               rec_fast ? 32u : text.terms.seq_shift, store_ranks);
 
     arena.rewind(sort_mark);  // keys and the second value buffer are done
 
@@ -2036,6 +2084,14 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     auto write_all_ranks = [&] {
         ProfScope ps(ctx.profiler(), "sa_rank_scatter", s);
         const size_t smark = arena.mark();
+        // rank of a slot = slot of its group head + 1, and the heads are the slots whose LCP entry is decided: an
+        // inclusive max-scan (the regroup kernels no longer write this array: when the direct rounds finish the
+        // suffix array nobody reads it)
+        if (!store_ranks) {
+            head_flags_kernel<<<grid_for(n, kThreads), kThreads, 0, s>>>(lcp, n, rank_by_slot);
+            KERNEL_CHECK();
+            scan_inclusive_max_u32(rank_by_slot, rank_by_slot, n, arena, s);
+        }
         uint32_t *idx[2] = {sa, arena.alloc<uint32_t>(n)};
         uint32_t *val[2] = {rank_by_slot, arena.alloc<uint32_t>(n)};
         bucketed_scatter(idx, val, n, rank, n, arena, s, ctx.profiler(), true, /*keep_val=*/false, ctx.rec_plan);
@@ -2092,7 +2148,7 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         m = regroup<false>(ctx, nullptr, grp, out_lo, nullptr, slot, m, n, sa, rank, act_slot[a_cur ^ 1],
                            act_grp[a_cur ^ 1], nullptr, nullptr, nullptr, d_total, lcp,
                            0, 0, 0, lcp_list, 0, (uint32_t)h, rank_by_slot, nullptr, nullptr, nullptr, 0u,
-                           /*sa_is_current=*/true);
+                           /*sa_is_current=*/true, 0u, store_ranks);
         a_cur ^= 1;
         arena.rewind(direct_mark);
         // every group that is still tied agrees on at least min_depth symbols (K if a group was too large
@@ -2165,7 +2221,7 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         m = regroup<false>(ctx, nullptr, grp, out_lo, nullptr, slot, m, n, sa, rank, act_slot[a_cur ^ 1],
                            act_grp[a_cur ^ 1], nullptr, nullptr, nullptr, d_total, lcp,
                            0, 0, 0, lcp_list, 0, (uint32_t)h, rank_by_slot, nullptr, nullptr, nullptr, 0u,
-                           /*sa_is_current=*/true);
+                           /*sa_is_current=*/true, 0u, store_ranks);
         a_cur ^= 1;
         if (m > 0) {
             uint32_t depth = 0;
@@ -2177,13 +2233,8 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     }
     // Nothing is tied any more: no round below needs rank[].  A caller that can wait gets it from the permutation
     // that brings the factor-length codes into text order (pipeline.hpp) -- one full random permutation per
-    // factorization instead of two.  (Texts of more than 2^30 symbols keep the rank scatter: the two-value form of
-    // the permutation has two partition passes.  NOLZSS_NO_DEFER_ISA: A/B switch.)
-    static const bool no_defer = getenv("NOLZSS_NO_DEFER_ISA") != nullptr;
-    // (the two-value permutation takes 8 n bytes more than the one it replaces: 57 n at the peak of the
-    // candidate stage; an arena that settled for less keeps the rank scatter)
-    const bool room = arena.capacity() >= 60 * (size_t)n + (size_t(64) << 20);
-    if (m == 0 && isa_deferred && !no_defer && !independent && n <= (1u << 30) && room) {
+    // factorization instead of two.
+    if (m == 0 && can_defer) {
         *isa_deferred = true;
         if (trace) fprintf(stderr, "[nolzss]   suffix array finished by the direct rounds: rank[] is left to the permutation of the codes\n");
         HIP_CHECK(hipMemsetAsync(lcp + n, 0, sizeof(uint32_t), s));
@@ -2221,6 +2272,20 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     }
     uint32_t *rvals = rank_by_slot;  // free now that rank[] has been written
 
+    // how the tied suffixes are grouped decides which of the two passes can do anything: in_large = members beyond
+    // the first kRunGroupMax of their group, large_members = members of groups with more than kRunGroupMax members
+    uint32_t in_large = 0, large_members = 0;
+    uint32_t *d_large = arena.alloc<uint32_t>(2);
+    if (pair_runs) {
+        HIP_CHECK(hipMemsetAsync(d_large, 0, 2 * sizeof(uint32_t), s));
+        per_count_large_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(act_slot[a_cur], act_grp[a_cur], m, kRunGroupMax, d_large);
+        KERNEL_CHECK();
+        uint32_t h2[2] = {0, 0};
+        ctx.read_back(d_large, h2, 2);
+        in_large = h2[0];
+        large_members = h2[0] + kRunGroupMax * h2[1];
+    }
+
     // one range-minimum pyramid over the LCP values known so far; the regroup kernel keeps it current
     Pyramid Plcp{};
     const size_t pyr_mark = arena.mark();
@@ -2240,19 +2305,12 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         if (periodic_off || m == 0 || n >= 0x80000000u || wlen < n || per_attempts >= 3) return false;
         ProfScope ps(ctx.profiler(), "sa_periodic", s);
         const uint32_t *slot = act_slot[a_cur], *grp = act_grp[a_cur];
-        if (per_attempts == 0) {
+        if (per_attempts == 0 && in_large < m / 8) {
             // worth its two sorts only where large groups hold a good part of what is tied: copies of long
             // regions tie in groups of a few members (the pair-run pass takes those), runs of a short period
             // in groups as large as the runs are long
-            HIP_CHECK(hipMemsetAsync(d_total + 3, 0, sizeof(uint32_t), s));
-            per_count_large_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(slot, grp, m, kRunGroupMax, d_total + 3);
-            KERNEL_CHECK();
-            uint32_t in_large = 0;
-            ctx.read_back(d_total + 3, &in_large, 1);
-            if (in_large < m / 8) {
-                per_attempts = 3;  // (never again for this text)
-                return false;
-            }
+            per_attempts = 3;  // (never again for this text)
+            return false;
         }
         ++per_attempts;
         uint32_t *PQ = tmp_a, *rev = tmp_b, *end_of = tmp_c, *gq = lo, *kraw = rank_val;
@@ -2270,6 +2328,24 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         KERNEL_CHECK();
         const uint32_t depth = (uint32_t)std::min<uint64_t>(h, 0x7ffffffeu);
         const bool can_verify = text.terms.count == 1;  // (one segment: see per_verify_kernel)
+        {
+            // Large groups are not always periodic runs: two dozen copies of a genome tie in groups of two dozen
+            // members that lie a genome apart.  When next to nothing can be taken, the pass stops here, before
+            // its scans and its second sort (49 of 300 ms on 24 genomes of 2^28 bases in all).
+            const uint32_t qmax = std::max<uint32_t>(depth, (can_verify && depth < kPerVerifyMax) ? kPerVerifyMax : depth);
+            HIP_CHECK(hipMemsetAsync(d_large, 0, sizeof(uint32_t), s));
+            per_candidates_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(pk[c], m, gq, qmax, d_large);
+            KERNEL_CHECK();
+            uint32_t cand = 0;
+            ctx.read_back(d_large, &cand, 1);
+            if (cand < m / 16) {
+                arena.rewind(lmark);
+                per_attempts = 3;
+                if (trace) fprintf(stderr, "[nolzss]   periodic runs (depth %llu): %u of %u tied suffixes in groups that could be runs -- skipped\n",
+                                   (unsigned long long)h, cand, m);
+                return false;
+            }
+        }
         if (can_verify && depth < kPerVerifyMax) {  // longer periods than the depth: taken if the text confirms them
             const unsigned gv = grid_for(m, kThreads, 256u * 64u);
             switch (text.bits) {
@@ -2315,7 +2391,10 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     // groups without finishing them -- three copies, one of which differs behind the run -- is followed by
     // another one over the smaller groups.  NOLZSS_PAIR_RUNS_MIN: smallest number of tied suffixes for
     // which it runs, the tests set 1)
-    for (int pass = 0; pair_runs && pass < 10 && m > 0 && (pair_runs_min >= 0 ? (long long)m >= pair_runs_min : m >= n / 16); ++pass) {
+    // (the pass takes groups of up to kRunGroupMax members: where most of what is tied sits in larger groups -- 17
+    // and more copies of a genome -- its four sweeps over the text finish next to nothing: 120 of 300 ms on 24 genomes)
+    const bool runs_can_help = pair_runs_min >= 0 || large_members <= m / 2;
+    for (int pass = 0; pair_runs && runs_can_help && pass < 10 && m > 0 && (pair_runs_min >= 0 ? (long long)m >= pair_runs_min : m >= n / 16); ++pass) {
         ProfScope ps(ctx.profiler(), "sa_pair_runs", s);
         uint32_t *link = tmp_a, *gsz = rank_val, *rev = tmp_b, *end_of = tmp_c, *togo = scratch_idx;
         uint32_t *end_place = scratch_val, *end_lcp = lo;

@@ -41,7 +41,21 @@ cases = {
     "twelve genomes 0.1 % apart": np.concatenate([gen.random_dna(n // 12, 6)] + [mutated(gen.random_dna(n // 12, 6), 30 + k) for k in range(11)]),
     "random": gen.random_dna(n, 2),
 }
+# collections of similar genomes (the reference's reference / target and multi-FASTA entry points are made for them)
+for copies in (17, 24, 48, 96):
+    base = gen.random_dna(n // copies, 40 + copies)
+    cases[f"{copies} genomes 0.1 % apart"] = np.concatenate([base] + [mutated(base, 100 * copies + k) for k in range(copies - 1)])
+only = sys.argv[2].split(",") if len(sys.argv) > 2 else None
+if only:
+    cases = {k: v for k, v in cases.items() if any(o in k for o in only) or k == "random"}
 native.count_factors(cases["random"][:1 << 16])
 for name, t in cases.items():
     t0 = time.time(); z = native.count_factors(t); dt = time.time() - t0
     print(f"2^{lg} {name}: {dt*1e3:.1f} ms, z={z}", flush=True)
+# a reference and a target of n / 2 bases each, 0.1 % apart, through the reference-sequence entry point
+ref = gen.random_dna(n // 2, 77)
+tgt = mutated(ref, 78)
+t0 = time.time()
+f = native.factorize_dna_w_reference_seq(ref.tobytes().decode(), tgt.tobytes().decode()) if lg <= 24 else None
+if f is not None:
+    print(f"2^{lg} reference + target through factorize_dna_w_reference_seq (tuples): {(time.time()-t0)*1e3:.1f} ms, z={len(f)}", flush=True)
