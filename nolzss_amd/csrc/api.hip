@@ -2150,9 +2150,17 @@ int nolzss_factorize_batch_device(const void *const *d_texts, const size_t *lens
             std::vector<std::string> messages(workers);
             std::atomic<size_t> next{0};
             std::mutex mu;
+            // Two runs of the same size started together stay in step: both in their radix passes (HBM-bound), then
+            // both in the direct round (issue-bound), and gain nothing from each other -- or drift apart and overlap
+            // well: 512 records of 4 Mi bases took 144 or 170 ms, whichever way a call happened to fall.  The
+            // second lane therefore starts 20 ms late (NOLZSS_DEVICE_MERGE_STAGGER_MS; in bench.py: 145 / 162 / 164 ms
+            // without, 146 / 146 / 145 ms with it, profiles/r03_fasta512_stagger.txt).
+            static const long stagger_ms = getenv("NOLZSS_DEVICE_MERGE_STAGGER_MS") ? atol(getenv("NOLZSS_DEVICE_MERGE_STAGGER_MS")) : 20;
             auto worker = [&](size_t w) {
                 status[w] = guarded([&] {
                     Session ses(device, nullptr, (int)w);
+                    if (w > 0 && stagger_ms > 0 && chunks.size() > 1)
+                        std::this_thread::sleep_for(std::chrono::milliseconds(stagger_ms * (long)w));
                     for (;;) {
                         const size_t k = next.fetch_add(1);
                         if (k >= chunks.size()) break;
