@@ -1246,7 +1246,8 @@ template <int BITS, bool kTimed>
 __global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(kTimed ? 4 : 8, 8))) void group_refine_kernel(
     const uint32_t *__restrict__ act_slot, const uint32_t *__restrict__ act_grp, uint32_t *sa,
     const uint64_t *__restrict__ words, TermTable terms, uint32_t m, uint32_t h0, uint32_t cap,
-    uint32_t *__restrict__ out_lo, uint32_t *__restrict__ lcp_list, uint32_t *__restrict__ min_depth,
+    uint32_t *__restrict__ lcp, uint32_t *__restrict__ rank_by_slot, uint32_t *__restrict__ surv_slot,
+    uint32_t *__restrict__ surv_head, uint32_t *__restrict__ surv_count, uint32_t *__restrict__ min_depth,
     unsigned long long *__restrict__ phases, bool no_stragglers) {
     const bool timed = kTimed && phases != nullptr && (blockIdx.x & 31) == 0 && threadIdx.x == 0;
     unsigned long long ck0 = 0, ck_fetch = 0, ck_cmp = 0, ck_rounds = 0, ck1 = 0, ck2 = 0;
@@ -1280,6 +1281,7 @@ __global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(
     bool starts_here = false;
     uint32_t j = 0, my_head = 0;  // my index in the group, slot of the group's first member
     bool last = false;
+    bool stays = false;  // a member of a group this round leaves as it is, reported by this workgroup
     s_goff[t] = 0;  // doubles as the group size table until the pair offsets are written
     if (a < m) {
         const uint32_t g = act_grp[a];
@@ -1300,7 +1302,7 @@ __global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(
         const bool large = starts_here ? (sz == 0 || sz > kSmallGroup) : false;
         // too large for this round: stays one group, in place.  Its first kSmallGroup members are
         // written by the tile it starts in, the others by the tile that owns their list position.
-        if ((large && j < kSmallGroup) || (a < a1 && j >= kSmallGroup)) out_lo[a] = 0;  // (sa keeps its order)
+        stays = (large && j < kSmallGroup) || (a < a1 && j >= kSmallGroup);  // (sa keeps its order)
         // the symbols every group that stays tied is known to agree on: h0 for the groups this round does
         // not touch, the depth reached for the others (the doubling rounds start from the minimum)
         if (large && j == 0) lower_min(min_depth, h0);
@@ -1340,7 +1342,7 @@ __global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(
             gend = s_goff[my_gl] + (uint32_t)(my_gs * (my_gs - 1) / 2);
             handled = gend <= (uint32_t)kPairCap;
             if (handled && my_j == my_gs - 1) atomicMax(&s_npairs, gend);
-            if (!handled) out_lo[a] = 0;  // no room for its pairs: the group stays as it is
+            if (!handled) stays = true;  // no room for its pairs: the group stays as it is
             if (!handled && my_j == 0) lower_min(min_depth, h0);
         }
         __syncthreads();
@@ -1591,23 +1593,67 @@ __global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(
     const unsigned long long ck3 = timed ? __builtin_readcyclecounter() : 0;
     if (cnt > 0 && lane == 0) lower_min(min_depth, depth);
     // ---- members still tied keep their list order: count the tied partners in front of me --------
-    // (s_goff is free now)
+    // (s_goff is free now; s_tied[0] marks the members of pairs that are still tied)
     s_goff[t] = 0;
+    s_tied[0][t] = 0;
     __syncthreads();
     for (uint32_t c0 = 0; c0 < cnt; c0 += 64)
-        if (c0 + lane < cnt) atomicAdd(&s_goff[s_pair[seg0 + c0 + lane] & 0xffffu], 1u);
+        if (c0 + lane < cnt) {
+            const uint32_t item = s_pair[seg0 + c0 + lane];
+            atomicAdd(&s_goff[item & 0xffffu], 1u);
+            s_tied[0][item & 0xffffu] = 1;
+            s_tied[0][item >> 16] = 1;
+        }
+    // What used to be a pass of its own over the whole list (regroup_kernel: 4.9 ms at 2^30 bases) happens here:
+    // the LCP of every boundary that appeared goes straight to its slot, and the members that stay tied --
+    // a percent of the list on sequence data -- are collected IN SLOT ORDER: parked at their new position inside
+    // the workgroup's 256 list positions, compacted, and written to the workgroup's own region; a small kernel
+    // concatenates the regions (compact_survivors_kernel).  (The window buffer is free: it holds the parking lot.)
+    uint32_t *s_sv_slot = reinterpret_cast<uint32_t *>(&s_w[0][0]);
+    uint32_t *s_sv_head = s_sv_slot + kRefineThreads;
+    static_assert(sizeof(s_w) >= 2 * kRefineThreads * sizeof(uint32_t), "the parking lot fits the window buffer");
+    s_sv_slot[t] = 0xffffffffu;
     __syncthreads();
     if (handled) {
         const uint32_t cls = s_cls[t], ties_before = s_goff[t];
-        const size_t pos = a0 + my_gl + cls + ties_before;
-        out_lo[pos] = cls;
+        const uint32_t head = my_head + cls, slot = head + ties_before;
         // the new order goes straight into the suffix array: my group occupies the slots from my_head
         // on, in list order (only members of the group, all threads of this workgroup, ever read or
         // write those slots, and every read happened before the barriers above)
-        sa[my_head + cls + ties_before] = my_pos;
-        // LCP to the predecessor in the new order: the closest smaller member shares the
-        // longest prefix; a tied predecessor (then this is not a new head) stays pending
-        lcp_list[pos] = ties_before ? kLcpPending : s_best[t];
+        sa[slot] = my_pos;
+        // LCP to the predecessor in the new order: the closest smaller member shares the longest prefix
+        // (the first member of the group keeps the entry it has; a tied predecessor: no boundary, stays pending)
+        if (ties_before == 0 && cls > 0) lcp[slot] = s_best[t];
+        if (rank_by_slot) rank_by_slot[slot] = head + 1u;
+        if (s_tied[0][t]) {
+            const uint32_t nl = (uint32_t)my_gl + cls + ties_before;
+            s_sv_slot[nl] = slot;
+            s_sv_head[nl] = head;
+        }
+    } else if (stays) {
+        const uint32_t slot = my_head + j;
+        if (rank_by_slot) rank_by_slot[slot] = my_head + 1u;
+        s_sv_slot[t] = slot;
+        s_sv_head[t] = my_head;
+    }
+    __syncthreads();
+    {
+        const uint32_t sv = s_sv_slot[t], hd = s_sv_head[t];
+        const bool keep = sv != 0xffffffffu;
+        const uint64_t kb = __ballot(keep);
+        if (lane == 0) s_wtot[w] = (uint32_t)__popcll(kb);
+        __syncthreads();
+        uint32_t at = (uint32_t)__popcll(kb & lt), total = 0;
+#pragma unroll
+        for (int k = 0; k < kRefineWaves; ++k) {
+            if (k < w) at += s_wtot[k];
+            total += s_wtot[k];
+        }
+        if (keep) {
+            surv_slot[(size_t)blockIdx.x * kRefineThreads + at] = sv;
+            surv_head[(size_t)blockIdx.x * kRefineThreads + at] = hd;
+        }
+        if (t == 0) surv_count[blockIdx.x] = total;
     }
     if (timed) {
         __builtin_amdgcn_s_waitcnt(0);
@@ -1619,6 +1665,24 @@ __global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(
         atomicAdd(phases + 4, ck_rounds);
         atomicAdd(phases + 5, 1ull);
         atomicAdd(phases + 6, ck4 - ck0);
+    }
+}
+
+// the survivors of the direct round, region by region (one region of kRefineThreads entries per workgroup of
+// group_refine_kernel, `count` of them used), to the active list: four threads per region
+__global__ __launch_bounds__(kThreads) void compact_survivors_kernel(const uint32_t *__restrict__ surv_slot,
+                                                                     const uint32_t *__restrict__ surv_head,
+                                                                     const uint32_t *__restrict__ count,
+                                                                     const uint32_t *__restrict__ offset,
+                                                                     uint32_t regions, uint32_t *__restrict__ new_slot,
+                                                                     uint32_t *__restrict__ new_grp) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x / 4;
+    for (size_t r = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / 4; r < regions; r += stride) {
+        const uint32_t c = count[r], o = offset[r];
+        for (uint32_t k = threadIdx.x & 3u; k < c; k += 4) {
+            new_slot[o + k] = surv_slot[r * kRefineThreads + k];
+            new_grp[o + k] = surv_head[r * kRefineThreads + k];
+        }
     }
 }
 
@@ -2104,8 +2168,13 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     if (m > 0 && h < n) {
         const uint32_t *slot = act_slot[a_cur], *grp = act_grp[a_cur];
         const size_t direct_mark = arena.mark();
-        uint32_t *out_lo = arena.alloc<uint32_t>(m);
-        uint32_t *lcp_list = arena.alloc<uint32_t>(m);
+        // the members that stay tied come back in one region per workgroup (group_refine_kernel's epilogue)
+        const unsigned g = (unsigned)div_up(m, kRefineTile);
+        uint32_t *surv_slot = arena.alloc<uint32_t>((size_t)g * kRefineThreads);
+        uint32_t *surv_head = arena.alloc<uint32_t>((size_t)g * kRefineThreads);
+        uint32_t *surv_count = arena.alloc<uint32_t>(g);
+        uint32_t *surv_off = arena.alloc<uint32_t>(g);
+        uint32_t *rbs = store_ranks ? rank_by_slot : nullptr;
         // at most 32 words (1024 bases of DNA) deep; longer ties are cheaper in the doubling rounds
         static const uint32_t cap_words = getenv("NOLZSS_REFINE_WORDS") ? (uint32_t)atoi(getenv("NOLZSS_REFINE_WORDS")) : 32u;
         const uint32_t cap = (uint32_t)k_syms + cap_words * (64u / (uint32_t)text.bits);
@@ -2113,7 +2182,6 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         HIP_CHECK(hipMemsetAsync(d_min_depth, 0xff, sizeof(uint32_t), s));
         {
             ProfScope ps(ctx.profiler(), "sa_direct_sort", s);
-            const unsigned g = (unsigned)div_up(m, kRefineTile);
             static const bool want_rphases = getenv("NOLZSS_REFINE_PHASES") != nullptr;
             static const bool no_strag = getenv("NOLZSS_NO_STRAGGLERS") != nullptr;  // (A/B switch)
             unsigned long long *rphases = nullptr;
@@ -2123,16 +2191,16 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
             }
             switch (text.bits) {
             case 2:
-                if (rphases) group_refine_kernel<2, true><<<g, kRefineThreads, 0, s>>>(slot, grp, sa, text.words, text.terms, m, (uint32_t)h, cap, out_lo, lcp_list, d_min_depth, rphases, no_strag);
-                else group_refine_kernel<2, false><<<g, kRefineThreads, 0, s>>>(slot, grp, sa, text.words, text.terms, m, (uint32_t)h, cap, out_lo, lcp_list, d_min_depth, nullptr, no_strag);
+                if (rphases) group_refine_kernel<2, true><<<g, kRefineThreads, 0, s>>>(slot, grp, sa, text.words, text.terms, m, (uint32_t)h, cap, lcp, rbs, surv_slot, surv_head, surv_count, d_min_depth, rphases, no_strag);
+                else group_refine_kernel<2, false><<<g, kRefineThreads, 0, s>>>(slot, grp, sa, text.words, text.terms, m, (uint32_t)h, cap, lcp, rbs, surv_slot, surv_head, surv_count, d_min_depth, nullptr, no_strag);
                 break;
             case 4:
-                if (rphases) group_refine_kernel<4, true><<<g, kRefineThreads, 0, s>>>(slot, grp, sa, text.words, text.terms, m, (uint32_t)h, cap, out_lo, lcp_list, d_min_depth, rphases, no_strag);
-                else group_refine_kernel<4, false><<<g, kRefineThreads, 0, s>>>(slot, grp, sa, text.words, text.terms, m, (uint32_t)h, cap, out_lo, lcp_list, d_min_depth, nullptr, no_strag);
+                if (rphases) group_refine_kernel<4, true><<<g, kRefineThreads, 0, s>>>(slot, grp, sa, text.words, text.terms, m, (uint32_t)h, cap, lcp, rbs, surv_slot, surv_head, surv_count, d_min_depth, rphases, no_strag);
+                else group_refine_kernel<4, false><<<g, kRefineThreads, 0, s>>>(slot, grp, sa, text.words, text.terms, m, (uint32_t)h, cap, lcp, rbs, surv_slot, surv_head, surv_count, d_min_depth, nullptr, no_strag);
                 break;
             default:
-                if (rphases) group_refine_kernel<8, true><<<g, kRefineThreads, 0, s>>>(slot, grp, sa, text.words, text.terms, m, (uint32_t)h, cap, out_lo, lcp_list, d_min_depth, rphases, no_strag);
-                else group_refine_kernel<8, false><<<g, kRefineThreads, 0, s>>>(slot, grp, sa, text.words, text.terms, m, (uint32_t)h, cap, out_lo, lcp_list, d_min_depth, nullptr, no_strag);
+                if (rphases) group_refine_kernel<8, true><<<g, kRefineThreads, 0, s>>>(slot, grp, sa, text.words, text.terms, m, (uint32_t)h, cap, lcp, rbs, surv_slot, surv_head, surv_count, d_min_depth, rphases, no_strag);
+                else group_refine_kernel<8, false><<<g, kRefineThreads, 0, s>>>(slot, grp, sa, text.words, text.terms, m, (uint32_t)h, cap, lcp, rbs, surv_slot, surv_head, surv_count, d_min_depth, nullptr, no_strag);
                 break;
             }
             KERNEL_CHECK();
@@ -2145,10 +2213,15 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
                         hp[5], hp[0] / wn, hp[1] / wn, hp[2] / wn, hp[3] / wn, hp[6] / wn, hp[4] / wn);
             }
         }
-        m = regroup<false>(ctx, nullptr, grp, out_lo, nullptr, slot, m, n, sa, rank, act_slot[a_cur ^ 1],
-                           act_grp[a_cur ^ 1], nullptr, nullptr, nullptr, d_total, lcp,
-                           0, 0, 0, lcp_list, 0, (uint32_t)h, rank_by_slot, nullptr, nullptr, nullptr, 0u,
-                           /*sa_is_current=*/true, 0u, store_ranks);
+        {
+            // the next active list: the regions one after the other (they are in slot order already)
+            ProfScope ps(ctx.profiler(), "sa_regroup", s, 16.0 * (double)g);
+            scan_exclusive_add_u32(surv_count, surv_off, g, d_total, arena, s);
+            compact_survivors_kernel<<<grid_for((size_t)g * 4, kThreads), kThreads, 0, s>>>(
+                surv_slot, surv_head, surv_count, surv_off, g, act_slot[a_cur ^ 1], act_grp[a_cur ^ 1]);
+            KERNEL_CHECK();
+        }
+        ctx.read_back(d_total, &m, 1);
         a_cur ^= 1;
         arena.rewind(direct_mark);
         // every group that is still tied agrees on at least min_depth symbols (K if a group was too large
