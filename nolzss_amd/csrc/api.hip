@@ -268,14 +268,11 @@ size_t run_plain(Context &ctx, const uint8_t *d_text, size_t n, size_t start_pos
     uint32_t *lcp = arena.alloc<uint32_t>(n + 1);
     bool isa_deferred = false;
     build_suffix_array(ctx, text, sa, isa, lcp, &isa_deferred);
-    Pyramid Psa, Plcp;
-    {
-        ProfScope ps(ctx.profiler(), "pyramids", s);
-        Psa = build_pyramid(sa, (uint32_t)n, false, arena, s);
-        Plcp = build_lcp_pyramid(ctx, text, sa, lcp);
-    }
+    // (the pyramids are only allocated here: the candidate kernel writes their first level from the blocks it holds
+    // in LDS anyway, build_lstar fills the rest)
+    const Pyramid Psa = alloc_pyramid(sa, (uint32_t)n, arena), Plcp = alloc_pyramid(lcp, (uint32_t)n + 1, arena);
     uint32_t *lstar = arena.alloc<uint32_t>(n);
-    build_lstar(ctx, (uint32_t)n, sa, isa, lcp, Psa, Plcp, lstar, isa_deferred ? isa : nullptr);
+    build_lstar(ctx, (uint32_t)n, sa, isa, lcp, Psa, Plcp, lstar, isa_deferred ? isa : nullptr, &text);
     if (dbg) {
         copy_out(ctx, dbg->sa, sa, n);
         copy_out(ctx, dbg->isa, isa, n);  // (1-based on the device; nolzss_debug_arrays subtracts the one)

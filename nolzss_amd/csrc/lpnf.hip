@@ -72,7 +72,9 @@ __global__ __launch_bounds__(kLdsThreads) void lpf_tile_kernel(const uint32_t *_
                                                                uint32_t *__restrict__ lstar_by_rank,
                                                                ShardQueue exact_q, ShardQueue far_q,
                                                                uint32_t *__restrict__ far_aux,
-                                                               unsigned long long *__restrict__ phases) {
+                                                               unsigned long long *__restrict__ phases,
+                                                               uint32_t *__restrict__ psa1, uint32_t *__restrict__ plcp1,
+                                                               uint32_t pending_min, uint32_t *__restrict__ pending_flag) {
     constexpr int NS = 2;
     // (diagnostics, NOLZSS_LPF_PHASES: cycles per phase summed over the wavefronts of every 16th workgroup)
     const bool timed = kTimed && phases != nullptr && (blockIdx.x & 15) == 0;
@@ -86,11 +88,23 @@ __global__ __launch_bounds__(kLdsThreads) void lpf_tile_kernel(const uint32_t *_
     __shared__ uint32_t s_blk[3 * kNumBlk];
     const uint32_t base = blockIdx.x * (uint32_t)kLdsTile;
     const uint32_t shard = blockIdx.x % kQShards;
-    stage_tile(sa, lcp, n, base, s_sa, s_lcp);
+    stage_tile(sa, lcp, n, base, s_sa, s_lcp, pending_min, pending_flag);
     __syncthreads();
     const BlockTables T{s_blk, nullptr, s_blk + kNumBlk, s_blk + 2 * kNumBlk};
     build_block_tables<false>(s_sa, s_lcp, T);
     __syncthreads();
+    // The block tables of the tile's own ranks ARE the first level of the two pyramids the later stages query (min
+    // suffix start / min LCP of every aligned block of 16 ranks): written from here, the two streaming passes over SA
+    // and LCP that used to build that level are gone (pyramid.hpp, fill_pyramid from level 2; blocks that reach
+    // beyond rank n - 1 are left to fill_pyramid_tail).
+    if (psa1 != nullptr && threadIdx.x < kLdsTile / kBlk) {
+        const uint32_t B = (uint32_t)kLdsReach / kBlk + threadIdx.x;
+        const uint64_t first = (uint64_t)base + (uint64_t)threadIdx.x * kBlk;
+        if (first + kBlk <= (uint64_t)n) {
+            psa1[first >> 4] = T.mn[B];
+            plcp1[first >> 4] = T.ldn[B];
+        }
+    }
     if (timed) clk[1] = __builtin_readcyclecounter();
     const int w = threadIdx.x >> 6;
     const uint32_t far_bit = n <= 0x80000000u ? 0x80000000u : 0u;
@@ -202,9 +216,21 @@ __global__ __launch_bounds__(kThreads) void lpnf_fallback_kernel(ShardQueue exac
 }  // namespace
 
 uint32_t build_lstar(Context &ctx, uint32_t n, const uint32_t *sa, const uint32_t *isa, const uint32_t *lcp,
-                     const Pyramid &Psa, const Pyramid &Plcp, uint32_t *lstar, uint32_t *isa_fill) {
+                     const Pyramid &Psa, const Pyramid &Plcp, uint32_t *lstar, uint32_t *isa_fill,
+                     const PackedText *fill_pyramids) {
     hipStream_t s = ctx.stream;
     const size_t mark = ctx.arena.mark();
+    // fill_pyramids: Psa / Plcp are allocated but empty (alloc_pyramid): the tile kernel writes their first level,
+    // the upper levels are filled behind it, and the check for undecided LCP entries happens on the way
+    uint32_t *pending_flag = nullptr;
+    if (fill_pyramids) {
+        pending_flag = ctx.arena.alloc<uint32_t>(1);
+        HIP_CHECK(hipMemsetAsync(pending_flag, 0, sizeof(uint32_t), s));
+        inject_pending_for_test(ctx, const_cast<uint32_t *>(lcp), n);
+    }
+    uint32_t *psa1 = fill_pyramids && Psa.nlev > 1 ? const_cast<uint32_t *>(Psa.lvl[1]) : nullptr;
+    uint32_t *plcp1 = fill_pyramids && Plcp.nlev > 1 ? const_cast<uint32_t *>(Plcp.lvl[1]) : nullptr;
+    if (!psa1 || !plcp1) psa1 = plcp1 = nullptr;
     const unsigned tiles = (unsigned)div_up(n, kLdsTile);
     ShardQueue exact_q, far_q;
     exact_q.cap = far_q.cap = (uint32_t)shard_queue_cap(tiles, kLdsTile);
@@ -237,9 +263,11 @@ uint32_t build_lstar(Context &ctx, uint32_t n, const uint32_t *sa, const uint32_
             HIP_CHECK(hipMemsetAsync(phases, 0, 64, s));
         }
         if (phases)
-            lpf_tile_kernel<true><<<tiles, kLdsThreads, 0, s>>>(sa, lcp, n, by_rank, exact_q, far_q, far_aux, phases);
+            lpf_tile_kernel<true><<<tiles, kLdsThreads, 0, s>>>(sa, lcp, n, by_rank, exact_q, far_q, far_aux, phases, psa1, plcp1,
+                                                                pending_threshold(), pending_flag);
         else
-            lpf_tile_kernel<false><<<tiles, kLdsThreads, 0, s>>>(sa, lcp, n, by_rank, exact_q, far_q, far_aux, nullptr);
+            lpf_tile_kernel<false><<<tiles, kLdsThreads, 0, s>>>(sa, lcp, n, by_rank, exact_q, far_q, far_aux, nullptr, psa1,
+                                                                 plcp1, pending_threshold(), pending_flag);
         KERNEL_CHECK();
         if (phases) {
             unsigned long long h[8];
@@ -248,6 +276,29 @@ uint32_t build_lstar(Context &ctx, uint32_t n, const uint32_t *sa, const uint32_
             const double w = h[5] ? (double)h[5] : 1.0;
             fprintf(stderr, "[nolzss] lpf_tile phases (cycles per wavefront, %llu sampled): stage %.0f  round0 %.0f  %s %.0f  %s %.0f  epilogue %.0f\n",
                     h[5], h[0] / w, h[1] / w, "roundA", h[2] / w, "roundsBC", h[3] / w, h[4] / w);
+        }
+    }
+    if (fill_pyramids) {
+        ProfScope ps(ctx.profiler(), "pyramids", s);
+        if (psa1) {  // level 1 came from the tile kernel, but for the blocks that reach beyond the last rank
+            fill_pyramid_tail(Psa, n >> kPyrShift, false, s);
+            fill_pyramid_tail(Plcp, n >> kPyrShift, false, s);
+            fill_pyramid(Psa, 2, false, s);
+            fill_pyramid(Plcp, 2, false, s);
+        } else {  // (a text of fewer than 16 symbols)
+            fill_pyramid(Psa, 1, false, s);
+            fill_pyramid(Plcp, 1, false, s);
+        }
+        uint32_t pending = 0;
+        ctx.read_back(pending_flag, &pending, 1);
+        if (pending) {
+            // safety net (build_lcp_pyramid): an LCP entry nobody decided is compared in the text; the candidates are
+            // then computed again, the ordinary way
+            ctx.arena.rewind(mark);
+            finish_pending_lcp(ctx, *fill_pyramids, sa, const_cast<uint32_t *>(lcp));
+            fill_pyramid(Psa, 1, false, s);
+            fill_pyramid(Plcp, 1, false, s);
+            return build_lstar(ctx, n, sa, isa, lcp, Psa, Plcp, lstar, isa_fill, nullptr);
         }
     }
     {

@@ -63,8 +63,11 @@ struct OpMinU32 {
 };
 
 // stage SA[base - reach, base + tile + reach) and the matching LCP entries; out-of-range = 0
+// (flag, optional: *flag |= 1 if a staged LCP entry is >= flag_min, i.e. still a "pending" code of the suffix-array
+// construction -- the check build_lcp_pyramid makes on its first level, for callers that build that level here)
 __device__ __forceinline__ void stage_tile(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ lcp,
-                                           uint32_t n, uint32_t base, uint32_t *s_sa, uint32_t *s_lcp) {
+                                           uint32_t n, uint32_t base, uint32_t *s_sa, uint32_t *s_lcp,
+                                           uint32_t flag_min = 0, uint32_t *flag = nullptr) {
     const int64_t first = (int64_t)base - kLdsReach;
     // every load of the thread goes out before the first LDS store (one round trip to HBM per
     // workgroup instead of one per row)
@@ -79,12 +82,15 @@ __device__ __forceinline__ void stage_tile(const uint32_t *__restrict__ sa, cons
         a[k] = in_sa ? sa[g] : 0u;
         c[k] = in_lcp ? lcp[g] : 0u;
     }
+    bool pending = false;
 #pragma unroll
     for (int k = 0; k < kRows; ++k) {
         const int j = k * kLdsThreads + (int)threadIdx.x;
         if (j < kLdsSpan) s_sa[j] = a[k];
         if (j <= kLdsSpan) s_lcp[j] = c[k];
+        pending |= flag != nullptr && c[k] >= flag_min;
     }
+    if (pending) atomicOr(flag, 1u);  // (never on a finished LCP array)
 }
 
 // One round of kSteps steps of one search, branch-free.  li = local index of rank r in the

@@ -56,8 +56,17 @@ struct Pyramid;
 // ---- stage 4: per-position factor length codes (lpnf.hip) ---------------------------------
 // lstar[i] = L*[i] (0 = literal).  Returns the number of positions that needed the exact search.
 // isa_fill (optional): isa[] has not been written yet (build_suffix_array, isa_deferred): it is filled here.
+// fill_pyramids (optional): Psa / Plcp are allocated (alloc_pyramid over sa / lcp) but not computed: the tile kernel
+// of this stage writes their first level from the blocks it has in LDS and the upper levels are filled here -- the
+// caller skips build_pyramid / build_lcp_pyramid (whose check for undecided LCP entries happens here too).
 uint32_t build_lstar(Context &ctx, uint32_t n, const uint32_t *sa, const uint32_t *isa, const uint32_t *lcp,
-                     const Pyramid &Psa, const Pyramid &Plcp, uint32_t *lstar, uint32_t *isa_fill = nullptr);
+                     const Pyramid &Psa, const Pyramid &Plcp, uint32_t *lstar, uint32_t *isa_fill = nullptr,
+                     const PackedText *fill_pyramids = nullptr);
+// pieces of build_lcp_pyramid for that form (suffix_array.hip): the code above which an LCP entry counts as
+// undecided, the comparison of the suffixes around every undecided entry, and the test hook that leaves one undecided
+uint32_t pending_threshold();
+void finish_pending_lcp(Context &ctx, const PackedText &text, const uint32_t *sa, uint32_t *lcp);
+void inject_pending_for_test(Context &ctx, uint32_t *lcp, uint32_t n);
 
 // ---- stage 5: greedy cursor + factor records (chain.hip) ------------------------------------
 uint32_t resolve_chain(Context &ctx, uint32_t n, uint32_t start_pos, const uint32_t *lstar, const uint32_t *sa,

@@ -38,31 +38,53 @@ __global__ __launch_bounds__(kThreads) void pyramid_level_kernel(const uint32_t 
 
 }  // namespace
 
-Pyramid build_pyramid(const uint32_t *base, uint32_t len, bool is_max, Arena &arena, hipStream_t stream,
-                      uint32_t flag_min, uint32_t *flag) {
+Pyramid alloc_pyramid(const uint32_t *base, uint32_t len, Arena &arena) {
     Pyramid P{};
     P.lvl[0] = base;
     P.len[0] = len;
     P.nlev = 1;
-    const bool aligned = ((uintptr_t)base & 15) == 0;
-    if (!aligned) throw HipError("pyramid: base array must be 16-byte aligned");
+    if (((uintptr_t)base & 15) != 0) throw HipError("pyramid: base array must be 16-byte aligned");
     while (P.len[P.nlev - 1] > 1 && P.nlev < kPyrMaxLevels) {
-        const uint32_t len_in = P.len[P.nlev - 1];
-        const uint32_t len_out = (len_in + kPyrFan - 1) >> kPyrShift;
-        uint32_t *out = arena.alloc<uint32_t>(len_out);
-        size_t g = div_up(len_out, kThreads);
-        if (g > 8192) g = 8192;
-        if (is_max)
-            pyramid_level_kernel<true><<<(unsigned)g, kThreads, 0, stream>>>(P.lvl[P.nlev - 1], len_in, out, len_out, 0u,
-                                                                             nullptr);
-        else
-            pyramid_level_kernel<false><<<(unsigned)g, kThreads, 0, stream>>>(P.lvl[P.nlev - 1], len_in, out, len_out,
-                                                                              flag_min, P.nlev == 1 ? flag : nullptr);
-        KERNEL_CHECK();
-        P.lvl[P.nlev] = out;
+        const uint32_t len_out = (P.len[P.nlev - 1] + kPyrFan - 1) >> kPyrShift;
+        P.lvl[P.nlev] = arena.alloc<uint32_t>(len_out);
         P.len[P.nlev] = len_out;
         ++P.nlev;
     }
+    return P;
+}
+
+void fill_pyramid(const Pyramid &P, int first_level, bool is_max, hipStream_t stream, uint32_t flag_min, uint32_t *flag) {
+    for (int lev = first_level < 1 ? 1 : first_level; lev < P.nlev; ++lev) {
+        const uint32_t len_in = P.len[lev - 1], len_out = P.len[lev];
+        uint32_t *out = const_cast<uint32_t *>(P.lvl[lev]);
+        size_t g = div_up(len_out, kThreads);
+        if (g > 8192) g = 8192;
+        if (is_max)
+            pyramid_level_kernel<true><<<(unsigned)g, kThreads, 0, stream>>>(P.lvl[lev - 1], len_in, out, len_out, 0u, nullptr);
+        else
+            pyramid_level_kernel<false><<<(unsigned)g, kThreads, 0, stream>>>(P.lvl[lev - 1], len_in, out, len_out, flag_min,
+                                                                              lev == 1 ? flag : nullptr);
+        KERNEL_CHECK();
+    }
+}
+
+void fill_pyramid_tail(const Pyramid &P, uint32_t first_entry, bool is_max, hipStream_t stream) {
+    if (P.nlev < 2 || first_entry >= P.len[1]) return;
+    const size_t skip = (size_t)first_entry << kPyrShift;  // base entries in front of the tail (a multiple of 16: aligned)
+    const uint32_t *in = P.lvl[0] + skip;
+    uint32_t *out = const_cast<uint32_t *>(P.lvl[1]) + first_entry;
+    const uint32_t len_in = (uint32_t)(P.len[0] - skip), len_out = P.len[1] - first_entry;
+    if (is_max)
+        pyramid_level_kernel<true><<<1, kThreads, 0, stream>>>(in, len_in, out, len_out, 0u, nullptr);
+    else
+        pyramid_level_kernel<false><<<1, kThreads, 0, stream>>>(in, len_in, out, len_out, 0u, nullptr);
+    KERNEL_CHECK();
+}
+
+Pyramid build_pyramid(const uint32_t *base, uint32_t len, bool is_max, Arena &arena, hipStream_t stream,
+                      uint32_t flag_min, uint32_t *flag) {
+    const Pyramid P = alloc_pyramid(base, len, arena);
+    fill_pyramid(P, 1, is_max, stream, flag_min, flag);
     return P;
 }
 

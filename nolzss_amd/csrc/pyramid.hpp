@@ -25,6 +25,14 @@ struct Pyramid {
 // only), *flag is OR-ed with 1 if some base entry is >= flag_min.
 Pyramid build_pyramid(const uint32_t *base, uint32_t len, bool is_max, Arena &arena, hipStream_t stream,
                       uint32_t flag_min = 0, uint32_t *flag = nullptr);
+// The same in two steps, for a caller that computes the first level(s) itself (the candidate kernel has every
+// aligned block of 16 ranks in LDS anyway): alloc_pyramid reserves the level arrays and computes nothing;
+// fill_pyramid computes the levels from `first_level` up (level 0 = base).  fill_pyramid_tail computes the entries
+// [first_entry, len[1]) of level 1 only (the blocks at the end of the array that such a caller leaves out).
+Pyramid alloc_pyramid(const uint32_t *base, uint32_t len, Arena &arena);
+void fill_pyramid(const Pyramid &P, int first_level, bool is_max, hipStream_t stream, uint32_t flag_min = 0,
+                  uint32_t *flag = nullptr);
+void fill_pyramid_tail(const Pyramid &P, uint32_t first_entry, bool is_max, hipStream_t stream);
 
 template <bool kMax> __device__ __forceinline__ bool pyr_hit(uint32_t v, uint32_t x) {
     return kMax ? (v > x) : (v < x);

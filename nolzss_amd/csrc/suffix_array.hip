@@ -2573,29 +2573,42 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     return rounds;
 }
 
+uint32_t pending_threshold() { return kLcpPendingMin; }
+
+void inject_pending_for_test(Context &ctx, uint32_t *lcp, uint32_t n) {
+    // (test hook: make one entry pending so that the safety net runs)
+    static const bool inject = getenv("NOLZSS_TEST_INJECT_PENDING") != nullptr;
+    if (inject && n > 2) HIP_CHECK(hipMemsetAsync(lcp + n / 2, 0xff, sizeof(uint32_t), ctx.stream));
+}
+
+// safety net: compare the suffixes in the packed text wherever an LCP entry is still undecided
+void finish_pending_lcp(Context &ctx, const PackedText &text, const uint32_t *sa, uint32_t *lcp) {
+    const uint32_t n = text.n;
+    hipStream_t s = ctx.stream;
+    ProfScope ps(ctx.profiler(), "lcp_finish", s);
+    const unsigned g = grid_for((size_t)n + 1, kThreads, 256u * 32u);
+    const uint32_t skip = 1;  // (all that is known for sure: the suffixes differ somewhere)
+    switch (text.bits) {
+    case 2: lcp_finish_kernel<2><<<g, kThreads, 0, s>>>(text.words, n, text.terms, sa, skip - 1, lcp); break;
+    case 4: lcp_finish_kernel<4><<<g, kThreads, 0, s>>>(text.words, n, text.terms, sa, skip - 1, lcp); break;
+    default: lcp_finish_kernel<8><<<g, kThreads, 0, s>>>(text.words, n, text.terms, sa, skip - 1, lcp); break;
+    }
+    KERNEL_CHECK();
+}
+
 Pyramid build_lcp_pyramid(Context &ctx, const PackedText &text, const uint32_t *sa, uint32_t *lcp) {
     const uint32_t n = text.n;
     hipStream_t s = ctx.stream;
     uint32_t *flag = ctx.arena.alloc<uint32_t>(1);
     HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(uint32_t), s));
-    // (test hook: make one entry pending so that the safety net below runs)
-    static const bool inject = getenv("NOLZSS_TEST_INJECT_PENDING") != nullptr;
-    if (inject && n > 2) HIP_CHECK(hipMemsetAsync(lcp + n / 2, 0xff, sizeof(uint32_t), s));
+    inject_pending_for_test(ctx, lcp, n);
     const size_t mark = ctx.arena.mark();
     Pyramid P = build_pyramid(lcp, n + 1, false, ctx.arena, s, kLcpPendingMin, flag);
     uint32_t pending = 0;
     ctx.read_back(flag, &pending, 1);
     if (pending) {  // safety net: compare the suffixes in the packed text, then build again
-        ProfScope ps(ctx.profiler(), "lcp_finish", s);
         ctx.arena.rewind(mark);
-        const unsigned g = grid_for((size_t)n + 1, kThreads, 256u * 32u);
-        const uint32_t skip = 1;  // (all that is known for sure: the suffixes differ somewhere)
-        switch (text.bits) {
-        case 2: lcp_finish_kernel<2><<<g, kThreads, 0, s>>>(text.words, n, text.terms, sa, skip - 1, lcp); break;
-        case 4: lcp_finish_kernel<4><<<g, kThreads, 0, s>>>(text.words, n, text.terms, sa, skip - 1, lcp); break;
-        default: lcp_finish_kernel<8><<<g, kThreads, 0, s>>>(text.words, n, text.terms, sa, skip - 1, lcp); break;
-        }
-        KERNEL_CHECK();
+        finish_pending_lcp(ctx, text, sa, lcp);
         P = build_pyramid(lcp, n + 1, false, ctx.arena, s);
     }
     return P;
