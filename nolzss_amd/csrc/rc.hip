@@ -56,7 +56,10 @@ __device__ __forceinline__ bool rc_decide(uint32_t i, uint32_t lp, uint32_t jp, 
 __global__ __launch_bounds__(kLdsThreads) void rc_tile_kernel(const uint32_t *__restrict__ sa,
                                                               const uint32_t *__restrict__ lcp, uint32_t m,
                                                               uint32_t N, uint32_t *__restrict__ code_by_rank,
-                                                              ShardQueue exact_q, ShardQueue far_q) {
+                                                              ShardQueue exact_q, ShardQueue far_q,
+                                                              uint32_t *__restrict__ pmin1, uint32_t *__restrict__ pmax1,
+                                                              uint32_t *__restrict__ plcp1, uint32_t pending_min,
+                                                              uint32_t *__restrict__ pending_flag) {
     constexpr int NS = 4, NP = 2;
     __shared__ __align__(16) uint32_t s_sa[kLdsSpan];
     __shared__ __align__(16) uint32_t s_lcp[kLdsSpan + 4];
@@ -66,11 +69,21 @@ __global__ __launch_bounds__(kLdsThreads) void rc_tile_kernel(const uint32_t *__
     __shared__ uint32_t s_blk[4 * kNumBlk];
     const uint32_t base = blockIdx.x * (uint32_t)kLdsTile;
     const uint32_t shard = blockIdx.x % kQShards;
-    stage_tile(sa, lcp, m, base, s_sa, s_lcp);
+    stage_tile(sa, lcp, m, base, s_sa, s_lcp, pending_min, pending_flag);
     __syncthreads();
     const BlockTables T{s_blk, s_blk + kNumBlk, s_blk + 2 * kNumBlk, s_blk + 3 * kNumBlk};
     build_block_tables<true>(s_sa, s_lcp, T);
     __syncthreads();
+    // the block tables of the tile's own ranks are the first level of the three pyramids (lpnf.hip, lpf_tile_kernel)
+    if (pmin1 != nullptr && threadIdx.x < kLdsTile / kBlk) {
+        const uint32_t B = (uint32_t)kLdsReach / kBlk + threadIdx.x;
+        const uint64_t first = (uint64_t)base + (uint64_t)threadIdx.x * kBlk;
+        if (first + kBlk <= (uint64_t)m) {
+            pmin1[first >> 4] = T.mn[B];
+            pmax1[first >> 4] = T.mx[B];
+            plcp1[first >> 4] = T.ldn[B];
+        }
+    }
     const int w = threadIdx.x >> 6;
     const uint32_t far_bit = m <= 0x80000000u ? 0x80000000u : 0u;
     lds_search_wave_blocks<NS, NP, true>(s_sa, s_lcp, T, m, base, s_len, s_pos, s_list[w][0], s_list[w][1],
@@ -293,13 +306,13 @@ uint32_t run_rc_pipeline_packed(Context &ctx, const PackedText &text, size_t sta
     uint32_t *lcp = arena.alloc<uint32_t>((size_t)m + 1);
     bool isa_deferred = false;
     build_suffix_array(ctx, text, sa, isa, lcp, &isa_deferred);
-    Pyramid Pmin, Pmax, Plcp;
-    {
-        ProfScope ps(ctx.profiler(), "pyramids", s);
-        Pmin = build_pyramid(sa, m, false, arena, s);
-        Pmax = build_pyramid(sa, m, true, arena, s);
-        Plcp = build_lcp_pyramid(ctx, text, sa, lcp);
-    }
+    // (allocated here, filled behind the tile kernel, which writes their first level: lpnf.hip)
+    const Pyramid Pmin = alloc_pyramid(sa, m, arena), Pmax = alloc_pyramid(sa, m, arena),
+                  Plcp = alloc_pyramid(lcp, m + 1, arena);
+    const bool fused_level1 = Pmin.nlev > 1 && Plcp.nlev > 1;
+    uint32_t *pending_flag = arena.alloc<uint32_t>(1);
+    HIP_CHECK(hipMemsetAsync(pending_flag, 0, sizeof(uint32_t), s));
+    inject_pending_for_test(ctx, lcp, m);
     // code[] spans all of S (entries >= N are unused) so that rank order -> text order is a
     // permutation scatter
     uint32_t *code = arena.alloc<uint32_t>(m);
@@ -330,8 +343,37 @@ uint32_t run_rc_pipeline_packed(Context &ctx, const PackedText &text, size_t sta
         };
         {
             ProfScope ps(ctx.profiler(), "rc_candidates", s);
-            rc_tile_kernel<<<tiles, kLdsThreads, 0, s>>>(sa, lcp, m, N, by_rank, exact_q, far_q);
+            rc_tile_kernel<<<tiles, kLdsThreads, 0, s>>>(
+                sa, lcp, m, N, by_rank, exact_q, far_q, fused_level1 ? const_cast<uint32_t *>(Pmin.lvl[1]) : nullptr,
+                fused_level1 ? const_cast<uint32_t *>(Pmax.lvl[1]) : nullptr,
+                fused_level1 ? const_cast<uint32_t *>(Plcp.lvl[1]) : nullptr, pending_threshold(), pending_flag);
             KERNEL_CHECK();
+        }
+        {
+            ProfScope ps(ctx.profiler(), "pyramids", s);
+            const int from = fused_level1 ? 2 : 1;
+            if (fused_level1) {
+                fill_pyramid_tail(Pmin, m >> kPyrShift, false, s);
+                fill_pyramid_tail(Pmax, m >> kPyrShift, true, s);
+                fill_pyramid_tail(Plcp, m >> kPyrShift, false, s);
+            }
+            fill_pyramid(Pmin, from, false, s);
+            fill_pyramid(Pmax, from, true, s);
+            fill_pyramid(Plcp, from, false, s);
+            uint32_t pending = 0;
+            ctx.read_back(pending_flag, &pending, 1);
+            if (pending) {
+                // safety net (build_lcp_pyramid): an undecided LCP entry is compared in the text, the pyramids are
+                // built again and the candidates computed once more from the repaired array
+                finish_pending_lcp(ctx, text, sa, lcp);
+                fill_pyramid(Pmin, 1, false, s);
+                fill_pyramid(Pmax, 1, true, s);
+                fill_pyramid(Plcp, 1, false, s);
+                HIP_CHECK(hipMemsetAsync(qcounts, 0, 2 * kQShards * kQPad * sizeof(uint32_t), s));
+                rc_tile_kernel<<<tiles, kLdsThreads, 0, s>>>(sa, lcp, m, N, by_rank, exact_q, far_q, nullptr, nullptr, nullptr,
+                                                             0u, nullptr);
+                KERNEL_CHECK();
+            }
         }
         {
             ProfScope ps(ctx.profiler(), "rc_to_text_order", s);
