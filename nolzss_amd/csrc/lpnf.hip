@@ -21,6 +21,7 @@
 #include "nearest_lds.hpp"
 #include "queues.hpp"
 #include "radix_sort.hpp"
+#include "scan.hpp"
 
 namespace nolzss {
 
@@ -70,7 +71,8 @@ template <bool kTimed>
 __global__ __launch_bounds__(kLdsThreads) void lpf_tile_kernel(const uint32_t *__restrict__ sa,
                                                                const uint32_t *__restrict__ lcp, uint32_t n,
                                                                uint32_t *__restrict__ lstar_by_rank,
-                                                               ShardQueue exact_q, ShardQueue far_q,
+                                                               ShardQueue exact_q, uint32_t *__restrict__ far_items,
+                                                               uint32_t *__restrict__ far_cnt,
                                                                uint32_t *__restrict__ far_aux,
                                                                unsigned long long *__restrict__ phases,
                                                                uint32_t *__restrict__ psa1, uint32_t *__restrict__ plcp1,
@@ -140,14 +142,28 @@ __global__ __launch_bounds__(kLdsThreads) void lpf_tile_kernel(const uint32_t *_
             exact[row] = lpf_decide(s_sa[t + kLdsReach], up, s_pos[t], down, s_pos[kLdsTile + t], lstar_by_rank + rr);
         }
     }
-    shard_slots<kRows>(far_q, shard, far, fslot);
+    // Far ranks: every wavefront has a region of its own -- the 256 entries at its own ranks -- and reports how
+    // many it used; a scan and a small kernel make one list of them (compact_far_kernel).  The returning atomic
+    // on a queue counter that almost every second wavefront needed here kept the wavefront alive for a round trip
+    // to memory: the epilogue took 10.8 k of a wavefront's 32 k cycles (NOLZSS_LPF_PHASES).
+    {
+        const uint32_t region = (blockIdx.x * (uint32_t)kLdsWaves + (uint32_t)w);
+        uint32_t used = 0;
+#pragma unroll
+        for (int row = 0; row < kRows; ++row) {
+            const uint64_t bal = __ballot(far[row]);
+            fslot[row] = region * (uint32_t)kLdsPerWave + used + (uint32_t)__popcll(bal & lanemask_lt());
+            used += (uint32_t)__popcll(bal);
+        }
+        if (lane_id() == 0) far_cnt[region] = used;
+    }
     shard_slots<kRows>(exact_q, shard, exact, eslot);
 #pragma unroll
     for (int row = 0; row < kRows; ++row) {
         const int t = w * kLdsPerWave + row * 64 + lane_id();
         const uint64_t rr = (uint64_t)base + t;
         if (far[row]) {
-            far_q.items[fslot[row]] = (uint32_t)rr;
+            far_items[fslot[row]] = (uint32_t)rr;
             lstar_by_rank[rr] = known[row];
             far_aux[rr] = aux[row];
         }
@@ -164,17 +180,31 @@ __global__ __launch_bounds__(kLdsThreads) void lpf_tile_kernel(const uint32_t *_
 }
 
 // ranks whose nearest earlier suffix lies outside the LDS reach: pyramid search.  Grid (kQShards, Y).
-__global__ __launch_bounds__(kThreads) void lpf_far_kernel(ShardQueue far_q, const uint32_t *__restrict__ sa,
+// the far ranks of all wavefront regions, one after the other: four threads per region
+__global__ __launch_bounds__(kThreads) void compact_far_kernel(const uint32_t *__restrict__ far_items,
+                                                               const uint32_t *__restrict__ far_cnt,
+                                                               const uint32_t *__restrict__ far_off, uint32_t regions,
+                                                               uint32_t *__restrict__ far_list) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x / 4;
+    for (size_t r = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / 4; r < regions; r += stride) {
+        const uint32_t c = far_cnt[r], o = far_off[r];
+        for (uint32_t k = threadIdx.x & 3u; k < c; k += 4) far_list[o + k] = far_items[r * (size_t)kLdsPerWave + k];
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void lpf_far_kernel(const uint32_t *__restrict__ far_list, uint32_t far_count,
+                                                           const uint32_t *__restrict__ sa,
                                                            const uint32_t *__restrict__ lcp, uint32_t n,
                                                            Pyramid Psa, Pyramid Plcp,
                                                            const uint32_t *__restrict__ by_rank,
                                                            const uint32_t *__restrict__ far_aux, bool bounded,
                                                            uint32_t *__restrict__ lstar, ShardQueue exact_q) {
-    const uint32_t shard = blockIdx.x;
-    const uint32_t count = far_q.counts[shard * kQPad];
-    const uint32_t *items = far_q.items + (size_t)shard * far_q.cap;
-    for (uint32_t k = blockIdx.y * blockDim.x + threadIdx.x; k < count; k += gridDim.y * blockDim.x) {
-        const uint32_t r = items[k];
+    const uint32_t shard = blockIdx.x % kQShards;
+    const uint32_t rounds = (far_count + gridDim.x * blockDim.x - 1) / (gridDim.x * blockDim.x);
+    for (uint32_t it = 0; it < rounds; ++it) {  // (every lane stays for the ballot of shard_slot)
+        const uint32_t k = it * gridDim.x * blockDim.x + blockIdx.x * blockDim.x + threadIdx.x;
+        const bool have = k < far_count;
+        const uint32_t r = far_list[have ? k : 0u];
         const uint32_t i = sa[r];
         const uint32_t aux = far_aux[r];
         uint32_t lp, jp, ls, js;
@@ -193,7 +223,8 @@ __global__ __launch_bounds__(kThreads) void lpf_far_kernel(ShardQueue far_q, con
             jp = (aux & 0x7fffffffu) == 0x7fffffffu ? kNoPos : (aux & 0x7fffffffu);
             far_down<false>(sa, n, Psa, Plcp, r, i, lp, ls, js);
         }
-        const bool exact = lpf_decide(i, lp, jp, ls, js, lstar + i);
+        uint32_t dummy = 0;
+        const bool exact = lpf_decide(i, lp, jp, ls, js, have ? lstar + i : &dummy) && have;
         const uint32_t eslot = shard_slot(exact_q, shard, exact);  // (a rank reaches the exact queue at most once)
         if (exact) exact_q.items[eslot] = i;
     }
@@ -232,25 +263,28 @@ uint32_t build_lstar(Context &ctx, uint32_t n, const uint32_t *sa, const uint32_
     uint32_t *plcp1 = fill_pyramids && Plcp.nlev > 1 ? const_cast<uint32_t *>(Plcp.lvl[1]) : nullptr;
     if (!psa1 || !plcp1) psa1 = plcp1 = nullptr;
     const unsigned tiles = (unsigned)div_up(n, kLdsTile);
-    ShardQueue exact_q, far_q;
-    exact_q.cap = far_q.cap = (uint32_t)shard_queue_cap(tiles, kLdsTile);
+    ShardQueue exact_q;
+    exact_q.cap = (uint32_t)shard_queue_cap(tiles, kLdsTile);
     exact_q.items = ctx.arena.alloc<uint32_t>((size_t)kQShards * exact_q.cap);
-    far_q.items = ctx.arena.alloc<uint32_t>((size_t)kQShards * far_q.cap);
-    uint32_t *qcounts = ctx.arena.alloc<uint32_t>(2 * kQShards * kQPad);
+    // far ranks: one region per wavefront of the tile kernel (its own 256 ranks), then one list
+    const uint32_t far_regions = tiles * (uint32_t)kLdsWaves;
+    uint32_t *far_items = ctx.arena.alloc<uint32_t>((size_t)far_regions * kLdsPerWave);
+    uint32_t *far_cnt = ctx.arena.alloc<uint32_t>(far_regions);
+    uint32_t *far_off = ctx.arena.alloc<uint32_t>(far_regions);
+    uint32_t *qcounts = ctx.arena.alloc<uint32_t>(kQShards * kQPad);
     exact_q.counts = qcounts;
-    far_q.counts = qcounts + kQShards * kQPad;
-    const uint32_t **count_ptrs = ctx.arena.alloc<const uint32_t *>(2);
-    uint32_t *totals = ctx.arena.alloc<uint32_t>(2);  // [0] exact-search queue, [1] far queue
+    const uint32_t **count_ptrs = ctx.arena.alloc<const uint32_t *>(1);
+    uint32_t *totals = ctx.arena.alloc<uint32_t>(2);  // [0] exact-search queue, [1] far ranks
     uint32_t *by_rank = ctx.arena.alloc<uint32_t>(n);
     uint32_t *far_aux = ctx.arena.alloc<uint32_t>(n);
     uint32_t *scratch_idx = ctx.arena.alloc<uint32_t>(n);
     uint32_t *scratch_val = ctx.arena.alloc<uint32_t>(isa_fill ? 2 * (size_t)n : (size_t)n);  // (two values per pair: radix_sort.hpp)
-    HIP_CHECK(hipMemsetAsync(qcounts, 0, 2 * kQShards * kQPad * sizeof(uint32_t), s));
-    const uint32_t *h_ptrs[2] = {exact_q.counts, far_q.counts};
+    HIP_CHECK(hipMemsetAsync(qcounts, 0, kQShards * kQPad * sizeof(uint32_t), s));
+    const uint32_t *h_ptrs[1] = {exact_q.counts};
     HIP_CHECK(hipMemcpyAsync(count_ptrs, h_ptrs, sizeof h_ptrs, hipMemcpyHostToDevice, s));
     HIP_CHECK(hipStreamSynchronize(s));  // h_ptrs is a local array
-    auto read_totals = [&](uint32_t h[2]) {
-        shard_totals_kernel<<<2, kQShards, 0, s>>>(count_ptrs, 2, totals);
+    auto read_totals = [&](uint32_t h[2]) {  // (totals[1] is written once, by the scan of the far counts)
+        shard_totals_kernel<<<1, kQShards, 0, s>>>(count_ptrs, 1, totals);
         KERNEL_CHECK();
         ctx.read_back(totals, h, 2);
     };
@@ -263,10 +297,10 @@ uint32_t build_lstar(Context &ctx, uint32_t n, const uint32_t *sa, const uint32_
             HIP_CHECK(hipMemsetAsync(phases, 0, 64, s));
         }
         if (phases)
-            lpf_tile_kernel<true><<<tiles, kLdsThreads, 0, s>>>(sa, lcp, n, by_rank, exact_q, far_q, far_aux, phases, psa1, plcp1,
+            lpf_tile_kernel<true><<<tiles, kLdsThreads, 0, s>>>(sa, lcp, n, by_rank, exact_q, far_items, far_cnt, far_aux, phases, psa1, plcp1,
                                                                 pending_threshold(), pending_flag);
         else
-            lpf_tile_kernel<false><<<tiles, kLdsThreads, 0, s>>>(sa, lcp, n, by_rank, exact_q, far_q, far_aux, nullptr, psa1,
+            lpf_tile_kernel<false><<<tiles, kLdsThreads, 0, s>>>(sa, lcp, n, by_rank, exact_q, far_items, far_cnt, far_aux, nullptr, psa1,
                                                                  plcp1, pending_threshold(), pending_flag);
         KERNEL_CHECK();
         if (phases) {
@@ -278,6 +312,7 @@ uint32_t build_lstar(Context &ctx, uint32_t n, const uint32_t *sa, const uint32_
                     h[5], h[0] / w, h[1] / w, "roundA", h[2] / w, "roundsBC", h[3] / w, h[4] / w);
         }
     }
+    scan_exclusive_add_u32(far_cnt, far_off, far_regions, totals + 1, ctx.arena, s);
     if (fill_pyramids) {
         ProfScope ps(ctx.profiler(), "pyramids", s);
         if (psa1) {  // level 1 came from the tile kernel, but for the blocks that reach beyond the last rank
@@ -315,9 +350,13 @@ uint32_t build_lstar(Context &ctx, uint32_t n, const uint32_t *sa, const uint32_
     if (trace) fprintf(stderr, "[nolzss] lpf: %u ranks to the far queue, %u positions to the exact search so far\n", h[1], h[0]);
     if (h[1] > 0) {
         ProfScope ps(ctx.profiler(), "lpf_far", s);
-        const unsigned gy = (unsigned)std::min<size_t>(64, std::max<size_t>(1, div_up(h[1], (size_t)kQShards * kThreads)));
-        lpf_far_kernel<<<dim3(kQShards, gy), kThreads, 0, s>>>(far_q, sa, lcp, n, Psa, Plcp, by_rank, far_aux,
-                                                              n <= 0x80000000u, lstar, exact_q);
+        uint32_t *far_list = ctx.arena.alloc<uint32_t>(h[1]);
+        compact_far_kernel<<<(unsigned)std::min<size_t>(div_up((size_t)far_regions * 4, kThreads), 256u * 16u), kThreads, 0, s>>>(
+            far_items, far_cnt, far_off, far_regions, far_list);
+        KERNEL_CHECK();
+        const unsigned g = (unsigned)std::min<size_t>(256u * 64u, std::max<size_t>(1, div_up(h[1], kThreads)));
+        lpf_far_kernel<<<g, kThreads, 0, s>>>(far_list, h[1], sa, lcp, n, Psa, Plcp, by_rank, far_aux, n <= 0x80000000u,
+                                              lstar, exact_q);
         KERNEL_CHECK();
         read_totals(h);
     }
