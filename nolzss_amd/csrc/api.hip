@@ -1640,10 +1640,10 @@ bool run_merged_chunk(Context &ctx, const uint8_t *const *texts, const size_t *l
         uint32_t *isa = arena.alloc<uint32_t>(n);
         uint32_t *lcp = arena.alloc<uint32_t>(n + 1);
         build_suffix_array(ctx, text, sa, isa, lcp);
-        const Pyramid Psa = build_pyramid(sa, (uint32_t)n, false, arena, s);
-        const Pyramid Plcp = build_lcp_pyramid(ctx, text, sa, lcp);
+        // (pyramids: allocated here, filled by build_lstar -- first level from the candidate kernel)
+        const Pyramid Psa = alloc_pyramid(sa, (uint32_t)n, arena), Plcp = alloc_pyramid(lcp, (uint32_t)n + 1, arena);
         uint32_t *lstar = arena.alloc<uint32_t>(n);
-        build_lstar(ctx, (uint32_t)n, sa, isa, lcp, Psa, Plcp, lstar);
+        build_lstar(ctx, (uint32_t)n, sa, isa, lcp, Psa, Plcp, lstar, nullptr, &text);
         // counts come from the factor starts; records are built only when the caller wants them, and leave
         // the factor kernel in record coordinates
         z = resolve_chain(ctx, (uint32_t)n, 0, lstar, sa, isa, lcp, Psa, Plcp, fs ? &d_recs : nullptr, 0, nullptr,
@@ -1775,14 +1775,10 @@ bool run_merged_chunk_device(Context &ctx, const void *const *d_texts, const siz
     uint32_t *isa = arena.alloc<uint32_t>(n);
     uint32_t *lcp = arena.alloc<uint32_t>(n + 1);
     build_suffix_array(ctx, text, sa, isa, lcp);
-    Pyramid Psa, Plcp;
-    {
-        ProfScope ps(ctx.profiler(), "pyramids", s);
-        Psa = build_pyramid(sa, (uint32_t)n, false, arena, s);
-        Plcp = build_lcp_pyramid(ctx, text, sa, lcp);
-    }
+    // (pyramids: allocated here, filled by build_lstar -- first level from the candidate kernel)
+    const Pyramid Psa = alloc_pyramid(sa, (uint32_t)n, arena), Plcp = alloc_pyramid(lcp, (uint32_t)n + 1, arena);
     uint32_t *lstar = arena.alloc<uint32_t>(n);
-    build_lstar(ctx, (uint32_t)n, sa, isa, lcp, Psa, Plcp, lstar);
+    build_lstar(ctx, (uint32_t)n, sa, isa, lcp, Psa, Plcp, lstar, nullptr, &text);
     void *d_recs = nullptr;
     uint32_t *d_fpos = nullptr;
     const uint32_t z = resolve_chain(ctx, (uint32_t)n, 0, lstar, sa, isa, lcp, Psa, Plcp, emit ? &d_recs : nullptr, 0,

@@ -192,19 +192,19 @@ __global__ __launch_bounds__(kThreads) void compact_far_kernel(const uint32_t *_
     }
 }
 
+// far_exact[k] = position i if the k-th far rank needs the exact search, else kNoPos.  (Not the sharded exact queue:
+// a shard's region is sized for what the tiles of that shard can append, and the far list deals ranks to workgroups
+// in list order, not by tile.)
 __global__ __launch_bounds__(kThreads) void lpf_far_kernel(const uint32_t *__restrict__ far_list, uint32_t far_count,
                                                            const uint32_t *__restrict__ sa,
                                                            const uint32_t *__restrict__ lcp, uint32_t n,
                                                            Pyramid Psa, Pyramid Plcp,
                                                            const uint32_t *__restrict__ by_rank,
                                                            const uint32_t *__restrict__ far_aux, bool bounded,
-                                                           uint32_t *__restrict__ lstar, ShardQueue exact_q) {
-    const uint32_t shard = blockIdx.x % kQShards;
-    const uint32_t rounds = (far_count + gridDim.x * blockDim.x - 1) / (gridDim.x * blockDim.x);
-    for (uint32_t it = 0; it < rounds; ++it) {  // (every lane stays for the ballot of shard_slot)
-        const uint32_t k = it * gridDim.x * blockDim.x + blockIdx.x * blockDim.x + threadIdx.x;
-        const bool have = k < far_count;
-        const uint32_t r = far_list[have ? k : 0u];
+                                                           uint32_t *__restrict__ lstar, uint32_t *__restrict__ far_exact) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < far_count; k += stride) {
+        const uint32_t r = far_list[k];
         const uint32_t i = sa[r];
         const uint32_t aux = far_aux[r];
         uint32_t lp, jp, ls, js;
@@ -223,10 +223,21 @@ __global__ __launch_bounds__(kThreads) void lpf_far_kernel(const uint32_t *__res
             jp = (aux & 0x7fffffffu) == 0x7fffffffu ? kNoPos : (aux & 0x7fffffffu);
             far_down<false>(sa, n, Psa, Plcp, r, i, lp, ls, js);
         }
-        uint32_t dummy = 0;
-        const bool exact = lpf_decide(i, lp, jp, ls, js, have ? lstar + i : &dummy) && have;
-        const uint32_t eslot = shard_slot(exact_q, shard, exact);  // (a rank reaches the exact queue at most once)
-        if (exact) exact_q.items[eslot] = i;
+        far_exact[k] = lpf_decide(i, lp, jp, ls, js, lstar + i) ? i : kNoPos;
+    }
+}
+
+// the exact search for the far ranks that need it (far_exact, above)
+__global__ __launch_bounds__(kThreads) void lpnf_fallback_list_kernel(const uint32_t *__restrict__ far_exact,
+                                                                      uint32_t far_count, uint32_t n,
+                                                                      const uint32_t *__restrict__ isa, Pyramid Psa,
+                                                                      Pyramid Plcp, uint32_t *__restrict__ lstar) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < far_count; k += stride) {
+        const uint32_t i = far_exact[k];
+        if (i == kNoPos) continue;
+        const uint32_t cap = (n - i) < i ? (n - i) : i;  // L* <= i - j <= i and L* <= n - i
+        lstar[i] = lpnf_search(Psa, Plcp, isa[i] - 1u, i, lstar[i], cap);  // P(lstar[i]) holds on entry
     }
 }
 
@@ -354,11 +365,13 @@ uint32_t build_lstar(Context &ctx, uint32_t n, const uint32_t *sa, const uint32_
         compact_far_kernel<<<(unsigned)std::min<size_t>(div_up((size_t)far_regions * 4, kThreads), 256u * 16u), kThreads, 0, s>>>(
             far_items, far_cnt, far_off, far_regions, far_list);
         KERNEL_CHECK();
+        uint32_t *far_exact = ctx.arena.alloc<uint32_t>(h[1]);
         const unsigned g = (unsigned)std::min<size_t>(256u * 64u, std::max<size_t>(1, div_up(h[1], kThreads)));
         lpf_far_kernel<<<g, kThreads, 0, s>>>(far_list, h[1], sa, lcp, n, Psa, Plcp, by_rank, far_aux, n <= 0x80000000u,
-                                              lstar, exact_q);
+                                              lstar, far_exact);
         KERNEL_CHECK();
-        read_totals(h);
+        lpnf_fallback_list_kernel<<<g, kThreads, 0, s>>>(far_exact, h[1], n, isa, Psa, Plcp, lstar);
+        KERNEL_CHECK();
     }
     if (h[0] > 0) {
         ProfScope ps(ctx.profiler(), "lpnf_fallback", s);

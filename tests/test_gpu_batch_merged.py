@@ -421,3 +421,28 @@ def test_device_batch_merges_and_matches_one_by_one(native):
     torch.cuda.synchronize()
     got = native.factorize_batch_device([t.data_ptr() for t in d2], [len(r) for r in other], emit=0)
     assert got == [oracle.count_factors(r) for r in other]
+
+
+def test_far_ranks_that_need_the_exact_search(native):
+    """Regression (round 3, found by tools/fuzz_batch.py 25 17, case 131): a merged run whose far ranks -- searches
+    that leave the candidate kernel's LDS reach -- mostly need the exact search (periodic records).  A far kernel that
+    appended them to the sharded exact queue in list order overflowed a shard's region; they now come back through a
+    list of their own (lpnf.hip, far_exact)."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tools"))
+    import fuzz_batch as fb
+    rng = np.random.default_rng(17)
+    for _ in range(132):
+        recs = fb.make_records(rng)
+    counts, arrays = native.factorize_batch(recs, want_factors=True)
+    for j, r in enumerate(recs):
+        exp = oracle.factors_array(r)
+        assert counts[j] == len(exp), j
+        for k in ("start", "length", "ref"):
+            assert np.array_equal(arrays[j][k], exp[k]), (j, k)
+    # the same records as one text each: long periodic texts whose far ranks all need the exact search
+    for t in (b"CT" * 40_000, b"CCCT" * 30_000 + b"G" + b"CCCT" * 30_000):
+        got, exp = native.factorize_array(t), oracle.factors_array(t)
+        assert len(got) == len(exp) and all(np.array_equal(got[k], exp[k]) for k in ("start", "length", "ref"))
+
