@@ -87,12 +87,12 @@ __global__ __launch_bounds__(kLdsThreads) void lpf_tile_kernel(const uint32_t *_
     __shared__ uint32_t s_len[NS * kLdsTile];
     __shared__ uint32_t s_pos[NS * kLdsTile];
     __shared__ uint16_t s_list[kLdsWaves][2][NS * kLdsPerWave];
-    __shared__ uint32_t s_blk[3 * kNumBlk];
+    __shared__ uint32_t s_blk[3 * kBlkTableLen];
     const uint32_t base = blockIdx.x * (uint32_t)kLdsTile;
     const uint32_t shard = blockIdx.x % kQShards;
     stage_tile(sa, lcp, n, base, s_sa, s_lcp, pending_min, pending_flag);
     __syncthreads();
-    const BlockTables T{s_blk, nullptr, s_blk + kNumBlk, s_blk + 2 * kNumBlk};
+    const BlockTables T = block_tables<false>(s_blk);
     build_block_tables<false>(s_sa, s_lcp, T);
     __syncthreads();
     // The block tables of the tile's own ranks ARE the first level of the two pyramids the later stages query (min

@@ -19,6 +19,8 @@
 #pragma once
 #include "nearest.hpp"
 
+#include <type_traits>
+
 namespace nolzss {
 
 constexpr int kLdsThreads = 256;
@@ -93,42 +95,38 @@ __device__ __forceinline__ void stage_tile(const uint32_t *__restrict__ sa, cons
     if (pending) atomicOr(flag, 1u);  // (never on a finished LCP array)
 }
 
-// One round of kSteps steps of one search, branch-free.  li = local index of rank r in the
-// staged tile, s0 = steps already taken, m = running LCP minimum (in/out).
-// Returns 0 = finished without a match (len 0), 1 = match (m = its LCP, pos = its suffix start),
-// 2 = still searching.  No bounds logic is needed: LCP[0] = LCP[n] = 0 (and 0 is staged outside
-// the array), so the running minimum dies exactly when a search would leave the array.
-template <int kSteps>
-__device__ __forceinline__ int lds_scan_round(const uint32_t *s_sa, const uint32_t *s_lcp, int li, int s0,
-                                              bool greater, bool up, uint32_t x, uint32_t &m, uint32_t &pos) {
+// One round of kSteps steps of one search, branch-free; kind (kGreater) and direction (kUp) are compile-time, so
+// every LDS address is the rank's own plus an immediate.  li = local index of rank r in the staged tile, s0 = steps
+// already taken, m = running LCP minimum (in/out).
+// Returns 0 = finished without a match (m = 0), 1 = match (m = its LCP, pos = its suffix start), 2 = still
+// searching.  No bounds logic is needed: LCP[0] = LCP[n] = 0 (and 0 is staged outside the array), so the running
+// minimum dies exactly when a search would leave the array.
+// Four VALU instructions per step (minimum, comparison, two selects; the "still going" predicate lives in scalar
+// registers).  A search does not stop when its minimum reaches 0: the minimum stays 0, whatever qualifies later is
+// discarded by the m == 0 test at the end.  (Round 2 selected status, length and position per step from the last
+// step backwards, with the direction a per-lane value: 12 VALU instructions per step; SQ_INSTS_VALU x 4 cycles /
+// 1024 SIMDs was the whole 10.5 ms of lpf_tile_kernel.)
+template <int kSteps, bool kGreater, bool kUp>
+__device__ __forceinline__ int lds_scan_round(const uint32_t *s_sa, const uint32_t *s_lcp, int li, int s0, uint32_t x,
+                                              uint32_t &m, uint32_t &pos) {
     uint32_t c[kSteps], v[kSteps];
-    const int dir = up ? -1 : 1;
 #pragma unroll
     for (int k = 0; k < kSteps; ++k) {
-        const int q = li + dir * (s0 + k + 1);
-        c[k] = s_lcp[q + (up ? 1 : 0)];
+        const int q = kUp ? li - (s0 + k + 1) : li + (s0 + k + 1);
+        c[k] = s_lcp[q + (kUp ? 1 : 0)];
         v[k] = s_sa[q];
     }
-    // "v > x" as "~v < ~x": one comparison form for both kinds of search
-    const uint32_t flip = greater ? 0xffffffffu : 0u;
-    const uint32_t xf = x ^ flip;
+    bool alive = true;
 #pragma unroll
-    for (int k = 0; k < kSteps; ++k) {  // running minima
-        m = c[k] < m ? c[k] : m;
-        c[k] = m;
-    }
-    int status = 2;
-    uint32_t len = m;
-#pragma unroll
-    for (int k = kSteps - 1; k >= 0; --k) {  // the earliest stopping step wins
-        const bool dead = c[k] == 0;
-        const bool stop = dead || (v[k] ^ flip) < xf;
-        status = stop ? (dead ? 0 : 1) : status;
-        len = stop ? c[k] : len;
+    for (int k = 0; k < kSteps; ++k) {
+        const uint32_t mk = c[k] < m ? c[k] : m;
+        const bool qual = kGreater ? v[k] > x : v[k] < x;
+        const bool stop = alive && qual;
+        m = alive ? mk : m;
         pos = stop ? v[k] : pos;
+        alive = alive != stop;  // (alive && !qual, without a second comparison)
     }
-    m = len;
-    return status;
+    return m == 0 ? 0 : (alive ? 2 : 1);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -156,10 +154,18 @@ constexpr int kStepA = 12;
 // passed ranks, never to the rank itself)
 static_assert(kLdsStep0 + kStepA + 1 >= kBlk, "round B would look at the rank itself and at ranks on its other side");
 
+// Every table has one entry in front of block 0 and one behind the last block that never stops a search (round B
+// reads 16 blocks from b0 without a bounds test): kBlkTableLen words per table, the pointers below point at block 0.
+constexpr int kBlkTableLen = kNumBlk + 2;
 struct BlockTables {
     uint32_t *mn, *mx;    // min / max suffix start of the block (mx may be null)
     uint32_t *lup, *ldn;  // min LCP crossed passing the block upwards (entries 16B+1 .. 16B+16) / downwards (16B .. 16B+15)
 };
+// the tables of a kernel in one LDS array of kTables * kBlkTableLen words (kTables = 3: mn, lup, ldn; 4: mn, mx, lup, ldn)
+template <bool kMax> __device__ __forceinline__ BlockTables block_tables(uint32_t *mem) {
+    if (kMax) return BlockTables{mem + 1, mem + kBlkTableLen + 1, mem + 2 * kBlkTableLen + 1, mem + 3 * kBlkTableLen + 1};
+    return BlockTables{mem + 1, nullptr, mem + kBlkTableLen + 1, mem + 2 * kBlkTableLen + 1};
+}
 
 // run by the whole workgroup after the tile has been staged (and a barrier); followed by a barrier
 template <bool kMax>
@@ -189,22 +195,112 @@ __device__ __forceinline__ void build_block_tables(const uint32_t *s_sa, const u
         if (kMax) T.mx[B] = mx;
         T.ldn[B] = lo < first ? lo : first;
         T.lup[B] = lo < last ? lo : last;
+    } else if (B < kNumBlk + 2) {  // the two entries outside: nothing qualifies there, no minimum changes
+        const int o = B == kNumBlk ? -1 : kNumBlk;
+        T.mn[o] = 0xffffffffu;
+        if (kMax) T.mx[o] = 0u;
+        T.ldn[o] = 0xffffffffu;
+        T.lup[o] = 0xffffffffu;
+    }
+}
+
+// Rounds A, B and C of ONE kind of search (kGreater, kUp) for the unfinished searches of a wavefront, 64 at a time.
+// list: ranks (index in the wave) still searching after round 0, cnt of them; list_b: scratch of the same size.
+template <bool kGreater, bool kUp, bool kHasPos, typename ThrGt>
+__device__ __forceinline__ void lds_search_tail(const uint32_t *s_sa, const uint32_t *s_lcp, const BlockTables &T, int w,
+                                                uint32_t *res_len, uint32_t *res_pos, const uint16_t *list, uint32_t cnt,
+                                                uint16_t *list_b, ThrGt thr_gt, uint32_t far_bit) {
+    const int lane = lane_id();
+    const uint64_t lt = lanemask_lt();
+    // ---- round A: kStepA more steps ------------------------------------------------------------
+    uint32_t cnt_b = 0;
+    for (uint32_t c0 = 0; c0 < cnt; c0 += 64) {
+        const bool have = c0 + lane < cnt;
+        const int tl = have ? (int)list[c0 + lane] : 0;
+        const int t = w * kLdsPerWave + tl;
+        const int li = t + kLdsReach;
+        bool pending = false;
+        if (have) {
+            const uint32_t i = s_sa[li];
+            uint32_t m = res_len[t], pos = kNoPos;
+            const int st = lds_scan_round<kStepA, kGreater, kUp>(s_sa, s_lcp, li, kLdsStep0, kGreater ? thr_gt(i) : i, m, pos);
+            pending = st == 2;
+            res_len[t] = m;
+            if (kHasPos) res_pos[t] = (st == 1) ? pos : kNoPos;
+        }
+        const uint64_t bal = __ballot(pending);
+        if (pending) list_b[cnt_b + (uint32_t)__popcll(bal & lt)] = (uint16_t)tl;
+        cnt_b += (uint32_t)__popcll(bal);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- rounds B + C: by blocks, then inside the block that stops the search ---------------------
+    const uint32_t *tv = kGreater ? T.mx : T.mn;
+    const uint32_t *tc = kUp ? T.lup : T.ldn;
+    for (uint32_t c0 = 0; c0 < cnt_b; c0 += 64) {
+        const bool have = c0 + lane < cnt_b;
+        const int tl = have ? (int)list_b[c0 + lane] : 0;
+        const int t = w * kLdsPerWave + tl;
+        const int li = t + kLdsReach;
+        const uint32_t i = s_sa[li];
+        const uint32_t x = kGreater ? thr_gt(i) : i;
+        // first block beyond the kLdsStep0 + kStepA ranks already passed (it may overlap them); the 16 blocks from
+        // there reach at most one block outside the staged span (the padded table entries)
+        const int b0 = kUp ? (li - (kLdsStep0 + kStepA + 1)) >> 4 : (li + (kLdsStep0 + kStepA + 1)) >> 4;
+        uint32_t c[kBlk], v[kBlk];
+#pragma unroll
+        for (int j = 0; j < kBlk; ++j) {
+            const int B = kUp ? b0 - j : b0 + j;
+            c[j] = tc[B];
+            v[j] = tv[B];
+        }
+        // run: the minimum in front of the block that stops the search (the first one that holds a qualifying suffix),
+        // or over all 16 blocks -- the bound the search leaves the reach with
+        uint32_t run = have ? res_len[t] : 0xffffffffu;
+        int jstar = -1;
+        bool alive = true;
+#pragma unroll
+        for (int j = 0; j < kBlk; ++j) {
+            const uint32_t rk = c[j] < run ? c[j] : run;
+            const bool qual = kGreater ? v[j] > x : v[j] < x;
+            const bool stop = alive && qual;
+            jstar = stop ? j : jstar;
+            alive = alive != stop;  // (alive && !qual, without a second comparison)
+            run = alive ? rk : run;
+        }
+        const bool inside = have && jstar >= 0;
+        // round C: the ranks of block Bs, nearest first: anchor = the rank just in front of the block
+        const int Bs = kUp ? b0 - jstar : b0 + jstar;
+        const int anchor = inside ? (kUp ? kBlk * Bs + kBlk : kBlk * Bs - 1) : li;
+        uint32_t m = run, pos = kNoPos;
+        const int st = lds_scan_round<kBlk, kGreater, kUp>(s_sa, s_lcp, anchor, 0, x, m, pos);
+        if (have) {
+            // inside: the block holds a qualifying suffix, so the scan ends there (st 0 or 1); otherwise the search
+            // left the reach
+            res_len[t] = inside ? m : far_mark(run, far_bit);
+            if (kHasPos) res_pos[t] = (inside && st == 1) ? pos : kNoPos;
+        }
     }
 }
 
 // kCompact: only some of the ranks search (reverse-complement mode: the ranks of the original strand, half of
 // them) -- they are gathered first, so that round 0 runs over full rows of searching ranks instead of spending
 // its instructions on rows that are half idle.
+// list0 / list1: NS lists of kLdsPerWave entries each, one per kind of search (search k: greater = k >= 2,
+// up = k even), so that every round runs with kind and direction known at compile time.
 template <int NS, int NP, bool kCompact = false, typename Active, typename ThrGt>
 __device__ __forceinline__ void lds_search_wave_blocks(const uint32_t *s_sa, const uint32_t *s_lcp,
                                                        const BlockTables &T, uint32_t n, uint32_t base,
                                                        uint32_t *res_len, uint32_t *res_pos, uint16_t *list0,
                                                        uint16_t *list1, Active active, ThrGt thr_gt,
                                                        uint32_t far_bit, unsigned long long *phase_clock = nullptr) {
+    static_assert(NS == 2 || NS == 4, "searches: smaller up / down, then greater up / down");
     const int lane = lane_id();
     const int w = threadIdx.x >> 6;
     const uint64_t lt = lanemask_lt();
-    uint32_t cnt = 0;
+    uint32_t cnt[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) cnt[k] = 0;
 
     // ---- round 0: every rank, every search, steps 1..kLdsStep0 --------------------------------
     uint32_t rows = kLdsPerWave / 64, n_act = kLdsPerWave;
@@ -232,114 +328,43 @@ __device__ __forceinline__ void lds_search_wave_blocks(const uint32_t *s_sa, con
         const int li = t + kLdsReach;
         const uint32_t i = s_sa[li];
         const bool valid = kCompact ? have : (rr < n && active(i));
-#pragma unroll
-        for (int k = 0; k < NS; ++k) {
-            const bool greater = k >= 2, up = (k & 1) == 0;
+        auto search = [&](auto kk) {
+            constexpr int k = decltype(kk)::value;
+            constexpr bool greater = k >= 2, up = (k & 1) == 0;
             uint32_t m = 0xffffffffu, pos = kNoPos;
             int st = 0;
-            if (valid) st = lds_scan_round<kLdsStep0>(s_sa, s_lcp, li, 0, greater, up, greater ? thr_gt(i) : i, m, pos);
+            if (valid) st = lds_scan_round<kLdsStep0, greater, up>(s_sa, s_lcp, li, 0, greater ? thr_gt(i) : i, m, pos);
             if (have) {  // (kCompact: the results of ranks that do not search are never read)
                 res_len[k * kLdsTile + t] = (st == 0) ? 0u : m;
                 if (k < NP) res_pos[k * kLdsTile + t] = (st == 1) ? pos : kNoPos;
             }
             const bool pending = st == 2;
             const uint64_t bal = __ballot(pending);
-            if (pending) list0[cnt + (uint32_t)__popcll(bal & lt)] = (uint16_t)(tl | (k << 8));  // rank in the wave | search << 8
-            cnt += (uint32_t)__popcll(bal);
+            if (pending) list0[k * kLdsPerWave + cnt[k] + (uint32_t)__popcll(bal & lt)] = (uint16_t)tl;
+            cnt[k] += (uint32_t)__popcll(bal);
+        };
+        search(std::integral_constant<int, 0>());
+        search(std::integral_constant<int, 1>());
+        if constexpr (NS > 2) {
+            search(std::integral_constant<int, 2>());
+            search(std::integral_constant<int, 3>());
         }
     }
     if (phase_clock) phase_clock[0] = __builtin_readcyclecounter();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
-    // ---- round A: kStepA more steps for the searches still going ---------------------------------
-    uint32_t cnt_b = 0;
-    for (uint32_t c0 = 0; c0 < cnt; c0 += 64) {
-        const bool have = c0 + lane < cnt;
-        const uint32_t item = have ? list0[c0 + lane] : 0u;
-        const int tl = item & 255, k = (item >> 8) & 3;
-        const int t = w * kLdsPerWave + tl;
-        const int li = t + kLdsReach;
-        const bool greater = k >= 2, up = (k & 1) == 0;
-        bool pending = false;
-        if (have) {
-            const uint32_t i = s_sa[li];
-            uint32_t m = res_len[k * kLdsTile + t], pos = kNoPos;
-            const int st = lds_scan_round<kStepA>(s_sa, s_lcp, li, kLdsStep0, greater, up, greater ? thr_gt(i) : i, m, pos);
-            pending = st == 2;
-            res_len[k * kLdsTile + t] = (st == 0) ? 0u : m;
-            if (k < NP) res_pos[k * kLdsTile + t] = (st == 1) ? pos : kNoPos;
-        }
-        const uint64_t bal = __ballot(pending);
-        if (pending) list1[cnt_b + (uint32_t)__popcll(bal & lt)] = (uint16_t)item;
-        cnt_b += (uint32_t)__popcll(bal);
+    // ---- rounds A, B, C per kind of search ---------------------------------------------------------
+    lds_search_tail<false, true, (0 < NP)>(s_sa, s_lcp, T, w, res_len, res_pos, list0, cnt[0], list1, thr_gt, far_bit);
+    lds_search_tail<false, false, (1 < NP)>(s_sa, s_lcp, T, w, res_len + kLdsTile, res_pos + kLdsTile, list0 + kLdsPerWave,
+                                            cnt[1], list1 + kLdsPerWave, thr_gt, far_bit);
+    if constexpr (NS > 2) {
+        lds_search_tail<true, true, (2 < NP)>(s_sa, s_lcp, T, w, res_len + 2 * kLdsTile, res_pos + (2 < NP ? 2 : 0) * kLdsTile,
+                                              list0 + 2 * kLdsPerWave, cnt[2], list1 + 2 * kLdsPerWave, thr_gt, far_bit);
+        lds_search_tail<true, false, (3 < NP)>(s_sa, s_lcp, T, w, res_len + 3 * kLdsTile, res_pos + (3 < NP ? 3 : 0) * kLdsTile,
+                                               list0 + 3 * kLdsPerWave, cnt[3], list1 + 3 * kLdsPerWave, thr_gt, far_bit);
     }
-    if (phase_clock) phase_clock[1] = __builtin_readcyclecounter();
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-
-    // ---- rounds B + C: by blocks, then inside the block that stops the search ---------------------
-    for (uint32_t c0 = 0; c0 < cnt_b; c0 += 64) {
-        const bool have = c0 + lane < cnt_b;
-        const uint32_t item = have ? list1[c0 + lane] : 0u;
-        const int tl = item & 255, k = (item >> 8) & 3;
-        const int t = w * kLdsPerWave + tl;
-        const int li = t + kLdsReach;
-        const bool greater = k >= 2, up = (k & 1) == 0;
-        const uint32_t i = s_sa[li];
-        const uint32_t x = greater ? thr_gt(i) : i;
-        const uint32_t flip = greater ? 0xffffffffu : 0u;
-        const uint32_t xf = x ^ flip;
-        const uint32_t m_in = have ? res_len[k * kLdsTile + t] : 0xffffffffu;
-        // first block beyond the kLdsStep0 + kStepA ranks already passed (it may overlap them)
-        const int b0 = up ? (li - (kLdsStep0 + kStepA + 1)) >> 4 : (li + (kLdsStep0 + kStepA + 1)) >> 4;
-        const uint32_t *tv = greater ? T.mx : T.mn;
-        const uint32_t *tc = up ? T.lup : T.ldn;
-        uint32_t c[kBlk], v[kBlk];
-#pragma unroll
-        for (int j = 0; j < kBlk; ++j) {
-            const int B = up ? b0 - j : b0 + j;
-            const bool in = have && B >= 0 && B < kNumBlk;
-            const int Bc = in ? B : 0;
-            const uint32_t cc = tc[Bc], vv = tv[Bc];
-            c[j] = in ? cc : 0xffffffffu;
-            v[j] = in ? (vv ^ flip) : 0xffffffffu;  // (flipped: "qualifies" is "< xf" for both kinds; out of range never does)
-        }
-        uint32_t run = m_in;
-#pragma unroll
-        for (int j = 0; j < kBlk; ++j) {
-            run = c[j] < run ? c[j] : run;
-            c[j] = run;
-        }
-        int jstar = -1;
-        uint32_t m_before = run;  // no stop: the bound the search leaves the reach with
-#pragma unroll
-        for (int j = kBlk - 1; j >= 0; --j) {
-            const bool stop = c[j] == 0 || v[j] < xf;
-            jstar = stop ? j : jstar;
-            m_before = stop ? (j ? c[j - 1] : m_in) : m_before;
-        }
-        const bool inside = have && jstar >= 0;
-        // round C: the ranks of block Bs, nearest first: anchor = the rank just in front of the block
-        const int Bs = up ? b0 - jstar : b0 + jstar;
-        const int anchor = inside ? (up ? kBlk * Bs + kBlk : kBlk * Bs - 1) : li;
-        uint32_t m = m_before, pos = kNoPos;
-        const int st = lds_scan_round<kBlk>(s_sa, s_lcp, anchor, 0, greater, up, x, m, pos);
-        if (have) {
-            uint32_t out_len, out_pos = kNoPos;
-            if (inside && st == 1) {
-                out_len = m;
-                out_pos = pos;
-            } else if (inside && st == 0) {
-                out_len = 0;
-            } else {  // left the reach (st == 2 inside a stopping block cannot happen; it would be treated the same way)
-                out_len = far_mark(m_before, far_bit);
-            }
-            res_len[k * kLdsTile + t] = out_len;
-            if (k < NP) res_pos[k * kLdsTile + t] = out_pos;
-        }
-    }
-    if (phase_clock) phase_clock[2] = __builtin_readcyclecounter();
+    if (phase_clock) phase_clock[1] = phase_clock[2] = __builtin_readcyclecounter();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }

@@ -66,12 +66,12 @@ __global__ __launch_bounds__(kLdsThreads) void rc_tile_kernel(const uint32_t *__
     __shared__ uint32_t s_len[NS * kLdsTile];
     __shared__ uint32_t s_pos[NP * kLdsTile];
     __shared__ uint16_t s_list[kLdsWaves][2][NS * kLdsPerWave];
-    __shared__ uint32_t s_blk[4 * kNumBlk];
+    __shared__ uint32_t s_blk[4 * kBlkTableLen];
     const uint32_t base = blockIdx.x * (uint32_t)kLdsTile;
     const uint32_t shard = blockIdx.x % kQShards;
     stage_tile(sa, lcp, m, base, s_sa, s_lcp, pending_min, pending_flag);
     __syncthreads();
-    const BlockTables T{s_blk, s_blk + kNumBlk, s_blk + 2 * kNumBlk, s_blk + 3 * kNumBlk};
+    const BlockTables T = block_tables<true>(s_blk);
     build_block_tables<true>(s_sa, s_lcp, T);
     __syncthreads();
     // the block tables of the tile's own ranks are the first level of the three pyramids (lpnf.hip, lpf_tile_kernel)
