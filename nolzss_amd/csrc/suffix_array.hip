@@ -905,27 +905,38 @@ __device__ __forceinline__ void lower_min(uint32_t *p, uint32_t v) {
 constexpr uint32_t kPerNone = 0xffffffffu;   // gq: no distance seen yet
 constexpr uint32_t kPerBad = 0x80000000u;    // gq: flag "leave this group alone" (positions are below 2^31 here)
 
-// count[0] += members beyond the first `limit` of their group, count[1] += groups with more than `limit` members
-// (the list is in slot order: a member's index inside its group is slot - head): one atomic pair per workgroup
+// count[0] += members beyond the first `limit` of their group, count[1] += groups with more than `limit` members,
+// count[2] += groups (the list is in slot order: a member's index inside its group is slot - head), count[3] +=
+// members whose successor in the list belongs to the same group and starts at most `near` symbols away in the text
+// (tied members keep the order of their text positions through every stable step of the construction, so these are
+// -- as an estimate, used to decide whether a pass is worth its sorts -- the members of periodic runs): one atomic
+// per counter and workgroup
 __global__ __launch_bounds__(kThreads) void per_count_large_kernel(const uint32_t *__restrict__ act_slot,
                                                                    const uint32_t *__restrict__ act_grp, uint32_t m,
-                                                                   uint32_t limit, uint32_t *__restrict__ count) {
-    uint32_t mine = 0, groups = 0;
+                                                                   const uint32_t *__restrict__ sa, uint32_t limit,
+                                                                   uint32_t near, uint32_t *__restrict__ count) {
+    uint32_t c[4] = {0, 0, 0, 0};
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x; a < m; a += stride) {
-        const uint32_t j = act_slot[a] - act_grp[a];
-        mine += j >= limit ? 1u : 0u;
-        groups += j == limit ? 1u : 0u;
+        const uint32_t slot = act_slot[a], g = act_grp[a];
+        const uint32_t j = slot - g;
+        c[0] += j >= limit ? 1u : 0u;
+        c[1] += j == limit ? 1u : 0u;
+        c[2] += j == 0 ? 1u : 0u;
+        if (a + 1 < m && act_grp[a + 1] == g) {
+            const uint32_t p = sa[slot], q = sa[act_slot[a + 1]];
+            const uint32_t d = p < q ? q - p : p - q;
+            c[3] += d <= near ? 1u : 0u;
+        }
     }
-    mine = wave_reduce(mine, OpAdd<uint32_t>());
-    groups = wave_reduce(groups, OpAdd<uint32_t>());
-    __shared__ uint32_t s_part[2][kThreads / 64];
-    if (lane_id() == 0) {
-        s_part[0][threadIdx.x >> 6] = mine;
-        s_part[1][threadIdx.x >> 6] = groups;
+    __shared__ uint32_t s_part[4][kThreads / 64];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t r = wave_reduce(c[k], OpAdd<uint32_t>());
+        if (lane_id() == 0) s_part[k][threadIdx.x >> 6] = r;
     }
     __syncthreads();
-    if (threadIdx.x < 2) {
+    if (threadIdx.x < 4) {
         uint32_t t = 0;
         for (int i = 0; i < kThreads / 64; ++i) t += s_part[threadIdx.x][i];
         if (t) atomicAdd(count + threadIdx.x, t);
@@ -2347,16 +2358,21 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
 
     // how the tied suffixes are grouped decides which of the two passes can do anything: in_large = members beyond
     // the first kRunGroupMax of their group, large_members = members of groups with more than kRunGroupMax members
-    uint32_t in_large = 0, large_members = 0;
-    uint32_t *d_large = arena.alloc<uint32_t>(2);
+    uint32_t in_large = 0, large_members = 0, tied_groups = 0, near_members = 0;
+    uint32_t *d_large = arena.alloc<uint32_t>(4);
     if (pair_runs) {
-        HIP_CHECK(hipMemsetAsync(d_large, 0, 2 * sizeof(uint32_t), s));
-        per_count_large_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(act_slot[a_cur], act_grp[a_cur], m, kRunGroupMax, d_large);
+        HIP_CHECK(hipMemsetAsync(d_large, 0, 4 * sizeof(uint32_t), s));
+        per_count_large_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(act_slot[a_cur], act_grp[a_cur], m, sa, kRunGroupMax,
+                                                                        kPerVerifyMax, d_large);
         KERNEL_CHECK();
-        uint32_t h2[2] = {0, 0};
-        ctx.read_back(d_large, h2, 2);
-        in_large = h2[0];
-        large_members = h2[0] + kRunGroupMax * h2[1];
+        uint32_t h4[4] = {0, 0, 0, 0};
+        ctx.read_back(d_large, h4, 4);
+        in_large = h4[0];
+        large_members = h4[0] + kRunGroupMax * h4[1];
+        tied_groups = h4[2];
+        near_members = h4[3];
+        if (trace) fprintf(stderr, "[nolzss]   %u tied suffixes in %u groups, %u of them in groups of more than %u, %u next to a member at most %u symbols away\n",
+                           m, tied_groups, large_members, kRunGroupMax, near_members, kPerVerifyMax);
     }
 
     // one range-minimum pyramid over the LCP values known so far; the regroup kernel keeps it current
@@ -2378,10 +2394,12 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         if (periodic_off || m == 0 || n >= 0x80000000u || wlen < n || per_attempts >= 3) return false;
         ProfScope ps(ctx.profiler(), "sa_periodic", s);
         const uint32_t *slot = act_slot[a_cur], *grp = act_grp[a_cur];
-        if (per_attempts == 0 && in_large < m / 8) {
+        if (per_attempts == 0 && (in_large < m / 8 || near_members < m / 32)) {
             // worth its two sorts only where large groups hold a good part of what is tied: copies of long
             // regions tie in groups of a few members (the pair-run pass takes those), runs of a short period
-            // in groups as large as the runs are long
+            // in groups as large as the runs are long -- and only where tied suffixes lie close to each other in
+            // the text: two dozen copies of a genome tie in groups of two dozen members a genome apart (the
+            // first sort of the pass, 28 of 212 ms on 24 genomes of 2^28 bases in all, found that out before)
             per_attempts = 3;  // (never again for this text)
             return false;
         }
@@ -2466,7 +2484,13 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     // which it runs, the tests set 1)
     // (the pass takes groups of up to kRunGroupMax members: where most of what is tied sits in larger groups -- 17
     // and more copies of a genome -- its four sweeps over the text finish next to nothing: 120 of 300 ms on 24 genomes)
-    const bool runs_can_help = pair_runs_min >= 0 || large_members <= m / 2;
+    // (and a group of k copies is finished by about k - 1 passes, each a sweep over the whole text that costs as much as
+    // two doubling rounds: 168 ms for the four passes of five genomes, 120 ms for one pass of twelve that finished 5 %
+    // of what was tied, where the doubling rounds from the depth the direct round reached take 85 ms; three genomes:
+    // 115 ms with two passes, 92 ms with the doubling rounds; two genomes: 72 against 82 ms, two exact copies 79 against
+    // 279 ms -- the passes run where the tied suffixes sit in pairs: mean group size at most 2.5)
+    static const uint32_t runs_avg4 = getenv("NOLZSS_PAIR_RUNS_AVG4") ? (uint32_t)atoi(getenv("NOLZSS_PAIR_RUNS_AVG4")) : 10u;  // 4 x mean group size
+    const bool runs_can_help = pair_runs_min >= 0 || (large_members <= m / 2 && (uint64_t)m * 4 <= (uint64_t)tied_groups * runs_avg4);
     for (int pass = 0; pair_runs && runs_can_help && pass < 10 && m > 0 && (pair_runs_min >= 0 ? (long long)m >= pair_runs_min : m >= n / 16); ++pass) {
         ProfScope ps(ctx.profiler(), "sa_pair_runs", s);
         uint32_t *link = tmp_a, *gsz = rank_val, *rev = tmp_b, *end_of = tmp_c, *togo = scratch_idx;
