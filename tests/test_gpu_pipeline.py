@@ -266,6 +266,37 @@ print("ok", len(texts))
     assert len(done) >= 15 and sum(done) > 100000, done  # the path ran and finished pairs
 
 
+@pytest.mark.parametrize("copies,base_len", [(5, 40_000), (17, 12_000), (33, 6_000), (65, 4_000), (130, 2_500),
+                                             (300, 1_200)])
+def test_collections_of_similar_genomes(native, copies, base_len):
+    """k genomes a few substitutions apart (the reference's use case for whole collections,
+    /root/reference/src/cpp/fasta_processor.cpp:298-341): nearly every suffix ties with k - 1 others for hundreds
+    to thousands of symbols.  Groups of up to 64 members go through the pair comparisons of the direct round, what
+    it leaves and every larger group through the doubling rounds -- groups of 65 .. 1024 members sorted in LDS
+    (mid_sort_kernel), larger ones by the radix sort.  Factors, suffix array, LCP and inverse against the oracle."""
+    rng = np.random.default_rng(1000 + copies)
+    base = gen.random_dna(base_len, 500 + copies)
+    parts = [base]
+    for _ in range(copies - 1):
+        y = base.copy()
+        idx = rng.integers(0, len(y), size=max(1, len(y) // 1000))
+        y[idx] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=len(idx))]
+        parts.append(y)
+    t = bytes(np.concatenate(parts))
+    got = native.factorize_array(t)
+    exp = oracle.factors_array(t)
+    assert len(got) == len(exp)
+    for k in ("start", "length", "ref"):
+        assert np.array_equal(got[k], exp[k]), k
+    d = native.debug_arrays(t)
+    sa = oracle.suffix_array(t)
+    assert np.array_equal(d["sa"].astype(np.int64), sa.astype(np.int64))
+    assert np.array_equal(d["lcp"][:len(t)].astype(np.int64), oracle.lcp_array(t, sa).astype(np.int64))
+    isa = np.empty(len(t), dtype=np.int64)
+    isa[sa] = np.arange(len(t))
+    assert np.array_equal(d["isa"].astype(np.int64), isa)
+
+
 def test_periodic_runs_pass():
     """Runs of a short period tie the suffixes of a run in groups that only log2(run length) doubling
     rounds would resolve; the periodic-run pass orders them arithmetically (suffix_array.hip, "Periodic
