@@ -492,30 +492,86 @@ const DnaTables &dna_tables() {
     static const DnaTables t;
     return t;
 }
+// Bytes that are all written right after the allocation: no value-initialisation (resize() of a std::vector<uint8_t>
+// zeroes -- and page-faults -- half a gigabyte on one thread for a reference + target pair of 2^27 bases each).
+template <typename T> struct DefaultInitAllocator : std::allocator<T> {
+    template <typename U> struct rebind { using other = DefaultInitAllocator<U>; };
+    using std::allocator<T>::allocator;
+    template <typename U> void construct(U *p) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new (static_cast<void *>(p)) U; }
+    template <typename U, typename... Args> void construct(U *p, Args &&...args) { ::new (static_cast<void *>(p)) U(std::forward<Args>(args)...); }
+};
+using HostBytes = std::vector<uint8_t, DefaultInitAllocator<uint8_t>>;
+
+// fn(lo, hi) over [0, n) in contiguous pieces on up to 16 host threads (one piece on the caller's thread for short
+// inputs): validation, case folding and reverse complement of sequences as long as the device factorizes in tens of
+// milliseconds were 250 ms on one core for that pair
+template <typename Fn> void host_parallel(size_t n, Fn fn) {
+    constexpr size_t kMinPiece = size_t(4) << 20;
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t pieces = std::min<size_t>({(size_t)(hw ? hw : 1u), (size_t)16, n / kMinPiece});
+    if (pieces <= 1) {
+        fn((size_t)0, n);
+        return;
+    }
+    const size_t per = (n + pieces - 1) / pieces;
+    std::vector<std::thread> pool;
+    std::exception_ptr err;
+    std::mutex mu;
+    for (size_t k = 1; k < pieces; ++k)
+        pool.emplace_back([&, k] {
+            try {
+                fn(std::min(n, k * per), std::min(n, (k + 1) * per));
+            } catch (...) {
+                std::lock_guard<std::mutex> g(mu);
+                err = std::current_exception();
+            }
+        });
+    try {
+        fn((size_t)0, std::min(n, per));
+    } catch (...) {
+        std::lock_guard<std::mutex> g(mu);
+        err = std::current_exception();
+    }
+    for (auto &t : pool) t.join();
+    if (err) std::rethrow_exception(err);
+}
+
 // index of the first byte that is not a nucleotide, n if there is none
 size_t first_invalid_nucleotide(const char *s, size_t n) {
     const DnaTables &t = dna_tables();
-    constexpr size_t kBlock = 4096;
-    for (size_t at = 0; at < n; at += kBlock) {
-        const size_t stop = std::min(n, at + kBlock);
-        uint8_t bad = 0;
-        for (size_t j = at; j < stop; ++j) bad |= t.invalid[(unsigned char)s[j]];
-        if (bad)
-            for (size_t j = at; j < stop; ++j)
-                if (t.invalid[(unsigned char)s[j]]) return j;
-    }
-    return n;
+    std::atomic<size_t> first{n};
+    host_parallel(n, [&](size_t lo, size_t hi) {
+        constexpr size_t kBlock = 4096;
+        for (size_t at = lo; at < hi && at < first.load(std::memory_order_relaxed); at += kBlock) {
+            const size_t stop = std::min(hi, at + kBlock);
+            uint8_t bad = 0;
+            for (size_t j = at; j < stop; ++j) bad |= t.invalid[(unsigned char)s[j]];
+            if (bad)
+                for (size_t j = at; j < stop; ++j)
+                    if (t.invalid[(unsigned char)s[j]]) {
+                        size_t cur = first.load();
+                        while (j < cur && !first.compare_exchange_weak(cur, j)) {
+                        }
+                        return;
+                    }
+        }
+    });
+    return first.load();
 }
 // dst = upper(src) for validated nucleotides (clearing bit 5 turns acgt into ACGT)
 void copy_upper(uint8_t *dst, const char *src, size_t n) {
-    for (size_t j = 0; j < n; ++j) dst[j] = (uint8_t)src[j] & 0xdfu;
+    host_parallel(n, [&](size_t lo, size_t hi) {
+        for (size_t j = lo; j < hi; ++j) dst[j] = (uint8_t)src[j] & 0xdfu;
+    });
 }
 void copy_reverse_complement(uint8_t *dst, const char *src, size_t n) {
     const DnaTables &t = dna_tables();
-    for (size_t j = 0; j < n; ++j) dst[j] = t.comp[(unsigned char)src[n - 1 - j]];
+    host_parallel(n, [&](size_t lo, size_t hi) {
+        for (size_t j = lo; j < hi; ++j) dst[j] = t.comp[(unsigned char)src[n - 1 - j]];
+    });
 }
 
-void prepare_w_rc(const char *const *seqs, const size_t *lens, size_t k, std::vector<uint8_t> &S,
+void prepare_w_rc(const char *const *seqs, const size_t *lens, size_t k, HostBytes &S,
                   size_t &original_length, std::vector<uint64_t> &sentinels) {
     S.clear();
     sentinels.clear();
@@ -696,7 +752,7 @@ int nolzss_prepare_multiple_dna_w_rc(const char *const *seqs, const size_t *lens
         *sentinel_positions = nullptr;
         *S_len = *original_length = *n_sentinels = 0;
         if (k && (!seqs || !lens)) throw std::invalid_argument("sequence array is null");
-        std::vector<uint8_t> buf;
+        HostBytes buf;
         std::vector<uint64_t> sent;
         size_t orig = 0;
         prepare_w_rc(seqs, lens, k, buf, orig, sent);
@@ -874,7 +930,7 @@ size_t dna_w_reference(const char *ref, size_t ref_len, const char *tgt, size_t 
     if ((ref_len && !ref) || (tgt_len && !tgt)) throw std::invalid_argument("sequence pointer is null");
     const char *seqs[2] = {ref, tgt};
     const size_t lens[2] = {ref_len, tgt_len};
-    std::vector<uint8_t> S;
+    HostBytes S;
     std::vector<uint64_t> sent;
     size_t orig = 0;
     prepare_w_rc(seqs, lens, 2, S, orig, sent);  // factorizer.cpp:827-828
@@ -1108,7 +1164,7 @@ FastaParse parse_fasta(const char *path, bool strict) {
 }
 
 // restates prepare_multiple_dna_sequences_no_rc, /root/reference/src/cpp/factorizer.cpp:199-294
-void prepare_no_rc(const char *const *seqs, const size_t *lens, size_t k, std::vector<uint8_t> &S,
+void prepare_no_rc(const char *const *seqs, const size_t *lens, size_t k, HostBytes &S,
                    size_t &original_length, std::vector<uint64_t> &sentinels) {
     S.clear();
     sentinels.clear();
@@ -1178,7 +1234,7 @@ void factorize_fasta(const char *path, bool with_rc, bool strict, int device, Fa
         ptrs.push_back(q.data());
         lens.push_back(q.size());
     }
-    std::vector<uint8_t> S;
+    HostBytes S;
     std::vector<uint64_t> sent;
     size_t orig = 0;
     if (with_rc) {
@@ -1215,7 +1271,7 @@ void factorize_ref_target_fasta(const char *ref_path, const char *tgt_path, bool
         ptrs.push_back(q.data());
         lens.push_back(q.size());
     }
-    std::vector<uint8_t> S;
+    HostBytes S;
     std::vector<uint64_t> sent;
     size_t orig = 0;
     prepare_w_rc(ptrs.data(), lens.data(), ptrs.size(), S, orig, sent);
@@ -1313,7 +1369,7 @@ int nolzss_prepare_multiple_dna_no_rc(const char *const *seqs, const size_t *len
         *sentinel_positions = nullptr;
         *S_len = *original_length = *n_sentinels = 0;
         if (k && (!seqs || !lens)) throw std::invalid_argument("sequence array is null");
-        std::vector<uint8_t> buf;
+        HostBytes buf;
         std::vector<uint64_t> sent;
         size_t orig = 0;
         prepare_no_rc(seqs, lens, k, buf, orig, sent);

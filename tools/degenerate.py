@@ -53,9 +53,20 @@ for name, t in cases.items():
     t0 = time.time(); z = native.count_factors(t); dt = time.time() - t0
     print(f"2^{lg} {name}: {dt*1e3:.1f} ms, z={z}", flush=True)
 # a reference and a target of n / 2 bases each, 0.1 % apart, through the reference-sequence entry point
-ref = gen.random_dna(n // 2, 77)
-tgt = mutated(ref, 78)
-t0 = time.time()
-f = native.factorize_dna_w_reference_seq(ref.tobytes().decode(), tgt.tobytes().decode()) if lg <= 24 else None
-if f is not None:
-    print(f"2^{lg} reference + target through factorize_dna_w_reference_seq (tuples): {(time.time()-t0)*1e3:.1f} ms, z={len(f)}", flush=True)
+# (factorize_dna_w_reference_seq up to 2^24: the Python tuples of millions of factors take seconds; beyond that the
+#  binary-file form of the same C entry point, nolzss_factorize_dna_w_reference_seq with a file for the records)
+if not only or any("reference" in o for o in only):
+    import os, tempfile
+    ref = gen.random_dna(n // 2, 77)
+    tgt = mutated(ref, 78)
+    rs, ts = ref.tobytes().decode(), tgt.tobytes().decode()
+    if lg <= 24:
+        t0 = time.time()
+        f = native.factorize_dna_w_reference_seq(rs, ts)
+        print(f"2^{lg} reference + target through factorize_dna_w_reference_seq (tuples): {(time.time()-t0)*1e3:.1f} ms, z={len(f)}", flush=True)
+    out = os.path.join(tempfile.gettempdir(), f"nolzss_degenerate_ref_{os.getpid()}.bin")
+    t0 = time.time()
+    z = native.factorize_dna_w_reference_seq_file(rs, ts, out)
+    print(f"2^{lg} reference + target of 2^{lg-1} bases each through factorize_dna_w_reference_seq_file: {(time.time()-t0)*1e3:.1f} ms, "
+          f"z={z}, {os.path.getsize(out)} bytes written", flush=True)
+    os.remove(out)
