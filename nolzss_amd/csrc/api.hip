@@ -1695,11 +1695,13 @@ bool run_merged_chunk(Context &ctx, const uint8_t *const *texts, const size_t *l
         uint32_t *sa = arena.alloc<uint32_t>(n);
         uint32_t *isa = arena.alloc<uint32_t>(n);
         uint32_t *lcp = arena.alloc<uint32_t>(n + 1);
-        build_suffix_array(ctx, text, sa, isa, lcp);
+        // (isa: left to the permutation of the codes when the direct rounds finish the suffix array, pipeline.hpp)
+        bool isa_deferred = false;
+        build_suffix_array(ctx, text, sa, isa, lcp, &isa_deferred);
         // (pyramids: allocated here, filled by build_lstar -- first level from the candidate kernel)
         const Pyramid Psa = alloc_pyramid(sa, (uint32_t)n, arena), Plcp = alloc_pyramid(lcp, (uint32_t)n + 1, arena);
         uint32_t *lstar = arena.alloc<uint32_t>(n);
-        build_lstar(ctx, (uint32_t)n, sa, isa, lcp, Psa, Plcp, lstar, nullptr, &text);
+        build_lstar(ctx, (uint32_t)n, sa, isa, lcp, Psa, Plcp, lstar, isa_deferred ? isa : nullptr, &text);
         // counts come from the factor starts; records are built only when the caller wants them, and leave
         // the factor kernel in record coordinates
         z = resolve_chain(ctx, (uint32_t)n, 0, lstar, sa, isa, lcp, Psa, Plcp, fs ? &d_recs : nullptr, 0, nullptr,
@@ -1830,11 +1832,12 @@ bool run_merged_chunk_device(Context &ctx, const void *const *d_texts, const siz
     uint32_t *sa = arena.alloc<uint32_t>(n);
     uint32_t *isa = arena.alloc<uint32_t>(n);
     uint32_t *lcp = arena.alloc<uint32_t>(n + 1);
-    build_suffix_array(ctx, text, sa, isa, lcp);
+    bool isa_deferred = false;  // (as in run_merged_chunk)
+    build_suffix_array(ctx, text, sa, isa, lcp, &isa_deferred);
     // (pyramids: allocated here, filled by build_lstar -- first level from the candidate kernel)
     const Pyramid Psa = alloc_pyramid(sa, (uint32_t)n, arena), Plcp = alloc_pyramid(lcp, (uint32_t)n + 1, arena);
     uint32_t *lstar = arena.alloc<uint32_t>(n);
-    build_lstar(ctx, (uint32_t)n, sa, isa, lcp, Psa, Plcp, lstar, nullptr, &text);
+    build_lstar(ctx, (uint32_t)n, sa, isa, lcp, Psa, Plcp, lstar, isa_deferred ? isa : nullptr, &text);
     void *d_recs = nullptr;
     uint32_t *d_fpos = nullptr;
     const uint32_t z = resolve_chain(ctx, (uint32_t)n, 0, lstar, sa, isa, lcp, Psa, Plcp, emit ? &d_recs : nullptr, 0,
@@ -2204,12 +2207,17 @@ int nolzss_factorize_batch_device(const void *const *d_texts, const size_t *lens
             // well: 512 records of 4 Mi bases took 144 or 170 ms, whichever way a call happened to fall.  The
             // second lane therefore starts 20 ms late (NOLZSS_DEVICE_MERGE_STAGGER_MS; in bench.py: 145 / 162 / 164 ms
             // without, 146 / 146 / 145 ms with it, profiles/r03_fasta512_stagger.txt).
+            // (20 ms is a sixth of a run of 2^30 bases; shorter runs wait in proportion -- a flat 20 ms made the two runs of
+            // 64 records x 4 Mi bases, 10 ms each, follow each other on one lane: 18.8 -> 20.4 ms)
             static const long stagger_ms = getenv("NOLZSS_DEVICE_MERGE_STAGGER_MS") ? atol(getenv("NOLZSS_DEVICE_MERGE_STAGGER_MS")) : 20;
+            size_t first_bases = 0;
+            for (size_t j : chunks[0]) first_bases += lens[j];
+            const long stagger_us = (long)((double)stagger_ms * 1000.0 * std::min(1.0, (double)first_bases / (double)(size_t(1) << 30)));
             auto worker = [&](size_t w) {
                 status[w] = guarded([&] {
                     Session ses(device, nullptr, (int)w);
-                    if (w > 0 && stagger_ms > 0 && chunks.size() > 1)
-                        std::this_thread::sleep_for(std::chrono::milliseconds(stagger_ms * (long)w));
+                    if (w > 0 && stagger_us > 0 && chunks.size() > 1)
+                        std::this_thread::sleep_for(std::chrono::microseconds(stagger_us * (long)w));
                     for (;;) {
                         const size_t k = next.fetch_add(1);
                         if (k >= chunks.size()) break;

@@ -181,6 +181,20 @@ struct LocalIdxSrc {
     __device__ __forceinline__ uint64_t window(size_t) const { return 0; }
 };
 
+// the same with the list position + 1 as a second value (RankSrc): the block-diagonal permutation of a merged batch
+// delivers the inverse suffix array on the way, too
+struct LocalRankSrc {
+    using Raw = uint32_t;
+    const uint32_t *__restrict__ idx;
+    const uint32_t *__restrict__ vals;
+    __device__ __forceinline__ Raw load(size_t i, const TileExtent &) const { return idx[i]; }
+    __device__ __forceinline__ uint32_t key_of(Raw raw, size_t, const TileExtent &ext) const { return raw - ext.aux; }
+    __device__ __forceinline__ uint32_t hist_digit_of(Raw raw, size_t, int shift, const TileExtent &ext) const { return digit_of(raw - ext.aux, shift); }
+    __device__ __forceinline__ uint64_t val(size_t i) const { return (uint64_t)vals[i] | ((uint64_t)((uint32_t)i + 1u) << 32); }
+    __device__ __forceinline__ bool digits_from_window(int) const { return false; }
+    __device__ __forceinline__ uint64_t window(size_t) const { return 0; }
+};
+
 template <typename KeyT, typename Src>
 __global__ __launch_bounds__(kThreads) void rs_hist_kernel(Src src, size_t n, int shift,
                                                            uint32_t *__restrict__ tile_hist,
@@ -401,7 +415,8 @@ void radix_pass(Src src, OutT *keys_out, ValT *vals_out, size_t n, int shift, ui
         // small sorts of the doubling rounds: rs_scatter.{text|u64|u32}[.small]
         const bool small = n < (size_t(1) << 24);
         const char *cls = (std::is_same<Src, ArraySrc<KeyT>>::value || std::is_same<Src, LocalIdxSrc>::value ||
-                           std::is_same<Src, RankSrc>::value || std::is_same<Src, PairSrc>::value)
+                           std::is_same<Src, LocalRankSrc>::value || std::is_same<Src, RankSrc>::value ||
+                           std::is_same<Src, PairSrc>::value)
                               ? (sizeof(KeyT) == 8 ? (small ? "rs_scatter.u64.small" : "rs_scatter.u64")
                                                    : (small ? "rs_scatter.u32.small" : "rs_scatter.u32"))
                               : "rs_scatter.text";
@@ -578,14 +593,56 @@ __global__ __launch_bounds__(kThreads) void record_window_scatter_kernel(const I
     for (uint32_t t = threadIdx.x; t < len; t += kThreads) out[obase + t] = s_out[t];
 }
 
+// two values per pair in one 64-bit word (low half -> out, high half -> out2), as window_scatter2_kernel
+__global__ __launch_bounds__(kWindow2Threads) void record_window_scatter2_kernel(const uint16_t *__restrict__ idx,
+                                                                                 const uint64_t *__restrict__ val,
+                                                                                 uint32_t *__restrict__ out,
+                                                                                 uint32_t *__restrict__ out2,
+                                                                                 const uint32_t *__restrict__ win,
+                                                                                 int window_bits) {
+    __shared__ uint32_t s_out[2 << kWindowBitsMax];
+    const uint32_t W = 1u << window_bits;
+    uint32_t *s_a = s_out, *s_b = s_out + W;
+    const size_t base = win[3 * (size_t)blockIdx.x];
+    const size_t obase = win[3 * (size_t)blockIdx.x + 1];
+    const uint32_t len = win[3 * (size_t)blockIdx.x + 2];
+    constexpr int kBatch = 4;
+    for (uint32_t t0 = 0; t0 < len; t0 += kBatch * kWindow2Threads) {
+        uint32_t ii[kBatch];
+        uint64_t vv[kBatch];
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            const uint32_t t = t0 + (uint32_t)j * kWindow2Threads + threadIdx.x;
+            const size_t at = base + (t < len ? t : 0u);  // (no branch around the loads)
+            ii[j] = (uint32_t)idx[at];
+            vv[j] = val[at];
+        }
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            const uint32_t t = t0 + (uint32_t)j * kWindow2Threads + threadIdx.x;
+            if (t < len) {
+                s_a[ii[j] & (W - 1u)] = (uint32_t)vv[j];
+                s_b[ii[j] & (W - 1u)] = (uint32_t)(vv[j] >> 32);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < len; t += kWindow2Threads) {
+        out[obase + t] = s_a[t];
+        out2[obase + t] = s_b[t];
+    }
+}
+
 __global__ void separator_scatter_kernel(const uint32_t *__restrict__ sep, uint32_t count,
                                          const uint32_t *__restrict__ idx, const uint32_t *__restrict__ val,
-                                         uint32_t *__restrict__ out, uint32_t *__restrict__ err) {
+                                         uint32_t *__restrict__ out, uint32_t *__restrict__ err,
+                                         uint32_t *__restrict__ out2) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= count) return;
     const uint32_t r = sep[2 * k], p = sep[2 * k + 1];
     if (idx[r] != p) atomicOr(err, 1u);  // the separator suffix is the first of its record
     out[p] = val[r];
+    if (out2) out2[p] = r + 1u;
 }
 
 }  // namespace
@@ -723,7 +780,8 @@ void bucketed_scatter(uint32_t *idx[2], uint32_t *val[2], size_t count, uint32_t
             arena.rewind(amark);
             return;
         }
-        if (out2) {  // small inputs and the other shapes: the second value by a scatter of its own
+        const bool plan_path = plan && plan->seg.desc && count == n_out && n_out == plan->n;
+        if (out2 && !plan_path) {  // small inputs and the other shapes: the second value by a scatter of its own
             ProfScope ps(prof, "bucket_scatter", stream, 8.0 * (double)count);
             const unsigned g = (unsigned)std::min<size_t>(div_up(count, kThreads), 256u * 16u);
             plain_rank_scatter_kernel<<<g, kThreads, 0, stream>>>(idx[0], count, out2, n_out);
@@ -737,19 +795,29 @@ void bucketed_scatter(uint32_t *idx[2], uint32_t *val[2], size_t count, uint32_t
         uint32_t *err = arena.alloc<uint32_t>(1);
         HIP_CHECK(hipMemsetAsync(err, 0, sizeof(uint32_t), stream));
         // (32-bit indices out of this pass measured 10 % slower end to end than the low 16 bits)
-        radix_pass<uint32_t, uint16_t>(LocalIdxSrc{idx[0], val[0]}, idx16, val[1], count, plan->window_bits, hist,
-                                       plan->seg.num_tiles, 4.0 * (double)count, 14.0 * (double)count, arena, stream,
-                                       prof, plan->seg);
-        {
+        if (out2) {  // two values per pair, as one 64-bit word (val[1] holds 2 * count words in this form)
+            uint64_t *packed = reinterpret_cast<uint64_t *>(val[1]);
+            radix_pass<uint32_t, uint16_t, LocalRankSrc, uint64_t>(LocalRankSrc{idx[0], val[0]}, idx16, packed, count,
+                                                                   plan->window_bits, hist, plan->seg.num_tiles,
+                                                                   4.0 * (double)count, 18.0 * (double)count, arena, stream,
+                                                                   prof, plan->seg);
+            ProfScope ps(prof, "window_scatter", stream, 18.0 * (double)count);
+            record_window_scatter2_kernel<<<plan->num_windows, kWindow2Threads, 0, stream>>>(idx16, packed, out, out2, plan->win,
+                                                                                            plan->window_bits);
+            KERNEL_CHECK();
+        } else {
+            radix_pass<uint32_t, uint16_t>(LocalIdxSrc{idx[0], val[0]}, idx16, val[1], count, plan->window_bits, hist,
+                                           plan->seg.num_tiles, 4.0 * (double)count, 14.0 * (double)count, arena, stream,
+                                           prof, plan->seg);
             ProfScope ps(prof, "window_scatter", stream, 10.0 * (double)count);
             record_window_scatter_kernel<uint16_t><<<plan->num_windows, kThreads, 0, stream>>>(idx16, val[1], out, plan->win,
                                                                                               plan->window_bits);
             KERNEL_CHECK();
-            if (plan->num_seps) {
-                separator_scatter_kernel<<<(unsigned)div_up(plan->num_seps, kThreads), kThreads, 0, stream>>>(
-                    plan->sep, plan->num_seps, idx[0], val[0], out, err);
-                KERNEL_CHECK();
-            }
+        }
+        if (plan->num_seps) {
+            separator_scatter_kernel<<<(unsigned)div_up(plan->num_seps, kThreads), kThreads, 0, stream>>>(
+                plan->sep, plan->num_seps, idx[0], val[0], out, err, out2);
+            KERNEL_CHECK();
         }
         uint32_t h_err = 0;
         HIP_CHECK(hipMemcpyAsync(&h_err, err, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));

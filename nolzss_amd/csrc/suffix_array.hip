@@ -2090,8 +2090,14 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     // stage; an arena that settled for less keeps the rank scatter.  Texts of more than 2^30 symbols keep it too:
     // the two-value form has two partition passes.  NOLZSS_NO_DEFER_ISA: A/B switch.)
     static const bool no_defer = getenv("NOLZSS_NO_DEFER_ISA") != nullptr;
-    const bool can_defer = isa_deferred && !no_defer && text.terms.seq_shift == 0 && n <= (1u << 30) &&
+    // (a merged batch of long records: its block-diagonal permutation has the two-value form too, RecordScatterPlan)
+    const bool plan_two = ctx.rec_plan && ctx.rec_plan->seg.desc && ctx.rec_plan->n == n && !text.terms.mirror;
+    const bool can_defer = isa_deferred && !no_defer && (plan_two || (text.terms.seq_shift == 0 && n <= (1u << 30))) &&
                            arena.capacity() >= 60 * (size_t)n + (size_t(64) << 20);
+    if (getenv("NOLZSS_TRACE") && isa_deferred && !can_defer)
+        fprintf(stderr, "[nolzss]   rank[] is scattered after the direct rounds (arena %.1f of %.1f GiB, %s)\n",
+                (double)arena.capacity() / 1073741824.0, (60.0 * (double)n + 67108864.0) / 1073741824.0,
+                text.terms.seq_shift ? (plan_two ? "records with a plan" : "independent records without a plan") : "one text");
     const bool store_ranks = !can_defer;
     uint32_t *act_slot[2] = {arena.alloc<uint32_t>(n), arena.alloc<uint32_t>(n)};
     uint32_t *act_grp[2] = {arena.alloc<uint32_t>(n), arena.alloc<uint32_t>(n)};
