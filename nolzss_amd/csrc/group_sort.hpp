@@ -37,7 +37,8 @@ __global__ __launch_bounds__(kThreads) void group_dir_kernel(const uint32_t *__r
                                                              uint32_t h0, uint32_t *__restrict__ out_lo,
                                                              uint32_t *__restrict__ lcp_list, ShardQueue q_mid0,
                                                              ShardQueue q_mid, ShardQueue q_big,
-                                                             uint32_t *__restrict__ min_depth) {
+                                                             uint32_t *__restrict__ min_depth,
+                                                             const uint32_t *__restrict__ lcp_mark) {
     const uint32_t shard = blockIdx.x % kQShards;
     const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // (the grid covers the list once: every lane
     bool mid0 = false, mid = false, big = false;                     //  stays for the ballots of shard_slot)
@@ -46,13 +47,16 @@ __global__ __launch_bounds__(kThreads) void group_dir_kernel(const uint32_t *__r
         out_lo[a] = 0;  // (a group nobody takes stays one group, in place)
         lcp_list[a] = kLcpPending;
         const uint32_t g = act_grp[a], j = act_slot[a] - g;
-        if (a + 1 == m || act_grp[a + 1] != g) {  // the last member knows the size
+        // (lcp_mark, the equalising round: only the groups the first direct round did not touch -- the boundary behind
+        // the group's first member still holds the plain pending code)
+        if ((a + 1 == m || act_grp[a + 1] != g) && (lcp_mark == nullptr || lcp_mark[g + 1] == kLcpPending)) {  // the last member knows the size
             sz = j + 1;
             first = (uint32_t)a - j;
             mid0 = sz > kGroupSortSmall && sz <= kGroupSortMid0;
             mid = sz > kGroupSortMid0 && sz <= kGroupSortMid;
             big = sz > kGroupSortMid && sz <= kGroupSortMax;
             if (sz > kGroupSortMax) lower_min(min_depth, h0);
+
         }
     }
     const uint32_t s0 = shard_slot(q_mid0, shard, mid0);
@@ -119,7 +123,8 @@ __global__ __launch_bounds__(THREADS) void group_sort_kernel(ShardQueue q, const
                                                              TermTable terms, uint32_t h0,
                                                              uint32_t *__restrict__ out_lo,
                                                              uint32_t *__restrict__ lcp_list,
-                                                             uint32_t *__restrict__ min_depth) {
+                                                             uint32_t *__restrict__ min_depth,
+                                                             const uint32_t *__restrict__ lcp_mark, uint32_t max_rounds) {
     constexpr uint32_t kPer = 64 / BITS;
     constexpr int kWavesB = THREADS / 64;
     constexpr uint32_t kTile = NMAX / 2;  // (tiled) list positions whose groups this workgroup takes
@@ -178,6 +183,7 @@ __global__ __launch_bounds__(THREADS) void group_sort_kernel(ShardQueue q, const
                 if (mine) {
                     const uint32_t gs = s_tmp[e - j];
                     mine = gs != 0 && gs <= kGroupSortSmall;       // ... and is small
+                    if (mine && lcp_mark != nullptr) mine = lcp_mark[g + 1] == kLcpPending;  // ... and was not compared yet
                 }
             } else if (mine) {
                 slot = act_grp[base] + e;  // (the group's members hold the slots from its head slot on)
@@ -207,7 +213,7 @@ __global__ __launch_bounds__(THREADS) void group_sort_kernel(ShardQueue q, const
         if (t == 0) s_head[N] = 1;
         __syncthreads();
         bool tied = true;
-        for (uint32_t round = 0; tied && round < kGroupSortRounds; ++round) {
+        for (uint32_t round = 0; tied && round < max_rounds; ++round) {
             // ---- 1. a segment that the last round did not split: how far does every member agree with its first
             // member?  (a scan of up to kScanWords words; the others take their window where they stand)
             for (uint32_t e = t; e < span; e += THREADS) {

@@ -217,6 +217,7 @@ __device__ __forceinline__ bool is_head(const uint64_t *__restrict__ keys, const
 // >= kLcpPendingMin act as +infinity in range minima).
 constexpr uint32_t kLcpPending = 0xffffffffu;
 constexpr uint32_t kLcpPendingMin = kLcpPending - 64u;
+constexpr uint32_t kLcpPendingCompared = kLcpPending - 1u;  // pending, inside a class the direct round has compared
 
 // ---- single-pass regroup --------------------------------------------------------------------
 // One kernel does what used to be five passes (mark heads, max-scan, commit, add-scan, compact):
@@ -1369,7 +1370,7 @@ __global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(
         stays = (large && j < kSmallGroup) || (a < a1 && j >= kSmallGroup);  // (sa keeps its order)
         // the symbols every group that stays tied is known to agree on: h0 for the groups this round does
         // not touch, the depth reached for the others (the doubling rounds start from the minimum)
-        if (large && j == 0) lower_min(min_depth, h0);
+        if (large && j == 0) lower_min(min_depth + 1, h0);  // ([1]: groups this round does not touch)
         if (starts_here && !large) {
             my_gs = (int)sz;
             my_j = (int)j;
@@ -1407,7 +1408,7 @@ __global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(
             handled = gend <= (uint32_t)kPairCap;
             if (handled && my_j == my_gs - 1) atomicMax(&s_npairs, gend);
             if (!handled) stays = true;  // no room for its pairs: the group stays as it is
-            if (!handled && my_j == 0) lower_min(min_depth, h0);
+            if (!handled && my_j == 0) lower_min(min_depth + 1, h0);
         }
         __syncthreads();
         npairs = s_npairs;
@@ -1688,6 +1689,9 @@ __global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(
         // LCP to the predecessor in the new order: the closest smaller member shares the longest prefix
         // (the first member of the group keeps the entry it has; a tied predecessor: no boundary, stays pending)
         if (ties_before == 0 && cls > 0) lcp[slot] = s_best[t];
+        // a boundary that stays undecided INSIDE a class this round compared: its own pending code, so that the
+        // groups the round did not touch (code kLcpPending) can be told from it (the equalising round, below)
+        if (ties_before > 0) lcp[slot] = kLcpPendingCompared;
         if (rank_by_slot) rank_by_slot[slot] = head + 1u;
         if (s_tied[0][t]) {
             const uint32_t nl = (uint32_t)my_gl + cls + ties_before;
@@ -1718,6 +1722,12 @@ __global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(
             surv_head[(size_t)blockIdx.x * kRefineThreads + at] = hd;
         }
         if (t == 0) surv_count[blockIdx.x] = total;
+    }
+    // how much of what stays tied was not compared at all: counted in every 64th workgroup (an estimate for the host's
+    // choice of what runs next; one atomic per counting workgroup)
+    if ((blockIdx.x & 63u) == 0) {
+        const int untouched = __syncthreads_count(stays);
+        if (t == 0 && untouched) atomicAdd(min_depth + 2, (uint32_t)untouched);
     }
     if (timed) {
         __builtin_amdgcn_s_waitcnt(0);
@@ -2235,6 +2245,8 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     // ---- direct round: small groups are finished by comparing packed suffixes ---------------
     // (groups larger than kSmallGroup stay as they are; rank[] is not needed before the doubling
     // rounds, so it is written once, after this round, instead of after each of the two)
+    uint32_t depth_compared = 0xffffffffu, depth_untouched = 0xffffffffu;  // what the direct round reports (0xffffffff: none)
+    uint64_t untouched_members = 0;                                         // (an estimate)
     if (m > 0 && h < n) {
         const uint32_t *slot = act_slot[a_cur], *grp = act_grp[a_cur];
         const size_t direct_mark = arena.mark();
@@ -2248,8 +2260,10 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         // at most 32 words (1024 bases of DNA) deep; longer ties are cheaper in the doubling rounds
         static const uint32_t cap_words = getenv("NOLZSS_REFINE_WORDS") ? (uint32_t)atoi(getenv("NOLZSS_REFINE_WORDS")) : 32u;
         const uint32_t cap = (uint32_t)k_syms + cap_words * (64u / (uint32_t)text.bits);
-        uint32_t *d_min_depth = arena.alloc<uint32_t>(1);
-        HIP_CHECK(hipMemsetAsync(d_min_depth, 0xff, sizeof(uint32_t), s));
+        // [0] classes the round compared and left tied, [1] groups it did not touch, [2] members of such groups in every 64th workgroup
+        uint32_t *d_min_depth = arena.alloc<uint32_t>(3);
+        HIP_CHECK(hipMemsetAsync(d_min_depth, 0xff, 2 * sizeof(uint32_t), s));
+        HIP_CHECK(hipMemsetAsync(d_min_depth + 2, 0, sizeof(uint32_t), s));
         {
             ProfScope ps(ctx.profiler(), "sa_direct_sort", s);
             static const bool want_rphases = getenv("NOLZSS_REFINE_PHASES") != nullptr;
@@ -2298,8 +2312,12 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         // for the round, more if the round left all its ties at the cap or at a bail-out depth): the
         // doubling rounds start there instead of repeating the steps K, 2K, 4K, ...
         if (m > 0) {
-            uint32_t depth = 0;
-            ctx.read_back(d_min_depth, &depth, 1);
+            uint32_t depth2[3] = {0, 0, 0};
+            ctx.read_back(d_min_depth, depth2, 3);
+            depth_compared = depth2[0];
+            depth_untouched = depth2[1];
+            untouched_members = (uint64_t)depth2[2] * 64u;
+            const uint32_t depth = depth2[0] < depth2[1] ? depth2[0] : depth2[1];
             if (depth != 0xffffffffu && depth > h) h = depth;
         }
         if (trace) fprintf(stderr, "[nolzss]   direct round (cap %u symbols): %u still tied, on at least %llu symbols\n", cap, m, (unsigned long long)h);
@@ -2310,7 +2328,25 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     // a text with more ties than that is repetitive, and the passes below are made for those)
     static const bool no_direct2 = getenv("NOLZSS_NO_DIRECT2") != nullptr;
     static const uint32_t direct2_div = getenv("NOLZSS_DIRECT2_MAX") ? (uint32_t)atoi(getenv("NOLZSS_DIRECT2_MAX")) : 64u;
-    if (!no_direct2 && m > 0 && h < n && !independent && direct2_div > 0 && m <= n / direct2_div + 1024u) {
+    // The EQUALISING round (collections of similar genomes): where much is tied and the first direct round left groups
+    // untouched -- more than 64 members, or pairs that did not fit its list -- the doubling rounds would start at the
+    // key depth for everything, four rounds over the whole list below the depth the compared classes already have.
+    // The same kernels take only the untouched groups (told by their pending code) for as many rounds as reach that
+    // depth: every round adds a window of 64 symbols to what a tied segment is known to agree on.  Only where the
+    // untouched groups hold a minor part of what is tied (estimated by the first round): a wavefront per group of 65 and
+    // more members that ALL stay tied takes 170 us per group and round -- 96 genomes of 2^28 bases in all, every suffix
+    // in such a group, spent 480 ms here -- and the tiles of small groups 85 ms on 48 genomes, what four doubling rounds cost.
+    static const bool no_equalise = getenv("NOLZSS_NO_EQUALISE") != nullptr;  // (A/B switch)
+    const bool full_direct2 = !no_direct2 && m > 0 && h < n && !independent && direct2_div > 0 && m <= n / direct2_div + 1024u;
+    const bool equalise = !full_direct2 && !no_direct2 && !no_equalise && m > 0 && h < n && !independent && text.bits == 2 &&
+                          depth_untouched != 0xffffffffu && depth_untouched == h &&
+                          depth_compared != 0xffffffffu && depth_compared >= 2 * h && untouched_members <= m / 3;
+    if (trace && m > 0 && depth_untouched != 0xffffffffu)
+        fprintf(stderr, "[nolzss]   about %llu of the tied suffixes sit in groups the direct round did not compare (depth %u; compared classes: %u)\n",
+                (unsigned long long)untouched_members, depth_untouched, depth_compared);
+    if (full_direct2 || equalise) {
+        const uint32_t max_rounds = equalise ? std::min<uint32_t>(kGroupSortRounds, (depth_compared - (uint32_t)h + 63u) / 64u) : kGroupSortRounds;
+        const uint32_t *lcp_mark = equalise ? lcp : nullptr;
         const uint32_t *slot = act_slot[a_cur], *grp = act_grp[a_cur];
         const size_t d2_mark = arena.mark();
         uint32_t *out_lo = arena.alloc<uint32_t>(m);
@@ -2330,7 +2366,7 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         HIP_CHECK(hipMemsetAsync(qcounts, 0, 3 * kQShards * kQPad * sizeof(uint32_t), s));
         {
             ProfScope ps(ctx.profiler(), "sa_direct_sort2", s);
-            group_dir_kernel<<<dir_blocks, kThreads, 0, s>>>(slot, grp, m, (uint32_t)h, out_lo, lcp_list, q_mid0, q_mid, q_big, d_min_depth);
+            group_dir_kernel<<<dir_blocks, kThreads, 0, s>>>(slot, grp, m, (uint32_t)h, out_lo, lcp_list, q_mid0, q_mid, q_big, d_min_depth, lcp_mark);
             KERNEL_CHECK();
             // small groups by tiles of the list; the larger ones from the queues (the consumers read the shard
             // counts on the device: no read-back in between)
@@ -2342,16 +2378,16 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
             const uint32_t h32 = (uint32_t)h;
 #define NOLZSS_GROUP_SORT(B)                                                                                                \
     group_sort_kernel<B, 64, kSmallN, true><<<tiles, 64, 0, s>>>(q_mid, slot, grp, m, sa, text.words, text.terms, h32,    \
-                                                                  out_lo, lcp_list, d_min_depth);                           \
+                                                                  out_lo, lcp_list, d_min_depth, lcp_mark, max_rounds);     \
     group_sort_kernel<B, 64, kMid0N, false><<<dim3(kQShards, ym), 64, 0, s>>>(q_mid0, slot, grp, m, sa, text.words,        \
                                                                               text.terms, h32, out_lo, lcp_list,           \
-                                                                              d_min_depth);                                \
+                                                                              d_min_depth, lcp_mark, max_rounds);          \
     group_sort_kernel<B, 64, kMidN, false><<<dim3(kQShards, ym), 64, 0, s>>>(q_mid, slot, grp, m, sa, text.words,          \
                                                                              text.terms, h32, out_lo, lcp_list,            \
-                                                                             d_min_depth);                                 \
+                                                                             d_min_depth, lcp_mark, max_rounds);           \
     group_sort_kernel<B, 256, kBigN, false><<<dim3(kQShards, yb), 256, 0, s>>>(q_big, slot, grp, m, sa, text.words,        \
                                                                                text.terms, h32, out_lo, lcp_list,          \
-                                                                               d_min_depth)
+                                                                               d_min_depth, lcp_mark, max_rounds)
             switch (text.bits) {
             case 2: NOLZSS_GROUP_SORT(2); break;
             case 4: NOLZSS_GROUP_SORT(4); break;
@@ -2369,10 +2405,13 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         if (m > 0) {
             uint32_t depth = 0;
             ctx.read_back(d_min_depth, &depth, 1);
+            // (equalising: the classes the first round compared were not looked at; they keep their depth)
+            if (equalise && depth_compared < depth) depth = depth_compared;
             if (depth != 0xffffffffu && depth > h) h = depth;
         }
         arena.rewind(d2_mark);
-        if (trace) fprintf(stderr, "[nolzss]   second direct round: %u of %u finished, %u still tied, on at least %llu symbols\n", before - m, before, m, (unsigned long long)h);
+        if (trace) fprintf(stderr, "[nolzss]   %s: %u of %u finished, %u still tied, on at least %llu symbols\n",
+                           equalise ? "equalising round (untouched groups only)" : "second direct round", before - m, before, m, (unsigned long long)h);
     }
     // Nothing is tied any more: no round below needs rank[].  A caller that can wait gets it from the permutation
     // that brings the factor-length codes into text order (pipeline.hpp) -- one full random permutation per
