@@ -206,7 +206,11 @@ __device__ __forceinline__ void build_block_tables(const uint32_t *s_sa, const u
 
 // Rounds A, B and C of ONE kind of search (kGreater, kUp) for the unfinished searches of a wavefront, 64 at a time.
 // list: ranks (index in the wave) still searching after round 0, cnt of them; list_b: scratch of the same size.
-template <bool kGreater, bool kUp, bool kHasPos, typename ThrGt>
+// kListCap: entries a list holds.  A search that finds its list full leaves with kListOverflow as its result: "left the
+// reach, nothing known" -- the caller sends the rank to the searches from global memory (below kLdsPerWave only for
+// callers that can: rc_tile_kernel, which buys a third workgroup per CU with the 1 KiB).
+constexpr uint32_t kListOverflow = 0xffffffffu;  // (= far_mark(0x7fffffff, far_bit) and the plain far marker)
+template <bool kGreater, bool kUp, bool kHasPos, int kListCap, typename ThrGt>
 __device__ __forceinline__ void lds_search_tail(const uint32_t *s_sa, const uint32_t *s_lcp, const BlockTables &T, int w,
                                                 uint32_t *res_len, uint32_t *res_pos, const uint16_t *list, uint32_t cnt,
                                                 uint16_t *list_b, ThrGt thr_gt, uint32_t far_bit) {
@@ -229,8 +233,15 @@ __device__ __forceinline__ void lds_search_tail(const uint32_t *s_sa, const uint
             if (kHasPos) res_pos[t] = (st == 1) ? pos : kNoPos;
         }
         const uint64_t bal = __ballot(pending);
-        if (pending) list_b[cnt_b + (uint32_t)__popcll(bal & lt)] = (uint16_t)tl;
+        const uint32_t at = cnt_b + (uint32_t)__popcll(bal & lt);
+        if (pending) {
+            if (kListCap >= kLdsPerWave || at < (uint32_t)kListCap)
+                list_b[at] = (uint16_t)tl;
+            else
+                res_len[t] = kListOverflow;
+        }
         cnt_b += (uint32_t)__popcll(bal);
+        if (kListCap < kLdsPerWave && cnt_b > (uint32_t)kListCap) cnt_b = (uint32_t)kListCap;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -286,9 +297,9 @@ __device__ __forceinline__ void lds_search_tail(const uint32_t *s_sa, const uint
 // kCompact: only some of the ranks search (reverse-complement mode: the ranks of the original strand, half of
 // them) -- they are gathered first, so that round 0 runs over full rows of searching ranks instead of spending
 // its instructions on rows that are half idle.
-// list0 / list1: NS lists of kLdsPerWave entries each, one per kind of search (search k: greater = k >= 2,
+// list0 / list1: NS lists of kListCap entries each (NS * kListCap >= kLdsPerWave: the gathered ranks of kCompact), one per kind of search (search k: greater = k >= 2,
 // up = k even), so that every round runs with kind and direction known at compile time.
-template <int NS, int NP, bool kCompact = false, typename Active, typename ThrGt>
+template <int NS, int NP, bool kCompact = false, int kListCap = kLdsPerWave, typename Active, typename ThrGt>
 __device__ __forceinline__ void lds_search_wave_blocks(const uint32_t *s_sa, const uint32_t *s_lcp,
                                                        const BlockTables &T, uint32_t n, uint32_t base,
                                                        uint32_t *res_len, uint32_t *res_pos, uint16_t *list0,
@@ -340,8 +351,15 @@ __device__ __forceinline__ void lds_search_wave_blocks(const uint32_t *s_sa, con
             }
             const bool pending = st == 2;
             const uint64_t bal = __ballot(pending);
-            if (pending) list0[k * kLdsPerWave + cnt[k] + (uint32_t)__popcll(bal & lt)] = (uint16_t)tl;
+            const uint32_t at = cnt[k] + (uint32_t)__popcll(bal & lt);
+            if (pending) {
+                if (kListCap >= kLdsPerWave || at < (uint32_t)kListCap)
+                    list0[k * kListCap + at] = (uint16_t)tl;
+                else
+                    res_len[k * kLdsTile + t] = kListOverflow;
+            }
             cnt[k] += (uint32_t)__popcll(bal);
+            if (kListCap < kLdsPerWave && cnt[k] > (uint32_t)kListCap) cnt[k] = (uint32_t)kListCap;
         };
         search(std::integral_constant<int, 0>());
         search(std::integral_constant<int, 1>());
@@ -355,14 +373,14 @@ __device__ __forceinline__ void lds_search_wave_blocks(const uint32_t *s_sa, con
     __builtin_amdgcn_wave_barrier();
 
     // ---- rounds A, B, C per kind of search ---------------------------------------------------------
-    lds_search_tail<false, true, (0 < NP)>(s_sa, s_lcp, T, w, res_len, res_pos, list0, cnt[0], list1, thr_gt, far_bit);
-    lds_search_tail<false, false, (1 < NP)>(s_sa, s_lcp, T, w, res_len + kLdsTile, res_pos + kLdsTile, list0 + kLdsPerWave,
-                                            cnt[1], list1 + kLdsPerWave, thr_gt, far_bit);
+    lds_search_tail<false, true, (0 < NP), kListCap>(s_sa, s_lcp, T, w, res_len, res_pos, list0, cnt[0], list1, thr_gt, far_bit);
+    lds_search_tail<false, false, (1 < NP), kListCap>(s_sa, s_lcp, T, w, res_len + kLdsTile, res_pos + kLdsTile, list0 + kListCap,
+                                                      cnt[1], list1 + kListCap, thr_gt, far_bit);
     if constexpr (NS > 2) {
-        lds_search_tail<true, true, (2 < NP)>(s_sa, s_lcp, T, w, res_len + 2 * kLdsTile, res_pos + (2 < NP ? 2 : 0) * kLdsTile,
-                                              list0 + 2 * kLdsPerWave, cnt[2], list1 + 2 * kLdsPerWave, thr_gt, far_bit);
-        lds_search_tail<true, false, (3 < NP)>(s_sa, s_lcp, T, w, res_len + 3 * kLdsTile, res_pos + (3 < NP ? 3 : 0) * kLdsTile,
-                                               list0 + 3 * kLdsPerWave, cnt[3], list1 + 3 * kLdsPerWave, thr_gt, far_bit);
+        lds_search_tail<true, true, (2 < NP), kListCap>(s_sa, s_lcp, T, w, res_len + 2 * kLdsTile, res_pos + (2 < NP ? 2 : 0) * kLdsTile,
+                                                        list0 + 2 * kListCap, cnt[2], list1 + 2 * kListCap, thr_gt, far_bit);
+        lds_search_tail<true, false, (3 < NP), kListCap>(s_sa, s_lcp, T, w, res_len + 3 * kLdsTile, res_pos + (3 < NP ? 3 : 0) * kLdsTile,
+                                                         list0 + 3 * kListCap, cnt[3], list1 + 3 * kListCap, thr_gt, far_bit);
     }
     if (phase_clock) phase_clock[1] = phase_clock[2] = __builtin_readcyclecounter();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

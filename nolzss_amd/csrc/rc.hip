@@ -65,7 +65,13 @@ __global__ __launch_bounds__(kLdsThreads) void rc_tile_kernel(const uint32_t *__
     __shared__ __align__(16) uint32_t s_lcp[kLdsSpan + 4];
     __shared__ uint32_t s_len[NS * kLdsTile];
     __shared__ uint32_t s_pos[NP * kLdsTile];
-    __shared__ uint16_t s_list[kLdsWaves][2][NS * kLdsPerWave];
+    // 128 instead of 256 entries per list: 46.6 instead of 54.8 KiB of LDS, THREE workgroups per CU instead of two --
+    // rc_candidates 14.2 -> 10.6 ms at 2^28 bases (240 entries, 53.8 KiB, still ran two per CU).  A list overflows when
+    // more than 128 of a wavefront's ranks are still searching in one direction after four steps (one in five is, of
+    // the 128 ranks of the original strand a wavefront holds on average): those ranks go to the searches from global memory.
+    constexpr int kListCap = 128;
+    static_assert(NS * kListCap >= kLdsPerWave, "list1 first holds the gathered ranks");
+    __shared__ uint16_t s_list[kLdsWaves][2][NS * kListCap];
     __shared__ uint32_t s_blk[4 * kBlkTableLen];
     const uint32_t base = blockIdx.x * (uint32_t)kLdsTile;
     const uint32_t shard = blockIdx.x % kQShards;
@@ -86,7 +92,7 @@ __global__ __launch_bounds__(kLdsThreads) void rc_tile_kernel(const uint32_t *__
     }
     const int w = threadIdx.x >> 6;
     const uint32_t far_bit = m <= 0x80000000u ? 0x80000000u : 0u;
-    lds_search_wave_blocks<NS, NP, true>(s_sa, s_lcp, T, m, base, s_len, s_pos, s_list[w][0], s_list[w][1],
+    lds_search_wave_blocks<NS, NP, true, kListCap>(s_sa, s_lcp, T, m, base, s_len, s_pos, s_list[w][0], s_list[w][1],
                                    [N](uint32_t i) { return i < N; }, [N](uint32_t i) { return 2u * N - i; }, far_bit);
     constexpr int kRows = kLdsPerWave / 64;
     bool far[kRows], exact[kRows];
@@ -106,9 +112,10 @@ __global__ __launch_bounds__(kLdsThreads) void rc_tile_kernel(const uint32_t *__
         uint32_t lp = s_len[t], ls = s_len[kLdsTile + t];
         uint32_t ru = s_len[2 * kLdsTile + t], rd = s_len[3 * kLdsTile + t];
         // which of the four searches left the reach (they restart behind the ranks already cleared)
+        // (a search that found its work list full knows nothing: it restarts at the rank itself, like a search whose bit is clear)
         if (far_bit)
-            mask[row] = (far_is(lp, far_bit) ? 1u : 0u) | (far_is(ls, far_bit) ? 2u : 0u) | (far_is(ru, far_bit) ? 4u : 0u) |
-                        (far_is(rd, far_bit) ? 8u : 0u);
+            mask[row] = ((far_is(lp, far_bit) && lp != kListOverflow) ? 1u : 0u) | ((far_is(ls, far_bit) && ls != kListOverflow) ? 2u : 0u) |
+                        ((far_is(ru, far_bit) && ru != kListOverflow) ? 4u : 0u) | ((far_is(rd, far_bit) && rd != kListOverflow) ? 8u : 0u);
         // a search that left the reach matters only if its bound can beat the other direction
         // (reverse-complement lengths <= 1 can never be chosen)
         const bool far_f = far_resolve(lp, ls, far_bit, 0u);
