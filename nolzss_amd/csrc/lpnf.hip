@@ -85,8 +85,13 @@ __global__ __launch_bounds__(kLdsThreads) void lpf_tile_kernel(const uint32_t *_
     __shared__ __align__(16) uint32_t s_sa[kLdsSpan];
     __shared__ __align__(16) uint32_t s_lcp[kLdsSpan + 4];
     __shared__ uint32_t s_len[NS * kLdsTile];
-    __shared__ uint32_t s_pos[NS * kLdsTile];
-    __shared__ uint16_t s_list[kLdsWaves][2][NS * kLdsPerWave];
+    __shared__ uint16_t s_pos[NS * kLdsTile];  // (local index of the match, nearest_lds.hpp: match_pos)
+    // lists of the searches still going after 4 steps (one per rank at most) and after 16 (one in 17 is: 64 entries,
+    // emptied by rounds B + C whenever the next step of round A might not fit): 30.9 KiB of LDS with the two-byte
+    // match indices, five workgroups per CU instead of four
+    constexpr int kListCapB = 64;
+    __shared__ uint16_t s_list0[kLdsWaves][NS * kLdsPerWave];
+    __shared__ uint16_t s_list1[kLdsWaves][NS * kListCapB];
     __shared__ uint32_t s_blk[3 * kBlkTableLen];
     const uint32_t base = blockIdx.x * (uint32_t)kLdsTile;
     const uint32_t shard = blockIdx.x % kQShards;
@@ -110,7 +115,7 @@ __global__ __launch_bounds__(kLdsThreads) void lpf_tile_kernel(const uint32_t *_
     if (timed) clk[1] = __builtin_readcyclecounter();
     const int w = threadIdx.x >> 6;
     const uint32_t far_bit = n <= 0x80000000u ? 0x80000000u : 0u;
-    lds_search_wave_blocks<NS, NS>(s_sa, s_lcp, T, n, base, s_len, s_pos, s_list[w][0], s_list[w][1],
+    lds_search_wave_blocks<NS, NS, false, kLdsPerWave, kListCapB>(s_sa, s_lcp, T, n, base, s_len, s_pos, s_list0[w], s_list1[w],
                                    [](uint32_t) { return true; }, [](uint32_t) { return 0u; }, far_bit,
                                    timed ? clk + 2 : nullptr);
     if (timed) clk[4] = __builtin_readcyclecounter();
@@ -135,11 +140,12 @@ __global__ __launch_bounds__(kLdsThreads) void lpf_tile_kernel(const uint32_t *_
             // the tile found travels along (length in the by-rank slot, position + side in far_aux)
             if (far_bit && fu != fd) {
                 known[row] = fu ? down : up;
-                const uint32_t p = fu ? s_pos[kLdsTile + t] : s_pos[t];
+                const uint32_t p = match_pos(s_sa, fu ? s_pos[kLdsTile + t] : s_pos[t]);
                 aux[row] = (known[row] ? (p & 0x7fffffffu) : 0x7fffffffu) | (fu ? 0x80000000u : 0u);
             }
         } else if (in) {
-            exact[row] = lpf_decide(s_sa[t + kLdsReach], up, s_pos[t], down, s_pos[kLdsTile + t], lstar_by_rank + rr);
+            exact[row] = lpf_decide(s_sa[t + kLdsReach], up, match_pos(s_sa, s_pos[t]), down, match_pos(s_sa, s_pos[kLdsTile + t]),
+                                    lstar_by_rank + rr);
         }
     }
     // Far ranks: every wavefront has a region of its own -- the 256 entries at its own ranks -- and reports how

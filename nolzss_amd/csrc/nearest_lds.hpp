@@ -106,9 +106,13 @@ __device__ __forceinline__ void stage_tile(const uint32_t *__restrict__ sa, cons
 // discarded by the m == 0 test at the end.  (Round 2 selected status, length and position per step from the last
 // step backwards, with the direction a per-lane value: 12 VALU instructions per step; SQ_INSTS_VALU x 4 cycles /
 // 1024 SIMDs was the whole 10.5 ms of lpf_tile_kernel.)
+// at: local index (into the staged tile) of the match when 1 is returned -- the results keep that index, two bytes,
+// instead of the suffix start (kNoMatch: none)
+constexpr uint16_t kNoMatch = 0xffffu;
+__device__ __forceinline__ uint32_t match_pos(const uint32_t *s_sa, uint16_t at) { return at == kNoMatch ? kNoPos : s_sa[at]; }
 template <int kSteps, bool kGreater, bool kUp>
 __device__ __forceinline__ int lds_scan_round(const uint32_t *s_sa, const uint32_t *s_lcp, int li, int s0, uint32_t x,
-                                              uint32_t &m, uint32_t &pos) {
+                                              uint32_t &m, uint32_t &at) {
     uint32_t c[kSteps], v[kSteps];
 #pragma unroll
     for (int k = 0; k < kSteps; ++k) {
@@ -117,15 +121,17 @@ __device__ __forceinline__ int lds_scan_round(const uint32_t *s_sa, const uint32
         v[k] = s_sa[q];
     }
     bool alive = true;
+    uint32_t kk = 0;
 #pragma unroll
     for (int k = 0; k < kSteps; ++k) {
         const uint32_t mk = c[k] < m ? c[k] : m;
         const bool qual = kGreater ? v[k] > x : v[k] < x;
         const bool stop = alive && qual;
         m = alive ? mk : m;
-        pos = stop ? v[k] : pos;
+        kk = stop ? (uint32_t)k : kk;
         alive = alive != stop;  // (alive && !qual, without a second comparison)
     }
+    at = (uint32_t)(kUp ? li - (s0 + (int)kk + 1) : li + (s0 + (int)kk + 1));
     return m == 0 ? 0 : (alive ? 2 : 1);
 }
 
@@ -205,20 +211,78 @@ __device__ __forceinline__ void build_block_tables(const uint32_t *s_sa, const u
 }
 
 // Rounds A, B and C of ONE kind of search (kGreater, kUp) for the unfinished searches of a wavefront, 64 at a time.
-// list: ranks (index in the wave) still searching after round 0, cnt of them; list_b: scratch of the same size.
-// kListCap: entries a list holds.  A search that finds its list full leaves with kListOverflow as its result: "left the
-// reach, nothing known" -- the caller sends the rank to the searches from global memory (below kLdsPerWave only for
-// callers that can: rc_tile_kernel, which buys a third workgroup per CU with the 1 KiB).
+// list: ranks (index in the wave) still searching after round 0, cnt of them; list_b: kListCapB >= 64 entries for the
+// searches still going after round A -- when the next 64 might not fit, rounds B + C run on what is there first.
+// (kListOverflow, a result of round 0 in lds_search_wave_blocks: "left the reach, nothing known", for a search that
+// found list0 full -- the caller sends the rank to the searches from global memory.)
 constexpr uint32_t kListOverflow = 0xffffffffu;  // (= far_mark(0x7fffffff, far_bit) and the plain far marker)
-template <bool kGreater, bool kUp, bool kHasPos, int kListCap, typename ThrGt>
+template <bool kGreater, bool kUp, bool kHasPos, int kListCapB, typename ThrGt>
 __device__ __forceinline__ void lds_search_tail(const uint32_t *s_sa, const uint32_t *s_lcp, const BlockTables &T, int w,
-                                                uint32_t *res_len, uint32_t *res_pos, const uint16_t *list, uint32_t cnt,
+                                                uint32_t *res_len, uint16_t *res_pos, const uint16_t *list, uint32_t cnt,
                                                 uint16_t *list_b, ThrGt thr_gt, uint32_t far_bit) {
+    static_assert(kListCapB >= 64, "a step of round A appends up to 64 searches");
     const int lane = lane_id();
     const uint64_t lt = lanemask_lt();
+    const uint32_t *tv = kGreater ? T.mx : T.mn;
+    const uint32_t *tc = kUp ? T.lup : T.ldn;
+    // ---- rounds B + C for the first cnt_b entries of list_b: by blocks, then inside the block that stops the search ----
+    auto rounds_bc = [&](uint32_t cnt_b) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t c0 = 0; c0 < cnt_b; c0 += 64) {
+            const bool have = c0 + lane < cnt_b;
+            const int tl = have ? (int)list_b[c0 + lane] : 0;
+            const int t = w * kLdsPerWave + tl;
+            const int li = t + kLdsReach;
+            const uint32_t i = s_sa[li];
+            const uint32_t x = kGreater ? thr_gt(i) : i;
+            // first block beyond the kLdsStep0 + kStepA ranks already passed (it may overlap them); the 16 blocks from
+            // there reach at most one block outside the staged span (the padded table entries)
+            const int b0 = kUp ? (li - (kLdsStep0 + kStepA + 1)) >> 4 : (li + (kLdsStep0 + kStepA + 1)) >> 4;
+            uint32_t c[kBlk], v[kBlk];
+#pragma unroll
+            for (int j = 0; j < kBlk; ++j) {
+                const int B = kUp ? b0 - j : b0 + j;
+                c[j] = tc[B];
+                v[j] = tv[B];
+            }
+            // run: the minimum in front of the block that stops the search (the first one that holds a qualifying
+            // suffix), or over all 16 blocks -- the bound the search leaves the reach with
+            uint32_t run = have ? res_len[t] : 0xffffffffu;
+            int jstar = -1;
+            bool alive = true;
+#pragma unroll
+            for (int j = 0; j < kBlk; ++j) {
+                const uint32_t rk = c[j] < run ? c[j] : run;
+                const bool qual = kGreater ? v[j] > x : v[j] < x;
+                const bool stop = alive && qual;
+                jstar = stop ? j : jstar;
+                alive = alive != stop;  // (alive && !qual, without a second comparison)
+                run = alive ? rk : run;
+            }
+            const bool inside = have && jstar >= 0;
+            // round C: the ranks of block Bs, nearest first: anchor = the rank just in front of the block
+            const int Bs = kUp ? b0 - jstar : b0 + jstar;
+            const int anchor = inside ? (kUp ? kBlk * Bs + kBlk : kBlk * Bs - 1) : li;
+            uint32_t m = run, at = 0;
+            const int st = lds_scan_round<kBlk, kGreater, kUp>(s_sa, s_lcp, anchor, 0, x, m, at);
+            if (have) {
+                // inside: the block holds a qualifying suffix, so the scan ends there (st 0 or 1); otherwise the
+                // search left the reach
+                res_len[t] = inside ? m : far_mark(run, far_bit);
+                if (kHasPos) res_pos[t] = (inside && st == 1) ? (uint16_t)at : kNoMatch;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
     // ---- round A: kStepA more steps ------------------------------------------------------------
     uint32_t cnt_b = 0;
     for (uint32_t c0 = 0; c0 < cnt; c0 += 64) {
+        if (kListCapB < kLdsPerWave && cnt_b + 64 > (uint32_t)kListCapB) {  // (wave-uniform) room for this step's searches
+            rounds_bc(cnt_b);
+            cnt_b = 0;
+        }
         const bool have = c0 + lane < cnt;
         const int tl = have ? (int)list[c0 + lane] : 0;
         const int t = w * kLdsPerWave + tl;
@@ -226,83 +290,29 @@ __device__ __forceinline__ void lds_search_tail(const uint32_t *s_sa, const uint
         bool pending = false;
         if (have) {
             const uint32_t i = s_sa[li];
-            uint32_t m = res_len[t], pos = kNoPos;
-            const int st = lds_scan_round<kStepA, kGreater, kUp>(s_sa, s_lcp, li, kLdsStep0, kGreater ? thr_gt(i) : i, m, pos);
+            uint32_t m = res_len[t], at = 0;
+            const int st = lds_scan_round<kStepA, kGreater, kUp>(s_sa, s_lcp, li, kLdsStep0, kGreater ? thr_gt(i) : i, m, at);
             pending = st == 2;
             res_len[t] = m;
-            if (kHasPos) res_pos[t] = (st == 1) ? pos : kNoPos;
+            if (kHasPos) res_pos[t] = (st == 1) ? (uint16_t)at : kNoMatch;
         }
         const uint64_t bal = __ballot(pending);
-        const uint32_t at = cnt_b + (uint32_t)__popcll(bal & lt);
-        if (pending) {
-            if (kListCap >= kLdsPerWave || at < (uint32_t)kListCap)
-                list_b[at] = (uint16_t)tl;
-            else
-                res_len[t] = kListOverflow;
-        }
+        if (pending) list_b[cnt_b + (uint32_t)__popcll(bal & lt)] = (uint16_t)tl;
         cnt_b += (uint32_t)__popcll(bal);
-        if (kListCap < kLdsPerWave && cnt_b > (uint32_t)kListCap) cnt_b = (uint32_t)kListCap;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // ---- rounds B + C: by blocks, then inside the block that stops the search ---------------------
-    const uint32_t *tv = kGreater ? T.mx : T.mn;
-    const uint32_t *tc = kUp ? T.lup : T.ldn;
-    for (uint32_t c0 = 0; c0 < cnt_b; c0 += 64) {
-        const bool have = c0 + lane < cnt_b;
-        const int tl = have ? (int)list_b[c0 + lane] : 0;
-        const int t = w * kLdsPerWave + tl;
-        const int li = t + kLdsReach;
-        const uint32_t i = s_sa[li];
-        const uint32_t x = kGreater ? thr_gt(i) : i;
-        // first block beyond the kLdsStep0 + kStepA ranks already passed (it may overlap them); the 16 blocks from
-        // there reach at most one block outside the staged span (the padded table entries)
-        const int b0 = kUp ? (li - (kLdsStep0 + kStepA + 1)) >> 4 : (li + (kLdsStep0 + kStepA + 1)) >> 4;
-        uint32_t c[kBlk], v[kBlk];
-#pragma unroll
-        for (int j = 0; j < kBlk; ++j) {
-            const int B = kUp ? b0 - j : b0 + j;
-            c[j] = tc[B];
-            v[j] = tv[B];
-        }
-        // run: the minimum in front of the block that stops the search (the first one that holds a qualifying suffix),
-        // or over all 16 blocks -- the bound the search leaves the reach with
-        uint32_t run = have ? res_len[t] : 0xffffffffu;
-        int jstar = -1;
-        bool alive = true;
-#pragma unroll
-        for (int j = 0; j < kBlk; ++j) {
-            const uint32_t rk = c[j] < run ? c[j] : run;
-            const bool qual = kGreater ? v[j] > x : v[j] < x;
-            const bool stop = alive && qual;
-            jstar = stop ? j : jstar;
-            alive = alive != stop;  // (alive && !qual, without a second comparison)
-            run = alive ? rk : run;
-        }
-        const bool inside = have && jstar >= 0;
-        // round C: the ranks of block Bs, nearest first: anchor = the rank just in front of the block
-        const int Bs = kUp ? b0 - jstar : b0 + jstar;
-        const int anchor = inside ? (kUp ? kBlk * Bs + kBlk : kBlk * Bs - 1) : li;
-        uint32_t m = run, pos = kNoPos;
-        const int st = lds_scan_round<kBlk, kGreater, kUp>(s_sa, s_lcp, anchor, 0, x, m, pos);
-        if (have) {
-            // inside: the block holds a qualifying suffix, so the scan ends there (st 0 or 1); otherwise the search
-            // left the reach
-            res_len[t] = inside ? m : far_mark(run, far_bit);
-            if (kHasPos) res_pos[t] = (inside && st == 1) ? pos : kNoPos;
-        }
-    }
+    rounds_bc(cnt_b);
 }
 
 // kCompact: only some of the ranks search (reverse-complement mode: the ranks of the original strand, half of
 // them) -- they are gathered first, so that round 0 runs over full rows of searching ranks instead of spending
 // its instructions on rows that are half idle.
-// list0 / list1: NS lists of kListCap entries each (NS * kListCap >= kLdsPerWave: the gathered ranks of kCompact), one per kind of search (search k: greater = k >= 2,
+// list0 / list1: NS lists of kListCap / kListCapB entries each (kCompact: NS * kListCapB >= kLdsPerWave, the gathered
+// ranks), one per kind of search (search k: greater = k >= 2,
 // up = k even), so that every round runs with kind and direction known at compile time.
-template <int NS, int NP, bool kCompact = false, int kListCap = kLdsPerWave, typename Active, typename ThrGt>
+template <int NS, int NP, bool kCompact = false, int kListCap = kLdsPerWave, int kListCapB = kListCap, typename Active, typename ThrGt>
 __device__ __forceinline__ void lds_search_wave_blocks(const uint32_t *s_sa, const uint32_t *s_lcp,
                                                        const BlockTables &T, uint32_t n, uint32_t base,
-                                                       uint32_t *res_len, uint32_t *res_pos, uint16_t *list0,
+                                                       uint32_t *res_len, uint16_t *res_pos, uint16_t *list0,
                                                        uint16_t *list1, Active active, ThrGt thr_gt,
                                                        uint32_t far_bit, unsigned long long *phase_clock = nullptr) {
     static_assert(NS == 2 || NS == 4, "searches: smaller up / down, then greater up / down");
@@ -342,19 +352,19 @@ __device__ __forceinline__ void lds_search_wave_blocks(const uint32_t *s_sa, con
         auto search = [&](auto kk) {
             constexpr int k = decltype(kk)::value;
             constexpr bool greater = k >= 2, up = (k & 1) == 0;
-            uint32_t m = 0xffffffffu, pos = kNoPos;
+            uint32_t m = 0xffffffffu, at = 0;
             int st = 0;
-            if (valid) st = lds_scan_round<kLdsStep0, greater, up>(s_sa, s_lcp, li, 0, greater ? thr_gt(i) : i, m, pos);
+            if (valid) st = lds_scan_round<kLdsStep0, greater, up>(s_sa, s_lcp, li, 0, greater ? thr_gt(i) : i, m, at);
             if (have) {  // (kCompact: the results of ranks that do not search are never read)
                 res_len[k * kLdsTile + t] = (st == 0) ? 0u : m;
-                if (k < NP) res_pos[k * kLdsTile + t] = (st == 1) ? pos : kNoPos;
+                if (k < NP) res_pos[k * kLdsTile + t] = (st == 1) ? (uint16_t)at : kNoMatch;
             }
             const bool pending = st == 2;
             const uint64_t bal = __ballot(pending);
-            const uint32_t at = cnt[k] + (uint32_t)__popcll(bal & lt);
+            const uint32_t slot = cnt[k] + (uint32_t)__popcll(bal & lt);
             if (pending) {
-                if (kListCap >= kLdsPerWave || at < (uint32_t)kListCap)
-                    list0[k * kListCap + at] = (uint16_t)tl;
+                if (kListCap >= kLdsPerWave || slot < (uint32_t)kListCap)
+                    list0[k * kListCap + slot] = (uint16_t)tl;
                 else
                     res_len[k * kLdsTile + t] = kListOverflow;
             }
@@ -373,14 +383,15 @@ __device__ __forceinline__ void lds_search_wave_blocks(const uint32_t *s_sa, con
     __builtin_amdgcn_wave_barrier();
 
     // ---- rounds A, B, C per kind of search ---------------------------------------------------------
-    lds_search_tail<false, true, (0 < NP), kListCap>(s_sa, s_lcp, T, w, res_len, res_pos, list0, cnt[0], list1, thr_gt, far_bit);
-    lds_search_tail<false, false, (1 < NP), kListCap>(s_sa, s_lcp, T, w, res_len + kLdsTile, res_pos + kLdsTile, list0 + kListCap,
-                                                      cnt[1], list1 + kListCap, thr_gt, far_bit);
+    static_assert(!kCompact || NS * kListCapB >= kLdsPerWave, "list1 first holds the gathered ranks");
+    lds_search_tail<false, true, (0 < NP), kListCapB>(s_sa, s_lcp, T, w, res_len, res_pos, list0, cnt[0], list1, thr_gt, far_bit);
+    lds_search_tail<false, false, (1 < NP), kListCapB>(s_sa, s_lcp, T, w, res_len + kLdsTile, res_pos + kLdsTile, list0 + kListCap,
+                                                       cnt[1], list1 + kListCapB, thr_gt, far_bit);
     if constexpr (NS > 2) {
-        lds_search_tail<true, true, (2 < NP), kListCap>(s_sa, s_lcp, T, w, res_len + 2 * kLdsTile, res_pos + (2 < NP ? 2 : 0) * kLdsTile,
-                                                        list0 + 2 * kListCap, cnt[2], list1 + 2 * kListCap, thr_gt, far_bit);
-        lds_search_tail<true, false, (3 < NP), kListCap>(s_sa, s_lcp, T, w, res_len + 3 * kLdsTile, res_pos + (3 < NP ? 3 : 0) * kLdsTile,
-                                                         list0 + 3 * kListCap, cnt[3], list1 + 3 * kListCap, thr_gt, far_bit);
+        lds_search_tail<true, true, (2 < NP), kListCapB>(s_sa, s_lcp, T, w, res_len + 2 * kLdsTile, res_pos + (2 < NP ? 2 : 0) * kLdsTile,
+                                                         list0 + 2 * kListCap, cnt[2], list1 + 2 * kListCapB, thr_gt, far_bit);
+        lds_search_tail<true, false, (3 < NP), kListCapB>(s_sa, s_lcp, T, w, res_len + 3 * kLdsTile, res_pos + (3 < NP ? 3 : 0) * kLdsTile,
+                                                          list0 + 3 * kListCap, cnt[3], list1 + 3 * kListCapB, thr_gt, far_bit);
     }
     if (phase_clock) phase_clock[1] = phase_clock[2] = __builtin_readcyclecounter();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -64,14 +64,15 @@ __global__ __launch_bounds__(kLdsThreads) void rc_tile_kernel(const uint32_t *__
     __shared__ __align__(16) uint32_t s_sa[kLdsSpan];
     __shared__ __align__(16) uint32_t s_lcp[kLdsSpan + 4];
     __shared__ uint32_t s_len[NS * kLdsTile];
-    __shared__ uint32_t s_pos[NP * kLdsTile];
+    __shared__ uint16_t s_pos[NP * kLdsTile];  // (local index of the match, nearest_lds.hpp: match_pos)
     // 128 instead of 256 entries per list: 46.6 instead of 54.8 KiB of LDS, THREE workgroups per CU instead of two --
     // rc_candidates 14.2 -> 10.6 ms at 2^28 bases (240 entries, 53.8 KiB, still ran two per CU).  A list overflows when
     // more than 128 of a wavefront's ranks are still searching in one direction after four steps (one in five is, of
     // the 128 ranks of the original strand a wavefront holds on average): those ranks go to the searches from global memory.
     constexpr int kListCap = 128;
-    static_assert(NS * kListCap >= kLdsPerWave, "list1 first holds the gathered ranks");
-    __shared__ uint16_t s_list[kLdsWaves][2][NS * kListCap];
+    constexpr int kListCapB = 64;  // (searches still going after 16 steps: one in 17)
+    __shared__ uint16_t s_list0[kLdsWaves][NS * kListCap];
+    __shared__ uint16_t s_list1[kLdsWaves][NS * kListCapB];
     __shared__ uint32_t s_blk[4 * kBlkTableLen];
     const uint32_t base = blockIdx.x * (uint32_t)kLdsTile;
     const uint32_t shard = blockIdx.x % kQShards;
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(kLdsThreads) void rc_tile_kernel(const uint32_t *__
     }
     const int w = threadIdx.x >> 6;
     const uint32_t far_bit = m <= 0x80000000u ? 0x80000000u : 0u;
-    lds_search_wave_blocks<NS, NP, true, kListCap>(s_sa, s_lcp, T, m, base, s_len, s_pos, s_list[w][0], s_list[w][1],
+    lds_search_wave_blocks<NS, NP, true, kListCap, kListCapB>(s_sa, s_lcp, T, m, base, s_len, s_pos, s_list0[w], s_list1[w],
                                    [N](uint32_t i) { return i < N; }, [N](uint32_t i) { return 2u * N - i; }, far_bit);
     constexpr int kRows = kLdsPerWave / 64;
     bool far[kRows], exact[kRows];
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(kLdsThreads) void rc_tile_kernel(const uint32_t *__
         far[row] = far_f || far_r;  // finished from global memory
         if (!far[row]) {
             rcl[row] = ru > rd ? ru : rd;
-            exact[row] = rc_decide(i, lp, s_pos[t], ls, s_pos[kLdsTile + t], rcl[row], code_by_rank + rr);
+            exact[row] = rc_decide(i, lp, match_pos(s_sa, s_pos[t]), ls, match_pos(s_sa, s_pos[kLdsTile + t]), rcl[row], code_by_rank + rr);
         }
     }
     shard_slots<kRows>(far_q, shard, far, fslot);
