@@ -9,9 +9,12 @@
 //   * the workgroup stages kLdsTile ranks of SA and LCP plus a halo of kLdsReach on both sides, and per
 //     aligned block of 16 staged ranks the min (max) suffix start and the min LCP crossed passing it;
 //   * round 0: every lane advances each of its searches by 4 steps, branch-free (ends 4 of 5);
-//   * unfinished searches are compacted (ballot + popcount) into a per-wave work list in LDS and taken 64
-//     at a time: 12 more steps (round A), then 16 BLOCKS nearest first (round B), then the 16 ranks of the
+//   * unfinished searches are compacted (ballot + popcount) into per-wave work lists in LDS, ONE LIST PER KIND
+//     of search (smaller / greater suffix start, towards smaller / larger ranks: kind and direction are then
+//     compile-time constants of every round, and an LDS address is the rank's own plus an immediate), and taken
+//     64 at a time: 12 more steps (round A), then 16 BLOCKS nearest first (round B), then the 16 ranks of the
 //     block that stops the search (round C) -- see lds_search_wave_blocks below;
+//   * results per rank and search: the length (4 bytes) and the LOCAL INDEX of the match (2 bytes, match_pos);
 //   * a search that leaves the reach keeps its running LCP minimum as a bound (far_mark): the rank
 //     is finished from global memory with the pyramids only if that bound can still win.
 // Round 1 ran the unfinished searches in work-list rounds of 8 steps and a tail of one search per 16-lane
@@ -147,7 +150,8 @@ __device__ __forceinline__ int lds_scan_round(const uint32_t *s_sa, const uint32
 //   round A   16 more steps, the unfinished searches 64 at a time (as above),
 // continues by BLOCKS:
 //   round B   the next 16 blocks away from the rank, nearest first: running minimum of the block LCP
-//             minima, stop at the first block that holds a qualifying suffix or drives the minimum to 0;
+//             minima, stop at the first block that holds a qualifying suffix (a minimum that reaches 0 stays 0:
+//             whatever the search finds behind it is discarded, lds_scan_round);
 //   round C   the 16 ranks of that block, nearest first, from the minimum carried so far: ends inside.
 // Blocks that overlap ranks already passed are harmless (a minimum is idempotent and those ranks do not
 // qualify).  No stop within the 16 blocks (>= 261 ranks away): the search leaves the reach with its bound,
