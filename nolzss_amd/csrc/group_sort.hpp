@@ -191,8 +191,7 @@ __global__ __launch_bounds__(THREADS) void group_sort_kernel(ShardQueue q, const
             uint32_t p = 0, lim = 0, term = 0;
             if (mine) {
                 p = sa[slot];
-                term = terms.count == 1 ? 0u : term_lower_bound(terms, p);
-                lim = (terms.count == 1 ? terms.end : terms.pos[term]) - p;
+                lim = term_limit(terms, p, term);
             }
             s_pos[e] = p;
             s_lim[e] = lim;

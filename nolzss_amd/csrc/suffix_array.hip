@@ -1375,8 +1375,7 @@ __global__ __launch_bounds__(kRefineThreads) __attribute__((amdgpu_waves_per_eu(
             my_gs = (int)sz;
             my_j = (int)j;
             // (one segment: no table look-up, and above all no load between my position and my first window)
-            my_term = terms.count == 1 ? 0u : term_lower_bound(terms, my_pos);
-            my_lim = (terms.count == 1 ? terms.end : terms.pos[my_term]) - my_pos;
+            my_lim = term_limit(terms, my_pos, my_term);
         }
     }
     __syncthreads();  // everybody has read the sizes
@@ -1971,6 +1970,10 @@ void finish_packing(Context &ctx, PackedText &t, const uint8_t *d_text, size_t n
     t.terms.pos = d_terms;
     t.terms.count = (uint32_t)table.size();
     t.terms.end = (uint32_t)n;
+    if (table.size() <= kTermFew) {  // (a short table travels in the kernel arguments too, text.hpp)
+        t.terms.nfew = (uint32_t)table.size();
+        for (size_t k = 0; k < table.size(); ++k) t.terms.few[k] = table[k];
+    }
     if (table.size() > 256) {
         const uint32_t blocks = (uint32_t)(n >> kTermBlockShift) + 3;
         uint32_t *coarse = ctx.arena.alloc<uint32_t>(blocks);

@@ -41,10 +41,28 @@ struct TermTable {
     // independent sequences WITH their reverse complements (T1 $ .. Tk $ rc(Tk) $ .. rc(T1) $): segment t and
     // segment 2k - 1 - t belong to the same sequence
     uint32_t mirror = 0;
+    // tables of at most kTermFew entries travel in the kernel arguments too (few[k] = pos[k], 0xffffffff behind the
+    // last one; nfew = count, 0: not filled): a prepared reverse-complement string T $ rc(T) $ has three, and the first
+    // radix pass, the direct rounds and the histogram of a segmented text ask for the terminator of every suffix
+    uint32_t nfew = 0;
+    uint32_t few[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
 };
+constexpr uint32_t kTermFew = 4;
+
+// smallest k with pos[k] >= p and that terminator's position, for a table that travels in the kernel arguments
+__device__ __forceinline__ uint32_t term_few(const TermTable &t, uint32_t p, uint32_t &pos_k) {
+    // entries in front of p (the last entry is the end of the text, >= every suffix start)
+    const uint32_t k = (t.few[0] < p ? 1u : 0u) + (t.few[1] < p ? 1u : 0u) + (t.few[2] < p ? 1u : 0u);
+    pos_k = k == 0 ? t.few[0] : (k == 1 ? t.few[1] : (k == 2 ? t.few[2] : t.few[3]));
+    return k;
+}
 
 // smallest k with pos[k] >= p (exists for every suffix start p < n)
 __device__ __forceinline__ uint32_t term_lower_bound(const TermTable &t, uint32_t p) {
+    if (t.nfew) {
+        uint32_t unused;
+        return term_few(t, p, unused);
+    }
     uint32_t lo = 0, hi = t.count - 1;
     if (t.coarse) {
         lo = t.coarse[p >> kTermBlockShift];
@@ -58,6 +76,21 @@ __device__ __forceinline__ uint32_t term_lower_bound(const TermTable &t, uint32_
             lo = mid + 1;
     }
     return lo;
+}
+
+// index of the next terminator of suffix p and the symbols in front of it (one segment: no look-up at all)
+__device__ __forceinline__ uint32_t term_limit(const TermTable &t, uint32_t p, uint32_t &k) {
+    if (t.count == 1) {
+        k = 0;
+        return t.end - p;
+    }
+    if (t.nfew) {
+        uint32_t pos_k;
+        k = term_few(t, p, pos_k);
+        return pos_k - p;
+    }
+    k = term_lower_bound(t, p);
+    return t.pos[k] - p;
 }
 
 struct PackedText {
@@ -166,8 +199,8 @@ template <int BITS>
 __device__ __forceinline__ uint64_t initial_key_of(uint64_t w, const TermTable &terms, bool segmented, uint32_t i) {
     // (one segment: no search and, above all, no load that the key would have to wait for behind its text
     // window -- the first radix pass generates 2^30 keys)
-    const uint32_t k = terms.count == 1 ? 0u : term_lower_bound(terms, i);
-    const uint32_t lim = (terms.count == 1 ? terms.end : terms.pos[k]) - i;  // symbols before the next terminator
+    uint32_t k;
+    const uint32_t lim = term_limit(terms, i, k);  // symbols before the next terminator
     if (BITS == 2 && segmented && terms.seq_shift == 0) {
         const uint32_t tag = lim < (uint32_t)kSegSyms ? lim : (uint32_t)kSegSyms;
         uint64_t sym = w >> (64 - kSegSyms * 2);
