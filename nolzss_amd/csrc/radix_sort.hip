@@ -475,6 +475,21 @@ __global__ __launch_bounds__(kThreads) void plain_scatter_kernel(const uint32_t 
     }
 }
 
+// out[idx[k]] = low half, out2[idx[k]] = high half of packed[k] (small inputs of permute_packed)
+__global__ __launch_bounds__(kThreads) void plain_packed_scatter_kernel(const uint32_t *__restrict__ idx,
+                                                                        const uint64_t *__restrict__ packed, size_t count,
+                                                                        uint32_t *__restrict__ out, uint32_t *__restrict__ out2) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < count; k += stride) {
+        const uint32_t i = idx[k];
+        const uint64_t v = packed[k];
+        if (i < count) {
+            out[i] = (uint32_t)v;
+            out2[i] = (uint32_t)(v >> 32);
+        }
+    }
+}
+
 // out2[idx[k]] = k + 1 (small inputs: the second value of bucketed_scatter's out2 form, written directly)
 __global__ __launch_bounds__(kThreads) void plain_rank_scatter_kernel(const uint32_t *__restrict__ idx, size_t count,
                                                                       uint32_t *__restrict__ out2, uint32_t n_out) {
@@ -891,6 +906,40 @@ void bucketed_scatter(uint32_t *idx[2], uint32_t *val[2], size_t count, uint32_t
         const uint32_t num_tiles = (uint32_t)div_up(count, kTile);
         const uint32_t grid = xcd_grid(num_tiles);
         plain_scatter_kernel<<<grid, kThreads, 0, stream>>>(idx[cur], val[cur], count, out, n_out, num_tiles);
+        KERNEL_CHECK();
+    }
+    arena.rewind(amark);
+}
+
+void permute_packed(uint32_t *idx, uint64_t *packed, size_t count, uint32_t *out, uint32_t *out2, Arena &arena,
+                    hipStream_t stream, Profiler *prof) {
+    if (count == 0) return;
+    int nb = 1;
+    while (nb < 32 && (1ull << nb) < (uint64_t)count) ++nb;
+    if (count <= (size_t(1) << 22) || nb > 2 * kRadixBits + kWindowBitsMax) {
+        ProfScope ps(prof, "bucket_scatter", stream, 20.0 * (double)count);
+        const unsigned g = (unsigned)std::min<size_t>(div_up(count, kThreads), 256u * 16u);
+        plain_packed_scatter_kernel<<<g, kThreads, 0, stream>>>(idx, packed, count, out, out2);
+        KERNEL_CHECK();
+        return;
+    }
+    // two partition passes by the digits above the window bits, then the windows (bucketed_scatter, the two-value form)
+    const size_t amark = arena.mark();
+    const int wb = nb > 2 * kRadixBits + 10 ? nb - 2 * kRadixBits : 10;
+    const uint32_t num_tiles = (uint32_t)div_up(count, kTile);
+    uint32_t *hist = arena.alloc<uint32_t>((size_t)kBins * num_tiles);
+    uint32_t *idx_b = arena.alloc<uint32_t>(count);
+    uint64_t *packed_b = arena.alloc<uint64_t>(count);
+    radix_pass<uint32_t, uint32_t, PairSrc, uint64_t>(PairSrc{idx, packed}, idx_b, packed_b, count, wb, hist, num_tiles,
+                                                      4.0 * (double)count, 24.0 * (double)count, arena, stream, prof);
+    uint16_t *idx16 = reinterpret_cast<uint16_t *>(idx);  // (the inputs are free now)
+    radix_pass<uint32_t, uint16_t, PairSrc, uint64_t>(PairSrc{idx_b, packed_b}, idx16, packed, count, wb + kRadixBits, hist,
+                                                      num_tiles, 4.0 * (double)count, 22.0 * (double)count, arena, stream, prof);
+    {
+        ProfScope ps(prof, "window_scatter", stream, 18.0 * (double)count);
+        const uint32_t W = 1u << wb;
+        window_scatter2_kernel<<<(unsigned)div_up(count, W), kWindow2Threads, 0, stream>>>(idx16, packed, out, out2,
+                                                                                          (uint32_t)count, wb);
         KERNEL_CHECK();
     }
     arena.rewind(amark);

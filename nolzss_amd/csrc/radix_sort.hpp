@@ -135,6 +135,11 @@ struct RecordScatterPlan {
 void bucketed_scatter(uint32_t *idx[2], uint32_t *val[2], size_t count, uint32_t *out, uint32_t n_out,
                       Arena &arena, hipStream_t stream, Profiler *prof, bool keep_input, bool keep_val = true,
                       const RecordScatterPlan *plan = nullptr, uint32_t *out2 = nullptr);
+// The same permutation for pairs that already carry both values in one 64-bit word (low half -> out, high half ->
+// out2) and are a permutation of [0, count): out[idx[k]] = (uint32_t)packed[k], out2[idx[k]] = packed[k] >> 32.
+// Both inputs are overwritten (they serve as buffers of the later passes).
+void permute_packed(uint32_t *idx, uint64_t *packed, size_t count, uint32_t *out, uint32_t *out2, Arena &arena,
+                    hipStream_t stream, Profiler *prof);
 // The plan for a text of n symbols whose records end at h_terms[k] (separator positions, the last entry = n);
 // false when the shape does not allow it (a record longer than 2^22 bases, or too many short ones).  The
 // tables live in the arena (not released here).

@@ -22,6 +22,7 @@
 #include "pipeline.hpp"
 #include "queues.hpp"
 #include "radix_sort.hpp"
+#include "scan.hpp"
 
 namespace nolzss {
 namespace {
@@ -59,7 +60,9 @@ __global__ __launch_bounds__(kLdsThreads) void rc_tile_kernel(const uint32_t *__
                                                               ShardQueue exact_q, ShardQueue far_q,
                                                               uint32_t *__restrict__ pmin1, uint32_t *__restrict__ pmax1,
                                                               uint32_t *__restrict__ plcp1, uint32_t pending_min,
-                                                              uint32_t *__restrict__ pending_flag) {
+                                                              uint32_t *__restrict__ pending_flag,
+                                                              const uint32_t *__restrict__ tile_off,
+                                                              uint32_t *__restrict__ cidx, uint64_t *__restrict__ cpacked) {
     constexpr int NS = 4, NP = 2;
     __shared__ __align__(16) uint32_t s_sa[kLdsSpan];
     __shared__ __align__(16) uint32_t s_lcp[kLdsSpan + 4];
@@ -98,6 +101,20 @@ __global__ __launch_bounds__(kLdsThreads) void rc_tile_kernel(const uint32_t *__
     constexpr int kRows = kLdsPerWave / 64;
     bool far[kRows], exact[kRows];
     uint32_t mask[kRows], rcl[kRows], fslot[kRows], eslot[kRows];
+    // COMPACT output (cidx != nullptr): only the ranks of the original strand leave the kernel, as pairs (position,
+    // code | rank + 1 << 32) in rank order at tile_off[tile] -- half of the pairs of S never need a place in text order
+    // (the codes and the inverse suffix array are read at positions < N only), so the permutation behind this kernel
+    // moves N pairs instead of 2 N + 2.  Ranks of the original strand in the wavefronts in front of mine: counted from
+    // the staged tile.
+    const bool compact_out = cidx != nullptr;
+    uint32_t cbase = 0;
+    if (compact_out) {
+        uint32_t before = 0;
+        for (int t2 = lane_id(); t2 < w * kLdsPerWave; t2 += 64)
+            before += ((uint64_t)base + t2 < m && s_sa[t2 + kLdsReach] < N) ? 1u : 0u;
+        cbase = tile_off[blockIdx.x] + wave_reduce(before, OpAdd<uint32_t>());
+    }
+    uint32_t cv[kRows], cat[kRows];
 #pragma unroll
     for (int row = 0; row < kRows; ++row) {
         const int t = w * kLdsPerWave + row * 64 + lane_id();
@@ -105,9 +122,16 @@ __global__ __launch_bounds__(kLdsThreads) void rc_tile_kernel(const uint32_t *__
         const uint32_t i = s_sa[t + kLdsReach];
         far[row] = exact[row] = false;
         mask[row] = rcl[row] = 0;
+        cv[row] = 0;
+        const bool orig = rr < m && i < N;
+        {
+            const uint64_t ob = __ballot(orig);
+            cat[row] = orig ? cbase + (uint32_t)__popcll(ob & lanemask_lt()) : 0xffffffffu;
+            cbase += (uint32_t)__popcll(ob);
+        }
         if (rr >= m) continue;
         if (i >= N) {  // only positions of the original strand are factorized (:241)
-            code_by_rank[rr] = 0;
+            if (!compact_out) code_by_rank[rr] = 0;
             continue;
         }
         uint32_t lp = s_len[t], ls = s_len[kLdsTile + t];
@@ -124,7 +148,8 @@ __global__ __launch_bounds__(kLdsThreads) void rc_tile_kernel(const uint32_t *__
         far[row] = far_f || far_r;  // finished from global memory
         if (!far[row]) {
             rcl[row] = ru > rd ? ru : rd;
-            exact[row] = rc_decide(i, lp, match_pos(s_sa, s_pos[t]), ls, match_pos(s_sa, s_pos[kLdsTile + t]), rcl[row], code_by_rank + rr);
+            exact[row] = rc_decide(i, lp, match_pos(s_sa, s_pos[t]), ls, match_pos(s_sa, s_pos[kLdsTile + t]), rcl[row], &cv[row]);
+            if (!compact_out) code_by_rank[rr] = cv[row];
         }
     }
     shard_slots<kRows>(far_q, shard, far, fslot);
@@ -135,12 +160,37 @@ __global__ __launch_bounds__(kLdsThreads) void rc_tile_kernel(const uint32_t *__
         const uint64_t rr = (uint64_t)base + t;
         if (far[row]) {
             far_q.items[fslot[row]] = (uint32_t)rr;
-            code_by_rank[rr] = mask[row];
+            code_by_rank[rr] = mask[row];  // (read back by rc_far_kernel, by rank; the code of a far rank comes from there)
         }
         if (exact[row]) {
             exact_q.items[eslot[row]] = s_sa[t + kLdsReach];
             exact_q.items2[eslot[row]] = rcl[row];
         }
+        if (compact_out && cat[row] != 0xffffffffu) {
+            cidx[cat[row]] = s_sa[t + kLdsReach];
+            cpacked[cat[row]] = (uint64_t)cv[row] | ((uint64_t)((uint32_t)rr + 1u) << 32);
+        }
+    }
+}
+
+// ranks of the original strand per tile of rc_tile_kernel (the offsets of its compact output, after a scan)
+__global__ __launch_bounds__(kLdsThreads) void rc_count_original_kernel(const uint32_t *__restrict__ sa, uint32_t m, uint32_t N,
+                                                                        uint32_t *__restrict__ counts) {
+    const size_t base = (size_t)blockIdx.x * kLdsTile;
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < kLdsTile / kLdsThreads; ++k) {
+        const size_t r = base + (size_t)k * kLdsThreads + threadIdx.x;
+        c += (r < m && sa[r < m ? r : m - 1] < N) ? 1u : 0u;
+    }
+    c = wave_reduce(c, OpAdd<uint32_t>());
+    __shared__ uint32_t s_part[kLdsWaves];
+    if (lane_id() == 0) s_part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int k = 0; k < kLdsWaves; ++k) t += s_part[k];
+        counts[blockIdx.x] = t;
     }
 }
 
@@ -338,8 +388,26 @@ uint32_t run_rc_pipeline_packed(Context &ctx, const PackedText &text, size_t sta
         const uint32_t **count_ptrs = arena.alloc<const uint32_t *>(2);
         uint32_t *totals = arena.alloc<uint32_t>(2);  // [0] exact-search queue, [1] far queue
         uint32_t *by_rank = arena.alloc<uint32_t>(m);
-        uint32_t *scratch_idx = arena.alloc<uint32_t>(m);
-        uint32_t *scratch_val = arena.alloc<uint32_t>(isa_deferred ? 2 * (size_t)m : (size_t)m);  // (two values per pair: radix_sort.hpp)
+        // compact output of the tile kernel (above): when the permutation also delivers the inverse suffix array, and
+        // the N pairs fit its two partition passes
+        static const bool no_compact = getenv("NOLZSS_RC_NO_COMPACT") != nullptr;  // (A/B switch)
+        static const uint32_t compact_min = getenv("NOLZSS_RC_COMPACT_MIN") ? (uint32_t)atoll(getenv("NOLZSS_RC_COMPACT_MIN")) : (1u << 22);  // (tests: 1)
+        const bool compact = isa_deferred && !no_compact && N >= compact_min && N <= (1u << 30);
+        uint32_t *scratch_idx = nullptr, *scratch_val = nullptr, *tile_off = nullptr, *cidx = nullptr;
+        uint64_t *cpacked = nullptr;
+        if (compact) {
+            uint32_t *tile_cnt = arena.alloc<uint32_t>(tiles);
+            tile_off = arena.alloc<uint32_t>(tiles);
+            cidx = arena.alloc<uint32_t>(N);
+            cpacked = arena.alloc<uint64_t>(N);
+            ProfScope ps(ctx.profiler(), "rc_candidates", s);
+            rc_count_original_kernel<<<tiles, kLdsThreads, 0, s>>>(sa, m, N, tile_cnt);
+            KERNEL_CHECK();
+            scan_exclusive_add_u32(tile_cnt, tile_off, tiles, nullptr, arena, s);
+        } else {
+            scratch_idx = arena.alloc<uint32_t>(m);
+            scratch_val = arena.alloc<uint32_t>(isa_deferred ? 2 * (size_t)m : (size_t)m);  // (two values per pair: radix_sort.hpp)
+        }
         HIP_CHECK(hipMemsetAsync(qcounts, 0, 2 * kQShards * kQPad * sizeof(uint32_t), s));
         const uint32_t *h_ptrs[2] = {exact_q.counts, far_q.counts};
         HIP_CHECK(hipMemcpyAsync(count_ptrs, h_ptrs, sizeof h_ptrs, hipMemcpyHostToDevice, s));
@@ -354,7 +422,8 @@ uint32_t run_rc_pipeline_packed(Context &ctx, const PackedText &text, size_t sta
             rc_tile_kernel<<<tiles, kLdsThreads, 0, s>>>(
                 sa, lcp, m, N, by_rank, exact_q, far_q, fused_level1 ? const_cast<uint32_t *>(Pmin.lvl[1]) : nullptr,
                 fused_level1 ? const_cast<uint32_t *>(Pmax.lvl[1]) : nullptr,
-                fused_level1 ? const_cast<uint32_t *>(Plcp.lvl[1]) : nullptr, pending_threshold(), pending_flag);
+                fused_level1 ? const_cast<uint32_t *>(Plcp.lvl[1]) : nullptr, pending_threshold(), pending_flag, tile_off, cidx,
+                cpacked);
             KERNEL_CHECK();
         }
         {
@@ -379,16 +448,20 @@ uint32_t run_rc_pipeline_packed(Context &ctx, const PackedText &text, size_t sta
                 fill_pyramid(Plcp, 1, false, s);
                 HIP_CHECK(hipMemsetAsync(qcounts, 0, 2 * kQShards * kQPad * sizeof(uint32_t), s));
                 rc_tile_kernel<<<tiles, kLdsThreads, 0, s>>>(sa, lcp, m, N, by_rank, exact_q, far_q, nullptr, nullptr, nullptr,
-                                                             0u, nullptr);
+                                                             0u, nullptr, tile_off, cidx, cpacked);
                 KERNEL_CHECK();
             }
         }
         {
             ProfScope ps(ctx.profiler(), "rc_to_text_order", s);
-            uint32_t *idx[2] = {sa, scratch_idx};
-            uint32_t *val[2] = {by_rank, scratch_val};
-            // (isa_deferred: the same permutation writes isa[sa[r]] = r + 1)
-            bucketed_scatter(idx, val, m, code, m, arena, s, ctx.profiler(), true, true, nullptr, isa_deferred ? isa : nullptr);
+            if (compact) {  // code[i] and isa[i] for the N positions of the original strand
+                permute_packed(cidx, cpacked, N, code, isa, arena, s, ctx.profiler());
+            } else {
+                uint32_t *idx[2] = {sa, scratch_idx};
+                uint32_t *val[2] = {by_rank, scratch_val};
+                // (isa_deferred: the same permutation writes isa[sa[r]] = r + 1)
+                bucketed_scatter(idx, val, m, code, m, arena, s, ctx.profiler(), true, true, nullptr, isa_deferred ? isa : nullptr);
+            }
         }
         uint32_t h[2] = {0, 0};
         read_totals(h);
