@@ -297,7 +297,8 @@ def test_differential_fuzz_short():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for env_extra, seed in (({}, "11"), ({"NOLZSS_DNA_FAST_MIN": "1"}, "12")):
+    # (third run: RC mode hands only the ranks of the original strand to its permutation whatever the size, rc.hip)
+    for env_extra, seed in (({}, "11"), ({"NOLZSS_DNA_FAST_MIN": "1"}, "12"), ({"NOLZSS_RC_COMPACT_MIN": "1"}, "13")):
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz.py"), "8", seed], cwd=root,
                            env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and "no mismatch" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
