@@ -163,3 +163,19 @@ def test_concatenation_without_rc_many_sequences(native):
     S, total, sent = native.prepare_multiple_dna_sequences_no_rc_bytes(seqs)
     assert max(S) > ord("T") and len(sent) >= 199
     assert native.factorize(S) == oracle.factorize(S)
+
+
+@pytest.mark.timeout(600)
+def test_rc_six_million_bases_every_factor(native):
+    """6 M bases with copied blocks (and their reverse complements, which RC mode finds): above 2^22 bases the
+    candidate kernel hands only the ranks of the original strand to the permutation that brings codes and ranks
+    into text order, and that permutation takes its two partition passes and the LDS windows (rc.hip,
+    radix_sort.hip: permute_packed) -- the path of BASELINE config 5, here at a size the oracle finishes in seconds."""
+    t = gen.repeat_dna(6_000_000, seed=0x5EED0005 + 17)
+    got = native.factorize_dna_w_rc_array(t)
+    S, _, _ = oracle.prepare_multiple_dna_w_rc([t.tobytes()])
+    exp = oracle.factors_array_multiple_dna_w_rc(S)
+    assert len(got) == len(exp)
+    for k in ("start", "length", "ref"):
+        assert np.array_equal(got[k], exp[k]), k
+    assert (got["ref"] >> np.uint64(63)).any()  # reverse-complement factors are there

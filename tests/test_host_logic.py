@@ -134,6 +134,30 @@ def test_prepare_w_rc_host_side_matches_oracle():
         _noLZSS.prepare_multiple_dna_sequences_w_rc(["A"] * 70)
 
 
+def test_prepare_w_rc_long_sequences_on_several_threads():
+    """Sequences of tens of megabytes are validated, case-folded and reverse-complemented in pieces on several host
+    threads (api.hip: host_parallel): same bytes as numpy, and an invalid byte is still reported at its FIRST index."""
+    import numpy as np
+    from nolzss_amd import _noLZSS
+    rng = np.random.default_rng(7)
+    a = np.frombuffer(b"ACGTacgt", dtype=np.uint8)[rng.integers(0, 8, size=23_000_001)]
+    b = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=9_500_003)]
+    S, orig, sent = _noLZSS.prepare_multiple_dna_sequences_w_rc_bytes([a.tobytes().decode(), b.tobytes().decode()])
+    up = lambda x: x & np.uint8(0xDF)
+    comp = np.zeros(256, dtype=np.uint8)
+    comp[list(b"ACGT")] = list(b"TGCA")
+    rc = lambda x: comp[up(x)][::-1]
+    exp = np.concatenate([up(a), [1], up(b), [2], rc(b), [3], rc(a), [4]]).astype(np.uint8)
+    got = np.frombuffer(S, dtype=np.uint8)
+    assert orig == len(a) + len(b) + 2 and len(got) == len(exp)
+    assert np.array_equal(got, exp)
+    bad = bytearray(a.tobytes())
+    bad[20_000_000] = ord("N")
+    bad[11_111_111] = ord("x")
+    with pytest.raises(RuntimeError, match="Invalid nucleotide 'x'"):
+        _noLZSS.prepare_multiple_dna_sequences_w_rc_bytes([bytes(bad).decode()])
+
+
 def test_fasta_parsing_mirrors_reference(tmp_path):
     """reference: tests/test_genomics.py:96-144, src/noLZSS/genomics/fasta.py:28-76"""
     from nolzss_amd.genomics.fasta import FASTAError, _parse_fasta_content, _load_validated
