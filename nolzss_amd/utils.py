@@ -35,11 +35,13 @@ _FOOTER = struct.Struct("<8sQQQQQ")  # magic, num_factors, num_sequences, num_se
 
 
 def _read_footer(f) -> Tuple[int, int, int, int, int]:
-    f.seek(0, 2)
-    if f.tell() < _FOOTER.size:
-        raise NoLZSSError("File too small to contain valid footer")
+    # (a file shorter than the footer fails in the seek, as in the reference: the caller reports
+    # "Error reading file ...: [Errno 22] Invalid argument" -- pinned by tests/golden/python_ref_utils.json)
     f.seek(-_FOOTER.size, 2)
-    magic, nf, nseq, nsent, fsize, total = _FOOTER.unpack(f.read(_FOOTER.size))
+    raw = f.read(_FOOTER.size)
+    if len(raw) != _FOOTER.size:
+        raise NoLZSSError("File too small to contain valid footer")
+    magic, nf, nseq, nsent, fsize, total = _FOOTER.unpack(raw)
     if magic != b"noLZSSv2":
         raise NoLZSSError("Invalid file format: missing noLZSS magic footer (expected v2 format)")
     return nf, nseq, nsent, fsize, total
@@ -95,5 +97,9 @@ def read_factors_binary_file_with_metadata(filepath: Union[str, Path]) -> Dict[s
     """Factors as (start, length, ref & ~RC_MASK, is_rc) plus the metadata (reference: utils.py:254-357)."""
     meta = read_binary_file_metadata(filepath)
     rc_mask = 1 << 63
-    meta["factors"] = [(s, l, r & (rc_mask - 1), bool(r & rc_mask)) for s, l, r in read_factors_binary_file(filepath)]
-    return meta
+    factors = [(s, l, r & (rc_mask - 1), bool(r & rc_mask)) for s, l, r in read_factors_binary_file(filepath)]
+    # (the reference's dictionary has no 'num_factors' here, unlike read_binary_file_metadata: utils.py:350-357;
+    # pinned by tests/golden/python_ref_utils.json)
+    return {"factors": factors, "sentinel_factor_indices": meta["sentinel_factor_indices"],
+            "sequence_names": meta["sequence_names"], "num_sequences": meta["num_sequences"],
+            "num_sentinels": meta["num_sentinels"], "total_length": meta["total_length"]}
