@@ -74,7 +74,96 @@ ALG_BYTES_PER_BASE_RC = 84.0  # SURVEY.md 8d, reverse-complement mode (arrays ov
 # rs_scatter_kernel: 2 * (sizeof(key) + 4) algorithmic bytes per (key, value) pair per launch
 # (24 B for the u64-key sorts, 16 B for the u32-key partition passes); the library sums them.
 DOMINANT = "rs_scatter"
-PMC_FILES = ["r03_pmc_radix_traffic.json", "r02_pmc_radix_traffic.json", "r01_pmc_radix_traffic.json"]
+PMC_FILES = ["r04_pmc_radix_traffic.json", "r03_pmc_radix_traffic.json", "r02_pmc_radix_traffic.json", "r01_pmc_radix_traffic.json"]
+# per-kernel counters of ONE factorization of the 2^30-base benchmark text (tools/pmc_step.sh; committed summary)
+STEP_PMC_FILE = "r04_pmc_step.json"
+SHADER_CLOCK_HZ = 2.4e9   # MI355X peak engine clock
+SIMDS = 256 * 4           # 256 CUs x 4 SIMDs; a wave64 VALU instruction occupies its SIMD for 4 cycles
+GATHER_LINE_RATE = 44.1e9  # random 256-bit windows per second the chip sustains (tools/gatherbench.hip, profiles/r01_gatherbench.txt)
+
+
+def measure_copy_ceiling(dev, nbytes=1 << 30, reps=6):
+    """Streaming-copy ceiling of this box, measured before the timed region ("report both"): a device-to-
+    device copy of 1 GiB moves 2 GiB (read + write); best of `reps`, HIP events on torch's stream."""
+    a = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    b = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    a.zero_()
+    b.copy_(a)
+    torch.cuda.synchronize()
+    best = float("inf")
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        b.copy_(a)
+        e1.record()
+        e1.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    del a, b
+    torch.cuda.empty_cache()
+    return 2.0 * nbytes / (best * 1e-3) / 1e9
+
+
+def step_counters():
+    """The committed per-kernel counter summary (tools/pmc_step.sh) or None."""
+    try:
+        with open(ROOT / "profiles" / STEP_PMC_FILE) as f:
+            return json.load(f)
+    except Exception:
+        return None
+
+
+# library stage name -> (kernel of the counter summary, what bounds it)
+KERNEL_OF_STAGE = [
+    ("rs_scatter.u32", "rs_scatter_kernel<u32, u32, ArraySrc<u32>, u32>", "hbm"),
+    ("sa_direct_sort", "group_refine_kernel<2, false>", "valu_issue + random_lines"),
+    ("lpf", "lpf_tile_kernel<false>", "lds + valu_issue"),
+    ("factor_emit", "factor_kernel<false, false>", "random_lines"),
+    ("sa_regroup", "regroup_kernel<true, 3>", "valu_issue"),
+    ("window_scatter", "window_scatter2_kernel", "hbm"),
+    ("rs_scatter.text", "rs_scatter_kernel<u64, u32, Text16Src, u32>", "hbm (writes) + valu_issue"),
+    ("rs_hist", "rs_hist_kernel<u32, ArraySrc<u32> >", "hbm"),
+]
+
+
+def kernel_bounds(stats, steps, pmc):
+    """roofline.kernels: the largest kernels of the step, each with its own bound.  Durations are this run's HIP events
+    (live); instruction, LDS and HBM byte counts per launch come from the committed counter summary (derived: they do not
+    change unless the kernel does).  valu_issue_frac = VALU wave-instructions x 4 cycles / (1024 SIMDs x clock) over the
+    kernel's time; lds_frac = LDS-active cycles per CU over its time; hbm_frac = counter bytes over its time against the
+    8 TB/s spec peak; random_line_frac = fetched 128-byte lines per second against the gather ceiling of tools/gatherbench."""
+    out = []
+    ks = (pmc or {}).get("kernels", {})
+    for stage, kernel, bound in KERNEL_OF_STAGE:
+        if stage not in stats or stats[stage][1] <= 0:
+            continue
+        cnt, ms, nbytes = stats[stage]
+        e = {"stage": stage, "kernel": kernel, "bound": bound, "ms_per_step": ms / steps, "launches_per_step": cnt / steps}
+        if nbytes:
+            e["algorithmic_GBps"] = nbytes / (ms * 1e-3) / 1e9
+            e["algorithmic_frac_of_hbm_peak"] = e["algorithmic_GBps"] / HBM_PEAK_GBS
+        c = ks.get(kernel)
+        if c and c.get("launches"):
+            per_step_launches = cnt / steps
+            scale = per_step_launches / c["launches"]  # the summary holds one factorization
+            t = ms / steps * 1e-3
+            if "SQ_INSTS_VALU" in c:
+                e["valu_issue_frac"] = c["SQ_INSTS_VALU"] * scale * 4.0 / (SIMDS * SHADER_CLOCK_HZ) / t
+            if "SQ_INSTS_SALU" in c and "SQ_INSTS_VALU" in c and c["SQ_INSTS_VALU"]:
+                e["salu_per_valu"] = c["SQ_INSTS_SALU"] / c["SQ_INSTS_VALU"]
+            if "SQ_LDS_IDX_ACTIVE" in c:
+                e["lds_frac"] = c["SQ_LDS_IDX_ACTIVE"] * scale / 256.0 / SHADER_CLOCK_HZ / t
+                if c["SQ_LDS_IDX_ACTIVE"]:
+                    e["lds_bank_conflict_share"] = c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"]
+            hbm = (c.get("fetch_bytes", 0.0) + c.get("write_bytes", 0.0)) * scale
+            if hbm:
+                e["hbm_GBps"] = hbm / t / 1e9
+                e["hbm_frac"] = e["hbm_GBps"] / HBM_PEAK_GBS
+            if "random_lines" in bound and c.get("fetch_bytes"):
+                e["random_line_frac"] = c["fetch_bytes"] * scale / 128.0 / t / GATHER_LINE_RATE
+            e["counters_derived_from"] = f"profiles/{STEP_PMC_FILE}"
+        out.append(e)
+    out.sort(key=lambda e: -e["ms_per_step"])
+    return out
 
 
 def measured_traffic_ratio():
@@ -188,6 +277,7 @@ def run_single_sequence(job: Job, a):
             dist.all_gather_into_tensor(counts, mine)
         return z
 
+    copy_ceiling = measure_copy_ceiling(job.dev) if job.rank == 0 else None
     for _ in range(a.warmup):
         step()
     native.profile_enable(True)
@@ -200,6 +290,14 @@ def run_single_sequence(job: Job, a):
     elapsed = time.perf_counter() - t0
     stats = native.profile_report()
     native.profile_enable(False)
+    # every rank's own clock, device and factor count, for rank 0's line
+    mine_row = torch.tensor([elapsed / a.steps * 1e3, float(job.local_rank), float(z)], dtype=torch.float64, device=job.cdev)
+    rank_rows = torch.zeros(job.world * 3, dtype=torch.float64, device=job.cdev)
+    if job.collectives:
+        dist.all_gather_into_tensor(rank_rows, mine_row)
+    else:
+        rank_rows[:3] = mine_row
+    rank_rows = rank_rows.view(job.world, 3).cpu().tolist()
     elapsed = job.max_over_ranks(elapsed)
 
     # PCIe-inclusive variant (records downloaded into host memory), rank-local, one run
@@ -226,6 +324,7 @@ def run_single_sequence(job: Job, a):
                 for k, v in sorted(family.items())}
     nested = {"rs_hist", "rs_scan", "bucket_scatter", "window_scatter"} | set(family)
     ratio, ratio_file = measured_traffic_ratio()
+    pmc = step_counters()
     step_s = elapsed / a.steps
     out = {
         "metric": "bases/sec factorized (1 GB sigma=4 DNA) + HBM GB/s fraction",
@@ -247,18 +346,33 @@ def run_single_sequence(job: Job, a):
                    "parallelism": f"{job.world} independent sequence shard(s), all-gather of counts"},
         "roofline": {"bound": "hbm", "kernel": "rs_scatter_kernel", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     # the second ceiling of SURVEY.md 8d: a streaming copy measured on this box before the timed region
+                     "peak_measured": copy_ceiling, "frac_of_measured": (achieved / copy_ceiling) if copy_ceiling else None,
+                     "peak_measured_how": "device-to-device copy of 1 GiB (2 GiB moved), best of 6, HIP events",
                      "traffic": (ratio * nbytes / cnt) if (ratio and cnt) else None,
+                     "traffic_kind": "derived" if ratio_file else None,
+                     "traffic_derived_from": f"profiles/{ratio_file}" if ratio_file else None,
                      "traffic_source": (f"profiles/{ratio_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
                                         "passes): HBM bytes over algorithmic bytes of the u32 passes at 2^30 pairs")
                      if ratio_file else None,
                      "launches": cnt,
                      "avg_launch_ms": (ms / cnt) if cnt else None,
                      "algorithmic_bytes_per_launch": (nbytes / cnt) if cnt else None,
-                     "by_class": by_class},
+                     "by_class": by_class,
+                     "kernels": kernel_bounds(stats, a.steps, pmc)},
         # SURVEY.md 8d end-to-end figure: 50 B per base of compulsory traffic over the whole pipeline
         "pipeline_hbm": {"algorithmic_bytes_per_base": ALG_BYTES_PER_BASE,
                          "achieved_GBps_per_gpu": ALG_BYTES_PER_BASE * n / step_s / 1e9,
-                         "frac_of_peak_per_gpu": ALG_BYTES_PER_BASE * n / step_s / 1e9 / HBM_PEAK_GBS},
+                         "frac_of_peak_per_gpu": ALG_BYTES_PER_BASE * n / step_s / 1e9 / HBM_PEAK_GBS,
+                         # what the whole step really moves: FETCH_SIZE + WRITE_SIZE summed over every kernel of one
+                         # factorization (tools/pmc_step.sh, separate passes, gfx950 correction), per base
+                         "traffic_bytes_per_base": ((pmc or {}).get("step") or {}).get("hbm_bytes_per_base")
+                         if (pmc and pmc.get("bases") == n) else None,
+                         "traffic_GBps_per_gpu": (pmc["step"]["hbm_bytes_per_base"] * n / step_s / 1e9)
+                         if (pmc and pmc.get("bases") == n and pmc["step"].get("hbm_bytes_per_base")) else None,
+                         "traffic_derived_from": f"profiles/{STEP_PMC_FILE}" if pmc else None},
+        "per_rank": [{"rank": k, "device": f"cuda:{int(r[1])}", "bases": n, "factors": int(r[2]), "ms_per_step": r[0]}
+                     for k, r in enumerate(rank_rows)],
         "pcie_inclusive_bases_per_s": n / pcie_dt,
         "stages_ms_per_step": {k: v[1] / a.steps for k, v in sorted(stats.items(), key=lambda kv: -kv[1][1])
                                if k not in nested},
@@ -381,6 +495,7 @@ def run_fasta_shard(job: Job, a, with_file: bool):
     idx = torch.tensor(mine, dtype=torch.int64, device=job.cdev)
 
     lib_seconds = [0.0]
+    gather_seconds = [0.0]
 
     def step():
         t_lib = time.perf_counter()
@@ -390,7 +505,14 @@ def run_fasta_shard(job: Job, a, with_file: bool):
         if mine:
             vec[idx] = torch.tensor(zs, dtype=torch.int64, device=job.cdev)
         if job.collectives:
+            # the one collective of the path, timed on its own (it includes the wait for the slowest rank)
+            if job.backend == "nccl":
+                torch.cuda.synchronize()
+            t_g = time.perf_counter()
             dist.all_gather_into_tensor(gathered, vec)
+            if job.backend == "nccl":
+                torch.cuda.synchronize()
+            gather_seconds[0] += time.perf_counter() - t_g
             return gathered.view(job.world, m).sum(dim=0)
         return vec.clone()
 
@@ -398,12 +520,22 @@ def run_fasta_shard(job: Job, a, with_file: bool):
         step()
     job.barrier()
     lib_seconds[0] = 0.0
+    gather_seconds[0] = 0.0
     t0 = time.perf_counter()
     for _ in range(a.fasta_steps):
         counts = step()
     job.barrier()
     elapsed = job.max_over_ranks(time.perf_counter() - t0)
     counts = counts.cpu().tolist()
+    # what every rank did, for rank 0's line: compute time of its share, time in the all-gather, device, records
+    mine_row = torch.tensor([lib_seconds[0] / a.fasta_steps * 1e3, gather_seconds[0] / a.fasta_steps * 1e3,
+                             float(job.local_rank), float(len(mine))], dtype=torch.float64, device=job.cdev)
+    rows = torch.zeros(job.world * 4, dtype=torch.float64, device=job.cdev)
+    if job.collectives:
+        dist.all_gather_into_tensor(rows, mine_row)
+    else:
+        rows[:4] = mine_row
+    rows = rows.view(job.world, 4).cpu().tolist()
     step_s = elapsed / a.fasta_steps
     total = float(m) * L
     out = {"workload": f"fasta512: {m} records x 2^{a.fasta_record_log2} random ACGT bases (seeds 0x4000+k), LPT shard "
@@ -413,6 +545,10 @@ def run_fasta_shard(job: Job, a, with_file: bool):
            "value": total / step_s, "unit": "bases/s", "ms_per_step": step_s * 1e3,
            "library_call_ms_per_step": lib_seconds[0] / a.fasta_steps * 1e3,
            "records_per_rank": [owners.count(r) for r in range(job.world)],
+           "per_rank_ms": [r[0] for r in rows],          # compute of the rank's share per step (the library call)
+           "allgather_ms": [r[1] for r in rows],         # the all-gather of the counts per step, as each rank saw it
+           "per_rank": [{"rank": k, "device": f"cuda:{int(r[2])}", "records": int(r[3]), "compute_ms_per_step": r[0],
+                         "allgather_ms_per_step": r[1]} for k, r in enumerate(rows)],
            "total_factors": int(sum(counts)),
            "pipeline_hbm_frac_per_gpu": ALG_BYTES_PER_BASE * (total / job.world) / step_s / 1e9 / HBM_PEAK_GBS}
     # PCIe-inclusive: the host-buffer batch entry point (nolzss_factorize_batch), counts only

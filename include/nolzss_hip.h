@@ -226,7 +226,10 @@ void nolzss_free_batch(nolzss_factor **out, size_t *z, size_t m);
 /* The plain per-sequence batch with the records already in the memory of `device` (d_texts[j] = device
  * pointer to lens[j] bytes): no PCIe leg.  emit = 0 counts, emit = 1 also builds the factor records of
  * every record in HBM and stops there.  z[j] (caller-allocated, m entries) = factors of record j.  Used by
- * bench.py for the FASTA shard workload (inputs resident in HBM when the clock starts). */
+ * bench.py for the FASTA shard workload (inputs resident in HBM when the clock starts).
+ * THIS CALL MAY SLEEP: records are merged into runs that several host threads ("lanes") submit, and when the first two
+ * runs are of similar size the later lanes start up to NOLZSS_DEVICE_MERGE_STAGGER_MS (default 20 ms, scaled by the run
+ * size) after the first, so that their bandwidth-bound and issue-bound phases overlap instead of coinciding. */
 int nolzss_factorize_batch_device(const void *const *d_texts, const size_t *lens, size_t m, int device, int emit,
                                   size_t *z);
 
@@ -285,6 +288,13 @@ int nolzss_debug_parse_nucleotide_fasta(const char *path, char **ids, size_t *id
                                         size_t *sequences_bytes, size_t *count);
 /* The shard plan of nolzss_read_nucleotide_fasta: owners[j] = shard of a record of lens[j] bases. */
 int nolzss_debug_lpt_plan(const size_t *lens, size_t m, size_t bins, size_t *owners);
+/* The static plan of nolzss_factorize_batch / _dna_w_rc for m records on n_dev devices, without touching a device
+ * (host logic only): chunk_of[j] = index of the merged run record j shares (-1: none), device_of[j] = slot in the device
+ * list of the pipeline run record j takes on its own (-1: none; both -1: an empty record).  The merged runs are taken by
+ * n_dev x 2 lanes from ONE work queue (lane w on device w % n_dev), the single records are dealt to the devices
+ * longest-processing-time first.  n_chunks (optional) = number of merged runs. */
+int nolzss_debug_batch_plan(const size_t *lens, size_t m, size_t n_dev, int with_rc, int32_t *chunk_of, int32_t *device_of,
+                            size_t *n_chunks);
 /* Gives the device arenas that no call is using back to the driver (they are otherwise kept between
  * calls and only grow; the library does this by itself when a reservation fails). */
 int nolzss_debug_trim_arenas(int device, size_t *released_bytes);

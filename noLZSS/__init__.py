@@ -9,6 +9,18 @@ from the ctypes mirror `nolzss_amd._noLZSS` -- every one of them calls the same 
 (include/nolzss_hip.h) of libnolzss_hip.so.  There is no CPU fallback: without the compiled module or
 the HIP library the import fails.
 """
+import os as _os
+from pathlib import Path as _Path
+
+# The compiled module is linked against nolzss_amd/libnolzss_hip.so (rpath); NOLZSS_LIB makes the ctypes mirror load
+# ANOTHER build of the library (A/B measurements, tools/ab_variant.sh).  Two builds in one process -- two arenas,
+# two sets of device state -- is never what a caller wants: this package refuses it.
+if _os.environ.get("NOLZSS_LIB"):
+    _default = _Path(__file__).resolve().parent.parent / "nolzss_amd" / "libnolzss_hip.so"
+    if _Path(_os.environ["NOLZSS_LIB"]).resolve() != _default:
+        raise ImportError(f"noLZSS: NOLZSS_LIB={_os.environ['NOLZSS_LIB']} names another build than the one noLZSS._noLZSS is "
+                          f"linked against ({_default}); use the nolzss_amd package for variant libraries, or unset it")
+
 from nolzss_amd import _noLZSS as _mirror  # first: loads libnolzss_hip.so (and the HIP runtime it shares with torch)
 from . import _noLZSS  # compiled (pybind11); ImportError if it has not been built
 

@@ -131,6 +131,7 @@ def _load():
     lib.nolzss_debug_parse_nucleotide_fasta.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), szp, C.POINTER(C.c_void_p),
                                                         szp, szp]
     lib.nolzss_debug_lpt_plan.argtypes = [szp, sz, sz, szp]
+    lib.nolzss_debug_batch_plan.argtypes = [szp, sz, sz, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), szp]
     lib.nolzss_profile_enable.argtypes = [C.c_int, C.c_int]
     lib.nolzss_profile_reset.argtypes = [C.c_int]
     lib.nolzss_profile_report.argtypes = [C.c_int, C.c_char_p, sz]
@@ -165,7 +166,7 @@ EXPORTED_SYMBOLS = [
     "nolzss_debug_arrays", "nolzss_debug_sort_pairs", "nolzss_debug_scan", "nolzss_debug_arena",
     "nolzss_debug_batch_counters", "nolzss_factorize_batch_dna_w_rc",
     "nolzss_debug_trim_arenas", "nolzss_debug_parse_fasta",
-    "nolzss_read_nucleotide_fasta", "nolzss_free_nucleotide_fasta", "nolzss_debug_parse_nucleotide_fasta", "nolzss_debug_lpt_plan", "nolzss_factorize_batch_device",
+    "nolzss_read_nucleotide_fasta", "nolzss_free_nucleotide_fasta", "nolzss_debug_parse_nucleotide_fasta", "nolzss_debug_lpt_plan", "nolzss_debug_batch_plan", "nolzss_factorize_batch_device",
     "nolzss_factorize_dna_w_rc_device",
 ]
 

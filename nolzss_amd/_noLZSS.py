@@ -793,6 +793,19 @@ def debug_lpt_plan(lengths, bins: int):
     return [owners[j] for j in range(m)]
 
 
+def debug_batch_plan(lengths, n_dev: int, with_rc: bool = False):
+    """The static plan of factorize_batch for these record lengths on n_dev devices (host only, no device touched):
+    (chunk_of, device_of, n_chunks) -- chunk_of[j] = merged run of record j or -1, device_of[j] = slot in the device
+    list of the run record j takes on its own or -1."""
+    m = len(lengths)
+    lens = (C.c_size_t * max(m, 1))(*lengths)
+    chunk_of = (C.c_int32 * max(m, 1))()
+    device_of = (C.c_int32 * max(m, 1))()
+    n_chunks = C.c_size_t()
+    check(lib.nolzss_debug_batch_plan(lens, m, n_dev, 1 if with_rc else 0, chunk_of, device_of, C.byref(n_chunks)))
+    return [chunk_of[j] for j in range(m)], [device_of[j] for j in range(m)], n_chunks.value
+
+
 def debug_trim_arenas() -> int:
     """Releases the idle device arenas of the default device; returns the bytes given back."""
     r = C.c_size_t()

@@ -53,21 +53,28 @@ def bind(native) -> dict:
         """number of factors of the bytes of a file (reference: core.py:89-107; `validate` is unused there too)"""
         return native.count_factors_file(_existing(filepath))
 
-    def write_factors_binary_file(data: Text, output_filepath: PathLike, validate: bool = True) -> None:
+    def write_factors_binary_file(data: Text, output_filepath: PathLike) -> None:
         """Kept from the reference (core.py:110-132 against bindings.cpp:180-187): the validated `data` goes to a
-        parameter of the native function that is an input FILE PATH, so `data` must name a file (README.md:65)."""
-        native.write_factors_binary_file(checked(data, validate), _writable(output_filepath))
+        parameter of the native function that is an input FILE PATH, so `data` must name a file (README.md:65).
+        (No `validate` parameter: the reference's signature has none and always validates.)"""
+        native.write_factors_binary_file(validate_input(data), _writable(output_filepath))
+
+    def as_ascii_str(seq: Text) -> str:
+        # the reference hands the two sequences to its binding as str: bytes are decoded as ASCII first, and bytes
+        # above 0x7f raise UnicodeDecodeError there (core.py:201-205, 247-251)
+        return seq.decode("ascii") if isinstance(seq, bytes) else seq
 
     def factorize_w_reference(reference_seq: Text, target_seq: Text, validate: bool = True) -> Factors:
         """the target factorized against reference + '\\x01' + target, positions absolute in that string
         (reference: core.py:164-207)"""
-        return native.factorize_w_reference(checked(reference_seq, validate), checked(target_seq, validate))
+        return native.factorize_w_reference(as_ascii_str(checked(reference_seq, validate)),
+                                            as_ascii_str(checked(target_seq, validate)))
 
     def factorize_w_reference_file(reference_seq: Text, target_seq: Text, output_path: PathLike,
                                    validate: bool = True) -> int:
         """the same into a v2 binary factor file; returns the number of factors (reference: core.py:210-257)"""
-        return native.factorize_w_reference_file(checked(reference_seq, validate), checked(target_seq, validate),
-                                                 _writable(output_path))
+        return native.factorize_w_reference_file(as_ascii_str(checked(reference_seq, validate)),
+                                                 as_ascii_str(checked(target_seq, validate)), _writable(output_path))
 
     fns = locals()
     return {name: fns[name] for name in __all__}

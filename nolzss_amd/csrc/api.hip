@@ -1886,8 +1886,17 @@ size_t merge_below() {  // records shorter than this are merged (0: never)
 
 // The shared worker of the batch entry points: factorizes m records, zs[j] factors each; fs (optional)
 // receives the arrays, every malloc'ed block behind them is appended to `blocks`.
-void factorize_many(const uint8_t *const *texts, const size_t *lens, size_t m, const int *devices, size_t n_dev,
-                    bool with_rc, size_t *zs, nolzss_factor **fs, std::vector<void *> &blocks) {
+// The static part of the batch plan: which records share a merged run (`chunks`, in the order the lanes take them from
+// one work queue) and which take a pipeline run of their own (`singles`); empty records are in neither (z = 0).
+// Every record is in exactly one place (tests/test_host_logic.py::test_batch_plan_deals_every_record_once, through
+// nolzss_debug_batch_plan).
+struct BatchPlan {
+    std::vector<std::vector<size_t>> chunks;
+    std::vector<size_t> singles;
+};
+BatchPlan plan_batch(const size_t *lens, size_t m, bool with_rc) {
+    std::vector<size_t> singles;
+    std::vector<std::vector<size_t>> chunks;
     // 1. which records are merged: short, non-empty ones, in chunks of consecutive records
     // (with_rc: each record as T s0 revcomp(T) s1, dna_w_rc_common; a run holds both strands)
     const size_t below = with_rc ? merge_below() / 2 : merge_below();
@@ -1897,8 +1906,6 @@ void factorize_many(const uint8_t *const *texts, const size_t *lens, size_t m, c
         return v > 0 ? (size_t)v : kMergeChunkBases;
     }();
     const size_t run_bases = with_rc ? chunk_bases / 2 : chunk_bases;
-    std::vector<size_t> singles;
-    std::vector<std::vector<size_t>> chunks;
     // Long records (plain mode): runs of about 2^28 bases, each record uploaded straight into the run's device
     // text; one lane uploads while the other computes.
     // (NOLZSS_BATCH_MERGE_LONG_BELOW=0: long records one pipeline run each, as before round 2; read per call)
@@ -1973,6 +1980,28 @@ void factorize_many(const uint8_t *const *texts, const size_t *lens, size_t m, c
                 ++it;
             }
     }
+    return BatchPlan{std::move(chunks), std::move(singles)};
+}
+
+// longest-processing-time-first assignment of the single records to n_dev devices (singles sorted by length first)
+std::vector<std::vector<size_t>> lpt_plan_singles(std::vector<size_t> &singles, const size_t *lens, size_t n_dev) {
+    std::stable_sort(singles.begin(), singles.end(), [&](size_t a, size_t b) { return lens[a] > lens[b]; });
+    std::vector<std::vector<size_t>> plan(n_dev);
+    std::vector<size_t> load(n_dev, 0);
+    for (size_t j : singles) {
+        const size_t d = (size_t)(std::min_element(load.begin(), load.end()) - load.begin());
+        plan[d].push_back(j);
+        load[d] += lens[j];
+    }
+    return plan;
+}
+
+void factorize_many(const uint8_t *const *texts, const size_t *lens, size_t m, const int *devices, size_t n_dev,
+                    bool with_rc, size_t *zs, nolzss_factor **fs, std::vector<void *> &blocks) {
+    // 1. which records are merged: short, non-empty ones, in chunks of consecutive records (plan_batch)
+    BatchPlan bp = plan_batch(lens, m, with_rc);
+    std::vector<std::vector<size_t>> &chunks = bp.chunks;
+    std::vector<size_t> &singles = bp.singles;
     std::mutex out_mu;
     // 2. merged chunks: kMergeLanes host threads per device, each with its own stream and arena
     if (!chunks.empty()) {
@@ -2006,14 +2035,7 @@ void factorize_many(const uint8_t *const *texts, const size_t *lens, size_t m, c
     }
     if (singles.empty()) return;
     // 3. the others one by one: longest-processing-time-first assignment of sequences to devices
-    std::stable_sort(singles.begin(), singles.end(), [&](size_t a, size_t b) { return lens[a] > lens[b]; });
-    std::vector<std::vector<size_t>> plan(n_dev);
-    std::vector<size_t> load(n_dev, 0);
-    for (size_t j : singles) {
-        const size_t d = (size_t)(std::min_element(load.begin(), load.end()) - load.begin());
-        plan[d].push_back(j);
-        load[d] += lens[j];
-    }
+    std::vector<std::vector<size_t>> plan = lpt_plan_singles(singles, lens, n_dev);
     // Several pipelines per device: a 4 Mi-base sequence neither fills the GPU for long nor
     // hides its own launch / read-back gaps, so each device runs `lanes` sequences at a time,
     // every lane with its own stream and arena, fed from the device's queue.
@@ -2210,9 +2232,16 @@ int nolzss_factorize_batch_device(const void *const *d_texts, const size_t *lens
             // (20 ms is a sixth of a run of 2^30 bases; shorter runs wait in proportion -- a flat 20 ms made the two runs of
             // 64 records x 4 Mi bases, 10 ms each, follow each other on one lane: 18.8 -> 20.4 ms)
             static const long stagger_ms = getenv("NOLZSS_DEVICE_MERGE_STAGGER_MS") ? atol(getenv("NOLZSS_DEVICE_MERGE_STAGGER_MS")) : 20;
-            size_t first_bases = 0;
+            // (only runs of SIMILAR size fall into lock-step: the wait applies when the first two runs are within a factor
+            // of two of each other, and the lanes are spread over that one interval however many there are -- it does not
+            // grow with the lane index.  include/nolzss_hip.h says that this call may sleep.)
+            size_t first_bases = 0, second_bases = 0;
             for (size_t j : chunks[0]) first_bases += lens[j];
-            const long stagger_us = (long)((double)stagger_ms * 1000.0 * std::min(1.0, (double)first_bases / (double)(size_t(1) << 30)));
+            if (chunks.size() > 1)
+                for (size_t j : chunks[1]) second_bases += lens[j];
+            const bool similar = second_bases * 2 >= first_bases && first_bases * 2 >= second_bases;
+            const long stagger_us = !similar ? 0 : (long)((double)stagger_ms * 1000.0 * std::min(1.0, (double)first_bases / (double)(size_t(1) << 30)) /
+                                                          (double)std::max<size_t>(1, workers - 1));
             auto worker = [&](size_t w) {
                 status[w] = guarded([&] {
                     Session ses(device, nullptr, (int)w);
@@ -2721,6 +2750,27 @@ int nolzss_debug_lpt_plan(const size_t *lens, size_t m, size_t bins, size_t *own
         if ((m && (!lens || !owners)) || bins == 0) throw std::invalid_argument("bad plan arguments");
         const std::vector<size_t> o = lpt_owner(std::vector<size_t>(lens, lens + m), bins);
         for (size_t j = 0; j < m; ++j) owners[j] = o[j];
+    });
+}
+
+int nolzss_debug_batch_plan(const size_t *lens, size_t m, size_t n_dev, int with_rc, int32_t *chunk_of, int32_t *device_of,
+                            size_t *n_chunks) {
+    return guarded([&] {
+        if (!lens || !chunk_of || !device_of || n_dev == 0) throw std::invalid_argument("null argument");
+        BatchPlan bp = plan_batch(lens, m, with_rc != 0);
+        for (size_t j = 0; j < m; ++j) chunk_of[j] = device_of[j] = -1;
+        for (size_t k = 0; k < bp.chunks.size(); ++k)
+            for (size_t j : bp.chunks[k]) {
+                if (chunk_of[j] != -1) throw std::logic_error("batch plan: a record sits in two runs");
+                chunk_of[j] = (int32_t)k;
+            }
+        const std::vector<std::vector<size_t>> plan = lpt_plan_singles(bp.singles, lens, n_dev);
+        for (size_t d = 0; d < n_dev; ++d)
+            for (size_t j : plan[d]) {
+                if (chunk_of[j] != -1 || device_of[j] != -1) throw std::logic_error("batch plan: a record is dealt twice");
+                device_of[j] = (int32_t)d;
+            }
+        if (n_chunks) *n_chunks = bp.chunks.size();
     });
 }
 

@@ -30,6 +30,23 @@ constexpr uint32_t kGroupSortMax = 1024;   // up to here: 256 threads per group;
 constexpr uint32_t kScanWords = 8;         // 64-bit words a member scans per round to find where its segment splits
 constexpr uint32_t kGroupSortRounds = 24;  // rounds before a group gives up (each: kScanWords words + one window)
 
+// PIVOT rounds (round 4; kPivot): collections of similar sequences -- dozens to hundreds of copies of a genome, a
+// fraction of a percent apart -- tie in groups as large as the collection, and somebody in such a group differs
+// every few symbols: the window rounds above advance to the NEXT difference of ANY member, a hundred rounds for a
+// thousand symbols.  A pivot round compares every member of a segment with the segment's FIRST member R only, as
+// far as they agree (up to kPivotWords words per round, kPivotBatch words per trip to the text, all loads of a
+// batch in flight): member x learns l = lcp(x, R), which of the two is smaller, and its own symbol at l.  That
+// orders the whole segment at once -- the members below R by ascending l (x differs from R where y still agrees:
+// x < y), then R and what equals it as far as was compared, then the members above R by descending l; equal l:
+// by the symbol at l (the end of a suffix in front of every symbol, ends by terminator index, text.hpp) -- and
+// neighbours of different classes have LCP = the smaller l.  Members with the same (side, l, symbol) agree on l + 1
+// symbols and go on as a smaller segment with a pivot of their own.  With k copies that mutate independently a
+// round finishes every member that differs from the consensus before the pivot does -- half of the segment --
+// so a group is done in about log2(k) rounds, and every member reads the text about as far as its own LCP.
+// Segments that agree up to depth_cap are left tied for the doubling rounds, which start there.
+constexpr uint32_t kPivotWords = 32;  // words a member compares with its pivot per round (1024 bases of DNA)
+constexpr uint32_t kPivotBatch = 8;   // ... of which this many per dependent trip to the text
+
 // one queue entry per LARGE group of the leftover list (items = first list position, items2 = members); groups
 // of up to kGroupSortSmall members are found by the tile kernel itself
 __global__ __launch_bounds__(kThreads) void group_dir_kernel(const uint32_t *__restrict__ act_slot,
@@ -116,7 +133,44 @@ __device__ __forceinline__ void group_window(const uint64_t *__restrict__ words,
 //   hundreds of thousands of groups of two to eight members, and a wavefront per group would idle on their
 //   round trips to the text.  List positions are sorted positions: a group's members hold consecutive list
 //   positions (and slots), and sorting only ever moves members inside their group.
-template <int BITS, int THREADS, int NMAX, bool kTiled>
+// pivot rounds: the sort key of a member relative to its pivot, one 64-bit word (one LDS read and one comparison per
+// step of the ranking): [side : 2 | l - D, descending above the pivot : 11 | symbol : 9] in the high half, the
+// terminator index + 1 of a suffix that ends at l in the low half (D = depth of the segment, l - D <= kPivotWords
+// words of symbols; symbol 0 = the suffix ends, else 1 + the member's symbol at l)
+static_assert(kPivotWords * 32 <= 1024, "l - D fits 11 bits");
+__device__ __forceinline__ uint64_t pivot_key(uint32_t side, uint32_t lrel, uint32_t sym, uint32_t tword) {
+    const uint32_t k = (side << 30) | ((side == 2 ? 2047u - lrel : (side == 0 ? lrel : 0u)) << 9) | sym;
+    return ((uint64_t)k << 32) | tword;
+}
+// l - D of a key (0xffffffff for the pivot's own class: every other class decides an LCP with it)
+__device__ __forceinline__ uint32_t pivot_lrel_of(uint64_t key) {
+    const uint32_t k = (uint32_t)(key >> 32), side = k >> 30, v = (k >> 9) & 2047u;
+    return side == 1 ? 0xffffffffu : (side == 2 ? 2047u - v : v);
+}
+// kPivotBatch words of suffix p from symbol h on, as 2 * kPivotBatch 32-bit words in text order (the high half of
+// a 64-bit word first): kPivotBatch + 1 loads, one funnel shift per 32 bits
+template <int BITS>
+__device__ __forceinline__ void pivot_fetch(const uint64_t *__restrict__ words, uint64_t p, uint32_t h, uint32_t (&win)[2 * kPivotBatch]) {
+    const uint64_t bit = (p + h) * BITS;
+    const uint64_t *src = words + (bit >> 6);
+    uint32_t r[2 * kPivotBatch + 2];
+#pragma unroll
+    for (uint32_t k = 0; k <= kPivotBatch; ++k) {
+        const uint64_t v = src[k];
+        r[2 * k] = (uint32_t)(v >> 32);
+        r[2 * k + 1] = (uint32_t)v;
+    }
+    const uint32_t skip = (bit & 32) ? 0xffffffffu : 0u;
+    const uint32_t o = (uint32_t)bit & 31;
+    uint32_t q[2 * kPivotBatch + 1];
+#pragma unroll
+    for (uint32_t k = 0; k <= 2 * kPivotBatch; ++k) q[k] = (r[k + 1] & skip) | (r[k] & ~skip);
+#pragma unroll
+    for (uint32_t k = 0; k < 2 * kPivotBatch; ++k) win[k] = o ? __builtin_amdgcn_alignbit(q[k], q[k + 1], 32 - o) : q[k];
+}
+
+
+template <int BITS, int THREADS, int NMAX, bool kTiled, bool kPivot = false>
 __global__ __launch_bounds__(THREADS) void group_sort_kernel(ShardQueue q, const uint32_t *__restrict__ act_slot,
                                                              const uint32_t *__restrict__ act_grp, uint32_t m,
                                                              uint32_t *sa, const uint64_t *__restrict__ words,
@@ -124,7 +178,8 @@ __global__ __launch_bounds__(THREADS) void group_sort_kernel(ShardQueue q, const
                                                              uint32_t *__restrict__ out_lo,
                                                              uint32_t *__restrict__ lcp_list,
                                                              uint32_t *__restrict__ min_depth,
-                                                             const uint32_t *__restrict__ lcp_mark, uint32_t max_rounds) {
+                                                             const uint32_t *__restrict__ lcp_mark, uint32_t max_rounds,
+                                                             uint32_t depth_cap = 0xffffffffu) {
     constexpr uint32_t kPer = 64 / BITS;
     constexpr int kWavesB = THREADS / 64;
     constexpr uint32_t kTile = NMAX / 2;  // (tiled) list positions whose groups this workgroup takes
@@ -213,6 +268,79 @@ __global__ __launch_bounds__(THREADS) void group_sort_kernel(ShardQueue q, const
         __syncthreads();
         bool tied = true;
         for (uint32_t round = 0; tied && round < max_rounds; ++round) {
+            constexpr int kE = NMAX / THREADS;  // positions per thread: e = t + k * THREADS
+            uint64_t rk0[kE], rk1[kE];
+            uint32_t rtt[kE], rmem[kE], rhs[kE];
+            bool ract[kE];
+            if constexpr (kPivot) {
+                // ---- 1p. every member against the first member of its segment
+#pragma unroll
+                for (int k = 0; k < kE; ++k) {
+                    const uint32_t e = t + (uint32_t)k * THREADS;
+                    ract[k] = false;
+                    rk0[k] = rk1[k] = 0;
+                    rtt[k] = rmem[k] = rhs[k] = 0;
+                    if (e >= span) continue;
+                    const uint32_t mem = s_ord[e];
+                    if (!s_act[mem]) continue;
+                    ract[k] = true;
+                    rmem[k] = mem;
+                    const uint32_t hs = s_seg[mem];
+                    rhs[k] = hs;
+                    s_split[e] = 0;
+                    uint64_t key = pivot_key(1u, 0u, 0u, 0u);  // the pivot itself, and what equals it as far as compared
+                    if (e != hs) {
+                        const uint32_t D = s_depth[hs];
+                        const uint32_t lead = s_ord[hs];
+                        const uint32_t la = s_lim[mem], lb = s_lim[lead];
+                        const uint32_t limit = la < lb ? la : lb;  // symbols before the nearer terminator
+                        uint32_t stop = D + kPivotWords * kPer;
+                        stop = stop < depth_cap ? stop : depth_cap;
+                        const uint32_t stop2 = limit < stop ? limit : stop;
+                        const uint64_t pa = s_pos[mem], pb = s_pos[lead];
+                        constexpr uint32_t kPer32 = 32 / BITS;
+                        uint32_t h = D, xw = 0, yw = 0;
+                        bool found = false;
+                        while (h < stop2) {
+                            uint32_t x[2 * kPivotBatch], y[2 * kPivotBatch];
+                            pivot_fetch<BITS>(words, pa, h, x);
+                            pivot_fetch<BITS>(words, pb, h, y);
+                            uint32_t fb = 2 * kPivotBatch;
+#pragma unroll
+                            for (int b = 2 * (int)kPivotBatch - 1; b >= 0; --b) {
+                                const bool diff = x[b] != y[b];
+                                fb = diff ? (uint32_t)b : fb;
+                                xw = diff ? x[b] : xw;
+                                yw = diff ? y[b] : yw;
+                            }
+                            if (fb < 2 * kPivotBatch) {
+                                h += fb * kPer32 + (uint32_t)__clz((int)(xw ^ yw)) / BITS;
+                                found = true;
+                                break;
+                            }
+                            h += kPivotBatch * kPer;
+                        }
+                        if (found && h < stop2) {  // a difference in front of both terminators and of the round's reach
+                            const uint32_t in_word = (uint32_t)__clz((int)(xw ^ yw)) / BITS;
+                            const uint32_t sym = (xw >> (32 - BITS * (in_word + 1))) & ((1u << BITS) - 1u);
+                            key = pivot_key(xw < yw ? 0u : 2u, h - D, sym + 1u, 0u);
+                        } else if (limit <= stop) {  // a terminator is reached first
+                            if (la < lb) {  // mine: the suffix that ends is the smaller one
+                                key = pivot_key(0u, limit - D, 0u, (uint32_t)s_term[mem] + 1u);
+                            } else if (la > lb) {  // the pivot's: I go on with a symbol of my own
+                                const uint32_t sym = (uint32_t)(sym_word<BITS>(words, pa + limit) >> (64 - BITS));
+                                key = pivot_key(2u, limit - D, sym + 1u, 0u);
+                            } else {  // both end here: the lower terminator index first
+                                key = pivot_key(s_term[mem] < s_term[lead] ? 0u : 2u, limit - D, 0u, (uint32_t)s_term[mem] + 1u);
+                            }
+                        }
+                        // (else: equal as far as this round looks: the pivot's class)
+                    }
+                    rk0[k] = key;
+                    s_key[e] = key;
+                }
+                __syncthreads();
+            } else {
             // ---- 1. a segment that the last round did not split: how far does every member agree with its first
             // member?  (a scan of up to kScanWords words; the others take their window where they stand)
             for (uint32_t e = t; e < span; e += THREADS) {
@@ -248,10 +376,6 @@ __global__ __launch_bounds__(THREADS) void group_sort_kernel(ShardQueue q, const
             }
             __syncthreads();
             // ---- 2. the window at the segment's new depth: kept in registers and parked BY POSITION for the ranking
-            constexpr int kE = NMAX / THREADS;  // positions per thread: e = t + k * THREADS
-            uint64_t rk0[kE], rk1[kE];
-            uint32_t rtt[kE], rmem[kE], rhs[kE];
-            bool ract[kE];
 #pragma unroll
             for (int k = 0; k < kE; ++k) {
                 const uint32_t e = t + (uint32_t)k * THREADS;
@@ -276,6 +400,7 @@ __global__ __launch_bounds__(THREADS) void group_sort_kernel(ShardQueue q, const
                 const uint32_t e = t + (uint32_t)k * THREADS;
                 if (ract[k] && rhs[k] == e) s_depth[e] = s_tmp[e];
             }
+            }  // (!kPivot)
             // ---- 3. my place inside my segment: members with a smaller (window, terminator), plus the equal ones in
             // front of me.  Every lane walks its own segment (the members of a segment read the same entries: LDS
             // broadcasts); segments shrink round by round, so the walks get short quickly -- a sorting network over
@@ -287,6 +412,16 @@ __global__ __launch_bounds__(THREADS) void group_sort_kernel(ShardQueue q, const
                 npos[k] = e;
                 if (!ract[k]) continue;
                 uint32_t less = 0, eqb = 0;
+                if constexpr (kPivot) {  // one key word per member
+                    for (uint32_t x = rhs[k];; ++x) {
+                        if (x > rhs[k] && s_head[x]) break;
+                        const uint64_t xk = s_key[x];
+                        less += xk < rk0[k] ? 1u : 0u;
+                        eqb += (xk == rk0[k] && x < e) ? 1u : 0u;
+                    }
+                    npos[k] = rhs[k] + less + eqb;
+                    continue;
+                }
                 for (uint32_t x = rhs[k];; ++x) {
                     if (x > rhs[k] && s_head[x]) break;  // (s_head[N] = 1 ends the last segment)
                     const uint64_t xk0 = s_key[x], xk1 = s_key2[x];
@@ -314,6 +449,24 @@ __global__ __launch_bounds__(THREADS) void group_sort_kernel(ShardQueue q, const
                 if (!s_act[mem]) continue;
                 const uint32_t hs = s_seg[mem];
                 const uint32_t D = s_depth[hs];
+                if constexpr (kPivot) {
+                    // members that stay together: the pivot's class agrees as far as the round looked, the others
+                    // on their common l and the symbol behind it
+                    const uint64_t ka = s_key[e];
+                    const uint32_t la = pivot_lrel_of(ka);
+                    uint32_t stop = D + kPivotWords * kPer;
+                    stop = stop < depth_cap ? stop : depth_cap;
+                    s_tmp[e] = la == 0xffffffffu ? stop : D + la + 1u;
+                    if (e == hs) continue;
+                    const uint64_t kb = s_key[e - 1];
+                    if (ka != kb) {
+                        const uint32_t lb = pivot_lrel_of(kb);
+                        s_head[e] = 1;
+                        s_split[hs] = 1;
+                        s_blcp[e] = D + (la < lb ? la : lb);
+                    }
+                    continue;
+                }
                 s_tmp[e] = D + 2 * kPer;  // members that stay together agree on the whole window
                 if (e == hs) continue;
                 const uint64_t ka = s_key[e], kb = s_key[e - 1], ka2 = s_key2[e], kb2 = s_key2[e - 1];
@@ -356,12 +509,20 @@ __global__ __launch_bounds__(THREADS) void group_sort_kernel(ShardQueue q, const
                         const uint32_t hs = run - 1;
                         const uint32_t old_hs = s_seg[mem];
                         s_seg[mem] = (uint16_t)hs;
-                        const bool act = !(s_head[e] && s_head[e + 1]);
+                        bool act = !(s_head[e] && s_head[e + 1]);
+                        if constexpr (kPivot) {
+                            // a segment that agrees up to the cap stays tied: the doubling rounds start at its depth
+                            // (s_tmp of a position: the depth of the class it sits in, equal for the whole new segment)
+                            if (act && s_tmp[hs] >= depth_cap) {
+                                act = false;
+                                if (hs == e) lower_min(min_depth, s_tmp[e]);
+                            }
+                        }
                         s_act[mem] = act ? 1 : 0;
                         any |= act;
                         if (hs == e) {  // a segment start (old or new) of a segment that was tied
                             s_depth[e] = s_tmp[e];
-                            s_scanit[e] = s_split[old_hs] ? 0 : 1;
+                            s_scanit[e] = kPivot ? 0 : (s_split[old_hs] ? 0 : 1);
                         }
                     }
                 if (any) s_any = 1;

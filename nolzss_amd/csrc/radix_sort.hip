@@ -143,6 +143,43 @@ template <int BITS> struct TextSrc {
         return BITS == 2 && !segmented && digit_from_text && shift == kKeyBits - kRadixBits;
     }
     __device__ __forceinline__ uint64_t window(size_t idx) const { return sym_word<BITS>(words, idx); }
+    // digit of the j-th of the 16 suffixes that start in the window fetched for element idx0
+    __device__ __forceinline__ uint32_t window_digit(uint64_t w, int j, size_t) const {
+        return (uint32_t)((w >> (64 - kRadixBits - 2 * j)) & (uint64_t)(kBins - 1));
+    }
+};
+// Plain one-segment 2-bit DNA with the 16-base key of text.hpp (kP16Syms): the most-significant-digit pass.  The
+// 40-bit value it hands to the kernels is [32 key bits][8-bit tag]: the digit of this pass (shift 32) is the first
+// four bases, and the low 32 bits -- what the pass stores -- are [24 key bits][tag].  Element e of the pass is
+// suffix n - 1 - e for e < 16 and suffix e - 16 behind them: the suffixes that end inside the key window come
+// first, shortest first, and the stable passes leave them in front of the longer suffixes that tie with their
+// zero-padded keys (the packed text is zero behind its end: no masking).
+struct Text16Src {
+    using Raw = SymWords;
+    const uint64_t *__restrict__ words;
+    uint32_t n;  // >= 32
+    __device__ __forceinline__ uint32_t suffix_of(size_t idx) const {
+        return idx < 16 ? n - 1u - (uint32_t)idx : (uint32_t)idx - 16u;
+    }
+    __device__ __forceinline__ Raw load(size_t idx, const TileExtent &) const { return sym_words<2>(words, suffix_of(idx)); }
+    __device__ __forceinline__ uint64_t key_of(const Raw &raw, size_t idx, const TileExtent &) const {
+        const uint32_t s = suffix_of(idx);
+        const uint32_t lim = n - s;
+        const uint32_t tag = lim < (uint32_t)kP16Syms ? lim : (uint32_t)kP16Syms;
+        return ((sym_word_of<2>(raw, s) >> 32) << kP16TagBits) | tag;
+    }
+    __device__ __forceinline__ uint32_t val(size_t idx) const { return suffix_of(idx); }
+    __device__ __forceinline__ uint32_t hist_digit_of(const Raw &raw, size_t idx, int, const TileExtent &) const {
+        return (uint32_t)(sym_word_of<2>(raw, suffix_of(idx)) >> (64 - kRadixBits));
+    }
+    // (tiles start at multiples of 16 elements: only the very first window of the list holds the rotated suffixes;
+    // it is the window of suffix n - 16, read backwards)
+    __device__ __forceinline__ bool digits_from_window(int) const { return true; }
+    __device__ __forceinline__ uint64_t window(size_t idx0) const { return sym_word<2>(words, idx0 == 0 ? (uint64_t)n - 16u : idx0 - 16u); }
+    __device__ __forceinline__ uint32_t window_digit(uint64_t w, int j, size_t idx0) const {
+        const int jj = idx0 == 0 ? 15 - j : j;
+        return (uint32_t)((w >> (64 - kRadixBits - 2 * jj)) & (uint64_t)(kBins - 1));
+    }
 };
 // Independent records, one BUCKET per record (radix_sort_record_keys): the pairs of a tile are the suffixes at
 // the tile's own text positions, the key [kRecSyms bases][4-bit length tag] of a suffix needs the end of its
@@ -195,6 +232,9 @@ struct LocalRankSrc {
     __device__ __forceinline__ uint64_t window(size_t) const { return 0; }
 };
 
+template <typename S, typename = void> struct HasWindowDigits : std::false_type {};
+template <typename S> struct HasWindowDigits<S, std::void_t<decltype(&S::window_digit)>> : std::true_type {};
+
 template <typename KeyT, typename Src>
 __global__ __launch_bounds__(kThreads) void rs_hist_kernel(Src src, size_t n, int shift,
                                                            uint32_t *__restrict__ tile_hist,
@@ -214,15 +254,20 @@ __global__ __launch_bounds__(kThreads) void rs_hist_kernel(Src src, size_t n, in
     __syncthreads();
     const TileExtent ext = tile_extent(tile, n, num_tiles, seg);
     const uint32_t copy = threadIdx.x & (kCopies - 1);
-    if (src.digits_from_window(shift)) {
-        static_assert(kKeysPerThread == 16, "16 two-bit symbols and an 8-bit digit fit one 64-bit window");
-        const uint32_t local0 = threadIdx.x * (uint32_t)kKeysPerThread;
-        const uint64_t w = local0 < ext.count ? src.window(ext.first + local0) : 0ull;
+    bool windowed = false;
+    if constexpr (HasWindowDigits<Src>::value) {
+        if (src.digits_from_window(shift)) {
+            static_assert(kKeysPerThread == 16, "16 two-bit symbols and an 8-bit digit fit one 64-bit window");
+            windowed = true;
+            const uint32_t local0 = threadIdx.x * (uint32_t)kKeysPerThread;
+            const uint64_t w = local0 < ext.count ? src.window(ext.first + local0) : 0ull;
 #pragma unroll
-        for (int j = 0; j < kKeysPerThread; ++j)
-            if (local0 + (uint32_t)j < ext.count)
-                atomicAdd(&hist[(uint32_t)((w >> (64 - kRadixBits - 2 * j)) & (uint64_t)(kBins - 1)) * kCopies + copy], 1u);
-    } else {
+            for (int j = 0; j < kKeysPerThread; ++j)
+                if (local0 + (uint32_t)j < ext.count)
+                    atomicAdd(&hist[src.window_digit(w, j, ext.first + local0) * kCopies + copy], 1u);
+        }
+    }
+    if (!windowed) {
         // all loads first: the compiler does not move loads across the LDS atomics (elements past the end of
         // the tile load its first element again: no branch around a load, nothing waits in between)
         typename Src::Raw k[kKeysPerThread];
@@ -393,6 +438,188 @@ __global__ __launch_bounds__(kThreads, kScatterWavesPerSimd) void rs_scatter_ker
     for (int j = 0; j < kKeysPerThread; ++j) {
         const uint32_t p = (uint32_t)j * kThreads + tid;
         if (p < count) vals_out[gpos[j]] = s_vals[p];
+    }
+}
+
+// ---- fused records (round 4, A/B) ------------------------------------------------------------------------
+// The same pass on pairs that travel as ONE 64-bit word [key : 32 | value : 32]: one staging buffer of 8-byte
+// records, one store loop, bin runs of 16 x 8 = 128 bytes on average where the split form writes two streams of
+// 64-byte runs.  The price is paid by the histogram kernel of the pass, which reads the records (8 B per pair)
+// where the split form reads the keys alone (4 B).  kSplitOut: the last pass of a sort hands the halves to
+// separate arrays (the suffix array and the key words the regroup kernel reads).
+struct RecArraySrc {
+    using Raw = uint64_t;
+    static constexpr bool kDigitInRecord = true;
+    const uint64_t *__restrict__ recs;
+    __device__ __forceinline__ Raw load(size_t idx, const TileExtent &) const { return recs[idx]; }
+    __device__ __forceinline__ uint64_t rec_of(Raw raw, size_t, const TileExtent &, uint32_t &) const { return raw; }
+};
+// the most-significant-digit pass of the 16-base key sort (Text16Src), writing records: [stored key word | suffix];
+// its digit -- the first four bases -- is not part of the record
+struct TextRec16Src {
+    using Raw = SymWords;
+    static constexpr bool kDigitInRecord = false;
+    Text16Src t;
+    __device__ __forceinline__ Raw load(size_t idx, const TileExtent &ext) const { return t.load(idx, ext); }
+    __device__ __forceinline__ uint64_t rec_of(const Raw &raw, size_t idx, const TileExtent &ext, uint32_t &digit) const {
+        const uint64_t k = t.key_of(raw, idx, ext);  // [32 key bits][8-bit tag]
+        digit = (uint32_t)(k >> 32);
+        return (k << 32) | t.suffix_of(idx);
+    }
+};
+
+template <typename Src, bool kSplitOut>
+__global__ __launch_bounds__(kThreads) void rs_scatter_rec_kernel(Src src, uint64_t *__restrict__ rec_out,
+                                                                  uint32_t *__restrict__ keys_out,
+                                                                  uint32_t *__restrict__ vals_out, size_t n, int shift,
+                                                                  const uint32_t *__restrict__ tile_base,
+                                                                  uint32_t num_tiles, SegView seg) {
+    static_assert(kKeysPerThread == 16, "digits of a thread pack into four registers");
+    const uint32_t tile = xcd_tile(blockIdx.x, num_tiles);
+    if (tile == 0xffffffffu) return;
+    const TileExtent ext = tile_extent(tile, n, num_tiles, seg);
+    __shared__ __align__(16) uint64_t s_rec[kTile];
+    __shared__ uint32_t s_whist[kWaves * kBins];
+    __shared__ uint32_t s_glob[kBins];
+    __shared__ uint32_t s_scan[kWaves];
+    __shared__ uint8_t s_dig[Src::kDigitInRecord ? 4 : kTile];
+
+    const int tid = threadIdx.x;
+    const int w = tid >> 6;
+    const int lane = tid & 63;
+    for (int i = tid; i < kWaves * kBins; i += kThreads) s_whist[i] = 0;
+    __syncthreads();
+
+    const size_t base = ext.first;
+    uint64_t rec[kKeysPerThread];
+    uint32_t lrank[kKeysPerThread];
+    uint32_t dpk[kKeysPerThread / 4] = {0, 0, 0, 0};  // (digits that are not part of the record, four per register)
+    auto digit_at = [&](int row) -> uint32_t {
+        if constexpr (Src::kDigitInRecord)
+            return digit_of(rec[row], 32 + shift);
+        else
+            return (dpk[row >> 2] >> (8 * (row & 3))) & 255u;
+    };
+    constexpr int kBatch = sizeof(typename Src::Raw) > sizeof(uint64_t) ? 8 : kKeysPerThread;
+#pragma unroll
+    for (int r0 = 0; r0 < kKeysPerThread; r0 += kBatch) {
+        typename Src::Raw raw[kBatch];
+#pragma unroll
+        for (int r = 0; r < kBatch; ++r) {
+            const uint32_t local = (uint32_t)w * kWaveSpan + (uint32_t)(r0 + r) * 64 + lane;
+            raw[r] = src.load(base + (local < ext.count ? local : 0u), ext);  // (past the end: the first element again)
+        }
+#pragma unroll
+        for (int r = 0; r < kBatch; ++r) {
+            const uint32_t local = (uint32_t)w * kWaveSpan + (uint32_t)(r0 + r) * 64 + lane;
+            const bool valid = local < ext.count;
+            uint32_t d = 0;
+            const uint64_t x = src.rec_of(raw[r], base + (valid ? local : 0u), ext, d);
+            rec[r0 + r] = valid ? x : 0ull;
+            if constexpr (!Src::kDigitInRecord) dpk[(r0 + r) >> 2] |= (valid ? d : 0u) << (8 * ((r0 + r) & 3));
+        }
+    }
+    // ranking inside the wavefront, exactly as in rs_scatter_kernel
+    uint32_t *wcount = s_whist + w * kBins;
+#pragma unroll
+    for (int row = 0; row < kKeysPerThread; ++row) {
+        const bool valid = (uint32_t)w * kWaveSpan + (uint32_t)row * 64 + lane < ext.count;
+        const uint32_t d = digit_at(row);
+        uint32_t diff_lo = 0, diff_hi = 0;
+#pragma unroll
+        for (int b = 0; b < kRadixBits; ++b) {
+            const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)d, (unsigned)b, 1u);
+            const uint64_t bal = __ballot((int)m < 0);
+            diff_lo = __builtin_amdgcn_bitop3_b32(m, diff_lo, (uint32_t)bal, 0xde);
+            diff_hi = __builtin_amdgcn_bitop3_b32(m, diff_hi, (uint32_t)(bal >> 32), 0xde);
+        }
+        const uint64_t peers = ~(((uint64_t)diff_hi << 32) | diff_lo) & __ballot(valid);
+        const uint64_t below = peers & lanemask_lt();
+        uint32_t seen = 0;
+        if (valid && below == 0) seen = atomicAdd(&wcount[d], (uint32_t)__popcll(peers));
+        lrank[row] = seen | ((uint32_t)__popcll(below) << 11) | ((uint32_t)(peers ? __builtin_ctzll(peers) : 0) << 17);
+    }
+#pragma unroll
+    for (int row = 0; row < kKeysPerThread; ++row) {
+        const uint32_t packed = lrank[row];
+        lrank[row] = ((uint32_t)__shfl((int)packed, (int)(packed >> 17), 64) & 0x7ffu) + ((packed >> 11) & 63u);
+    }
+    __syncthreads();
+    {
+        const int d = tid;
+        const bool owner = tid < kBins;
+        uint32_t c[kWaves], total = 0;
+#pragma unroll
+        for (int k = 0; k < kWaves; ++k) {
+            c[k] = owner ? s_whist[k * kBins + d] : 0u;
+            total += c[k];
+        }
+        uint32_t tile_total;
+        const uint32_t bin_start = block_scan_exclusive<kWaves>(total, OpAdd<uint32_t>(), s_scan, tile_total);
+        if (owner) {
+            uint32_t run = bin_start;
+#pragma unroll
+            for (int k = 0; k < kWaves; ++k) {
+                s_whist[k * kBins + d] = run;
+                run += c[k];
+            }
+            s_glob[d] = tile_base[ext.hist0 + (size_t)d * ext.hstride] - bin_start;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int row = 0; row < kKeysPerThread; ++row) {
+        const uint32_t d = digit_at(row);
+        lrank[row] += s_whist[w * kBins + d];
+    }
+#pragma unroll
+    for (int row = 0; row < kKeysPerThread; ++row) {
+        if ((uint32_t)w * kWaveSpan + (uint32_t)row * 64 + lane < ext.count) {
+            s_rec[lrank[row]] = rec[row];
+            if constexpr (!Src::kDigitInRecord) s_dig[lrank[row]] = (uint8_t)digit_at(row);
+        }
+    }
+    __syncthreads();
+    const uint32_t count = ext.count;
+#pragma unroll
+    for (int j = 0; j < kKeysPerThread; ++j) {
+        const uint32_t p = (uint32_t)j * kThreads + tid;
+        if (p < count) {
+            const uint64_t x = s_rec[p];
+            uint32_t d;
+            if constexpr (Src::kDigitInRecord)
+                d = digit_of(x, 32 + shift);
+            else
+                d = s_dig[p];
+            const uint32_t g = s_glob[d] + p;
+            if constexpr (kSplitOut) {
+                keys_out[g] = (uint32_t)(x >> 32);
+                vals_out[g] = (uint32_t)x;
+            } else {
+                rec_out[g] = x;
+            }
+        }
+    }
+}
+
+template <typename Src, bool kSplitOut, typename HistSrc>
+void radix_pass_rec(Src src, HistSrc hsrc, int hist_shift, uint64_t *rec_out, uint32_t *keys_out, uint32_t *vals_out,
+                    size_t n, int shift, uint32_t *hist, uint32_t num_tiles, double hist_bytes, double scatter_bytes,
+                    Arena &arena, hipStream_t stream, Profiler *prof, const SegView &seg = SegView{}) {
+    {
+        ProfScope ps(prof, "rs_hist", stream, hist_bytes);
+        rs_hist_kernel<uint64_t, HistSrc><<<xcd_grid(num_tiles), kThreads, 0, stream>>>(hsrc, n, hist_shift, hist, num_tiles, seg);
+        KERNEL_CHECK();
+    }
+    {
+        ProfScope ps(prof, "rs_scan", stream, 8.0 * (double)kBins * num_tiles);
+        scan_exclusive_add_u32(hist, hist, (size_t)kBins * num_tiles, nullptr, arena, stream);
+    }
+    {
+        ProfScope ps(prof, Src::kDigitInRecord ? "rs_scatter.rec" : "rs_scatter.text", stream, scatter_bytes);
+        rs_scatter_rec_kernel<Src, kSplitOut><<<xcd_grid(num_tiles), kThreads, 0, stream>>>(src, rec_out, keys_out, vals_out, n,
+                                                                                     shift, hist, num_tiles, seg);
+        KERNEL_CHECK();
     }
 }
 
@@ -1046,6 +1273,113 @@ void radix_sort_dna_keys(const PackedText &text, uint32_t *keys32[2], uint32_t *
         cur ^= 1;
     }
     arena.rewind(m);  // (cur == 1 again)
+}
+
+void radix_sort_dna_keys16(const PackedText &text, uint32_t *keys32[2], uint32_t *vals[2], uint32_t *seg_mem,
+                           SegView &seg_out, Arena &arena, hipStream_t stream, Profiler *prof) {
+    const size_t n = text.n;
+    if (text.bits != 2 || text.segmented || text.terms.count != 1 || n < 32) throw HipError("radix_sort_dna_keys16: plain 2-bit texts only");
+    const size_t m = arena.mark();
+    const uint32_t tiles0 = (uint32_t)div_up(n, kTile);
+    uint32_t *hist = arena.alloc<uint32_t>((size_t)kBins * ((size_t)tiles0 + kBins));
+    uint32_t *tabs = arena.alloc<uint32_t>(4 * 257);
+    uint32_t *bstart = tabs, *tile0 = tabs + 257, *prev_ne = tabs + 2 * 257, *next_ne = tabs + 3 * 257;
+    const double text_bytes = (double)n * 2 / 8.0;
+    // most significant digit first: the first four bases (bits 32..39 of [32 key bits][8-bit tag])
+    radix_pass<uint64_t, uint32_t>(Text16Src{text.words, (uint32_t)n}, keys32[1], vals[1], n, 32, hist, tiles0, text_bytes,
+                                   text_bytes + 8.0 * (double)n, arena, stream, prof);
+    bucket_starts_kernel<<<1, kBins, 0, stream>>>(hist, tiles0, (uint32_t)n, bstart);
+    KERNEL_CHECK();
+    uint32_t h_start[kBins + 1], h_tab[3 * 257];
+    HIP_CHECK(hipMemcpyAsync(h_start, bstart, sizeof(h_start), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    uint32_t *h_tile0 = h_tab, *h_prev = h_tab + 257, *h_next = h_tab + 2 * 257;
+    h_tile0[0] = 0;
+    for (int b = 0; b < kBins; ++b) h_tile0[b + 1] = h_tile0[b] + (uint32_t)div_up((size_t)(h_start[b + 1] - h_start[b]), kTile);
+    uint32_t last = 0xffffffffu;
+    for (int b = 0; b < kBins; ++b) {
+        h_prev[b] = last;
+        if (h_start[b + 1] > h_start[b]) last = (uint32_t)b;
+    }
+    last = 0xffffffffu;
+    for (int b = kBins - 1; b >= 0; --b) {
+        h_next[b] = last;
+        if (h_start[b + 1] > h_start[b]) last = (uint32_t)b;
+    }
+    h_prev[256] = h_next[256] = 0;
+    HIP_CHECK(hipMemcpyAsync(tile0, h_tab, sizeof(h_tab), hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));  // h_tab is a local array
+    seg_out.num_tiles = h_tile0[kBins];
+    seg_desc_kernel<<<(unsigned)div_up(seg_out.num_tiles, kThreads), kThreads, 0, stream>>>(bstart, tile0, prev_ne, next_ne,
+                                                                                       seg_out.num_tiles, seg_mem, (uint32_t)kBins);
+    KERNEL_CHECK();
+    seg_out.desc = seg_mem;
+    // every bucket by the 24 key bits above the tag byte, least significant digit first: THREE passes
+    int cur = 1;
+    for (int p = 0; p < 3; ++p) {
+        radix_pass<uint32_t, uint32_t>(ArraySrc<uint32_t>{keys32[cur], vals[cur]}, keys32[cur ^ 1], vals[cur ^ 1], n,
+                                       kP16TagBits + 8 * p, hist, seg_out.num_tiles, 4.0 * (double)n, 16.0 * (double)n, arena,
+                                       stream, prof, seg_out);
+        cur ^= 1;
+    }
+    arena.rewind(m);  // (cur == 0: the sorted pairs are in keys32[0] / vals[0])
+}
+
+void radix_sort_dna_keys16_fused(const PackedText &text, uint64_t *rec[2], uint32_t *sa_out, uint32_t *seg_mem,
+                                 SegView &seg_out, Arena &arena, hipStream_t stream, Profiler *prof) {
+    const size_t n = text.n;
+    if (text.bits != 2 || text.segmented || text.terms.count != 1 || n < 32) throw HipError("radix_sort_dna_keys16_fused: plain 2-bit texts only");
+    const size_t m = arena.mark();
+    const uint32_t tiles0 = (uint32_t)div_up(n, kTile);
+    uint32_t *hist = arena.alloc<uint32_t>((size_t)kBins * ((size_t)tiles0 + kBins));
+    uint32_t *tabs = arena.alloc<uint32_t>(4 * 257);
+    uint32_t *bstart = tabs, *tile0 = tabs + 257, *prev_ne = tabs + 2 * 257, *next_ne = tabs + 3 * 257;
+    const double text_bytes = (double)n * 2 / 8.0;
+    const Text16Src tsrc{text.words, (uint32_t)n};
+    radix_pass_rec<TextRec16Src, false>(TextRec16Src{tsrc}, tsrc, 32, rec[1], nullptr, nullptr, n, 0, hist, tiles0, text_bytes,
+                                        text_bytes + 8.0 * (double)n, arena, stream, prof);
+    bucket_starts_kernel<<<1, kBins, 0, stream>>>(hist, tiles0, (uint32_t)n, bstart);
+    KERNEL_CHECK();
+    uint32_t h_start[kBins + 1], h_tab[3 * 257];
+    HIP_CHECK(hipMemcpyAsync(h_start, bstart, sizeof(h_start), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    uint32_t *h_tile0 = h_tab, *h_prev = h_tab + 257, *h_next = h_tab + 2 * 257;
+    h_tile0[0] = 0;
+    for (int b = 0; b < kBins; ++b) h_tile0[b + 1] = h_tile0[b] + (uint32_t)div_up((size_t)(h_start[b + 1] - h_start[b]), kTile);
+    uint32_t last = 0xffffffffu;
+    for (int b = 0; b < kBins; ++b) {
+        h_prev[b] = last;
+        if (h_start[b + 1] > h_start[b]) last = (uint32_t)b;
+    }
+    last = 0xffffffffu;
+    for (int b = kBins - 1; b >= 0; --b) {
+        h_next[b] = last;
+        if (h_start[b + 1] > h_start[b]) last = (uint32_t)b;
+    }
+    h_prev[256] = h_next[256] = 0;
+    HIP_CHECK(hipMemcpyAsync(tile0, h_tab, sizeof(h_tab), hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));  // h_tab is a local array
+    seg_out.num_tiles = h_tile0[kBins];
+    seg_desc_kernel<<<(unsigned)div_up(seg_out.num_tiles, kThreads), kThreads, 0, stream>>>(bstart, tile0, prev_ne, next_ne,
+                                                                                       seg_out.num_tiles, seg_mem, (uint32_t)kBins);
+    KERNEL_CHECK();
+    seg_out.desc = seg_mem;
+    // three segmented passes over the 24 key bits above the tag byte; the last one splits the records into the key
+    // words (left in the buffer the pass does not read: rec[1], as 32-bit words) and the suffix array
+    int cur = 1;
+    for (int p = 0; p < 3; ++p) {
+        const ArraySrc<uint64_t> hsrc{rec[cur], nullptr};
+        const int shift = kP16TagBits + 8 * p;
+        if (p < 2)
+            radix_pass_rec<RecArraySrc, false>(RecArraySrc{rec[cur]}, hsrc, 32 + shift, rec[cur ^ 1], nullptr, nullptr, n, shift,
+                                               hist, seg_out.num_tiles, 8.0 * (double)n, 16.0 * (double)n, arena, stream, prof, seg_out);
+        else
+            radix_pass_rec<RecArraySrc, true>(RecArraySrc{rec[cur]}, hsrc, 32 + shift, nullptr, reinterpret_cast<uint32_t *>(rec[cur ^ 1]),
+                                              sa_out, n, shift, hist, seg_out.num_tiles, 8.0 * (double)n, 16.0 * (double)n, arena,
+                                              stream, prof, seg_out);
+        cur ^= 1;
+    }
+    arena.rewind(m);  // (the key words are in rec[0], as 32-bit words; the suffixes in sa_out)
 }
 
 void radix_sort_record_keys(const PackedText &text, const std::vector<uint32_t> &h_terms, uint32_t *keys32[2],

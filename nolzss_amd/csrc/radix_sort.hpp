@@ -94,6 +94,17 @@ int radix_sort_initial_keys(const PackedText &text, uint64_t *keys[2], uint32_t 
 void radix_sort_dna_keys(const PackedText &text, uint32_t *keys32[2], uint32_t *vals[2], uint32_t *seg_mem,
                          SegView &seg_out, Arena &arena, hipStream_t stream, Profiler *prof = nullptr);
 
+// Plain one-segment 2-bit DNA, 16-base key (text.hpp, kP16Syms): the most-significant-digit pass from the text
+// and THREE segmented passes over the 24 key bits above the tag byte of the stored word [24 key bits][8-bit tag].
+// The sorted words end in keys32[0], the suffixes in vals[0].  8 + 3 * 16 bytes of scatter traffic per suffix.
+void radix_sort_dna_keys16(const PackedText &text, uint32_t *keys32[2], uint32_t *vals[2], uint32_t *seg_mem,
+                           SegView &seg_out, Arena &arena, hipStream_t stream, Profiler *prof = nullptr);
+
+// The same sort on FUSED records [stored key word : 32 | suffix : 32] (round 4, A/B: NOLZSS_FUSED_SORT): rec[0] and rec[1]
+// hold n 64-bit words each; the last pass writes the suffixes to sa_out and the key words to rec[0] (as 32-bit words).
+void radix_sort_dna_keys16_fused(const PackedText &text, uint64_t *rec[2], uint32_t *sa_out, uint32_t *seg_mem,
+                                 SegView &seg_out, Arena &arena, hipStream_t stream, Profiler *prof = nullptr);
+
 // Independent records of 2-bit DNA (text.terms.seq_shift != 0), at most n / 2^16 of them: the records are
 // the buckets -- the text is "partitioned" as it lies -- and every bucket is sorted on 8-byte records by the
 // 32-bit key [kRecSyms bases][4-bit length tag], least significant digit first, the first pass making its

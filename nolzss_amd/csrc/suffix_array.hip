@@ -402,16 +402,17 @@ __device__ __forceinline__ uint32_t lane_next(uint32_t v, uint32_t edge) {
 // kLayout (round 0 of the bucketed 2-bit key sorts): the key layout is known at compile time, which folds the
 // shifts and masks of every item (the kernel is bound by VALU issue: ~1300 instructions per wavefront and 512
 // suffixes).  1 = plain DNA: 34 symbol bits, 6-bit tag, no low bits, no sequence numbers, short suffixes flagged;
-// 2 = long independent records, bucket = record: 28 symbol bits, 4-bit tag, the record number above bit 32.
+// 2 = long independent records, bucket = record: 28 symbol bits, 4-bit tag, the record number above bit 32;
+// 3 = plain DNA with the 16-base key: 32 symbol bits (bucket + 24 stored bits), the tag in the low byte of the stored word.
 template <bool kRound0, int kLayout>
 __global__ __launch_bounds__(kFuseThreads) void regroup_kernel(RegroupArgs A) {
     constexpr bool kDnaFast = kLayout != 0;  // (bucketed, compile-time layout)
     const int low_bits = kDnaFast ? 0 : A.low_bits;
-    const int tag_bits = kLayout == 1 ? KeyLayout<2>::kTagBits : (kLayout == 2 ? kRecTagBits : A.tag_bits);
-    const int sym_bits = kLayout == 1 ? 2 * KeyLayout<2>::kSyms : (kLayout == 2 ? 2 * kRecSyms : A.sym_bits);
+    const int tag_bits = kLayout == 1 ? KeyLayout<2>::kTagBits : (kLayout == 2 ? kRecTagBits : (kLayout == 3 ? kP16TagBits : A.tag_bits));
+    const int sym_bits = kLayout == 1 ? 2 * KeyLayout<2>::kSyms : (kLayout == 2 ? 2 * kRecSyms : (kLayout == 3 ? 2 * kP16Syms : A.sym_bits));
     const int bits_shift = kDnaFast ? 1 : A.bits_shift;
-    const uint32_t short_tag = kLayout == 1 ? (uint32_t)KeyLayout<2>::kSyms : (kLayout == 2 ? 0u : A.short_tag);
-    const uint32_t seq_shift = kLayout == 1 ? 0u : (kLayout == 2 ? 32u : A.seq_shift);
+    const uint32_t short_tag = kLayout == 1 ? (uint32_t)KeyLayout<2>::kSyms : (kLayout == 2 ? 0u : (kLayout == 3 ? (uint32_t)kP16Syms : A.short_tag));
+    const uint32_t seq_shift = (kLayout == 1 || kLayout == 3) ? 0u : (kLayout == 2 ? 32u : A.seq_shift);
     constexpr int kWaves = kFuseThreads / 64;
     constexpr int kSegs = kFuseItems * kWaves;  // 64-element segments of the tile, in element order
     __shared__ uint32_t s_tile;
@@ -1843,8 +1844,12 @@ uint32_t regroup(Context &ctx, const uint64_t *keys, const uint32_t *grp, const 
                                  short_tag == (uint32_t)KeyLayout<2>::kSyms;
         const bool rec_layout = kRound0 && keys32 && seg && low_bits == 0 && tag_bits == kRecTagBits &&
                                 sym_bits == 2 * kRecSyms && bits == 2 && seq_shift == 32 && short_tag == 0;
+        const bool p16_layout = kRound0 && keys32 && seg && low_bits == 0 && tag_bits == kP16TagBits &&
+                                sym_bits == 2 * kP16Syms && bits == 2 && seq_shift == 0 && short_tag == (uint32_t)kP16Syms;
         if (fast_layout)
             regroup_kernel<kRound0, kRound0 ? 1 : 0><<<(unsigned)tiles, kFuseThreads, 0, s>>>(A);  // (layouts only exist for round 0)
+        else if (p16_layout)
+            regroup_kernel<kRound0, kRound0 ? 3 : 0><<<(unsigned)tiles, kFuseThreads, 0, s>>>(A);
         else if (rec_layout)
             regroup_kernel<kRound0, kRound0 ? 2 : 0><<<(unsigned)tiles, kFuseThreads, 0, s>>>(A);
         else
@@ -2078,6 +2083,10 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         if ((1u << seq_bits) < text.terms.count) throw HipError("suffix array: too many independent sequences");
     }
     const bool dna_fast = text.bits == 2 && n >= dna_fast_min && !independent;
+    // plain one-segment DNA: the 16-base key whose tag is not sorted (text.hpp, kP16Syms) -- one radix pass less
+    // (NOLZSS_NO_KEY16: A/B switch back to the 40-bit key [17 bases][6-bit tag])
+    static const bool no_key16 = getenv("NOLZSS_NO_KEY16") != nullptr;
+    const bool key16 = dna_fast && !no_key16 && !text.segmented && text.terms.count == 1 && n >= 32;
     // independent LONG records (text.hpp, kRecSyms): the records are the buckets of the segmented sort
     // (NOLZSS_REC_BUCKET_MIN: smallest average record that takes it; partial tiles cost 4096 / that)
     static const uint64_t rec_bucket_min =
@@ -2086,7 +2095,8 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
                           (uint64_t)text.terms.count * rec_bucket_min <= (uint64_t)n;
     int key_passes = 0;
     {
-        int kb = dna_fast ? KeyLayout<2>::kSyms * 2 + KeyLayout<2>::kTagBits
+        int kb = key16 ? kP16Syms * 2
+                 : dna_fast ? KeyLayout<2>::kSyms * 2 + KeyLayout<2>::kTagBits
                  : rec_fast ? kRecSyms * 2 + kRecTagBits
                  : independent ? kIndKeyBits + seq_bits
                  : text.segmented ? kSegSyms * 2 + kSegTagBits + kSegTermBits
@@ -2125,7 +2135,13 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     // the bucketed sort of plain DNA works on 8-byte (u32 key, u32 suffix) records: two 4n-byte key buffers;
     // the general sort on 12-byte records: two 8n-byte key buffers
     uint64_t *keys[2];
-    if (dna_fast || rec_fast) {
+    // (NOLZSS_FUSED_SORT: the 16-base key sort on fused 64-bit records, radix_sort.hip -- A/B switch)
+    static const bool fused_sort = getenv("NOLZSS_FUSED_SORT") != nullptr && atoi(getenv("NOLZSS_FUSED_SORT")) != 0;
+    const bool fused = key16 && fused_sort;
+    if (fused) {
+        keys[0] = arena.alloc<uint64_t>(n);
+        keys[1] = arena.alloc<uint64_t>(n);
+    } else if (dna_fast || rec_fast) {
         uint32_t *k32 = arena.alloc<uint32_t>(2 * (size_t)n + 4);
         keys[0] = reinterpret_cast<uint64_t *>(k32);
         keys[1] = reinterpret_cast<uint64_t *>(k32 + (((size_t)n + 1) & ~size_t(1)));
@@ -2134,7 +2150,7 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         keys[1] = arena.alloc<uint64_t>(n);
     }
     // The value buffers of the key sort: the one the last pass lands in IS sa (no copy afterwards).
-    uint32_t *vals_other = arena.alloc<uint32_t>(n);
+    uint32_t *vals_other = fused ? nullptr : arena.alloc<uint32_t>(n);
     uint32_t *vals[2] = {vals_other, vals_other};
     vals[key_passes & 1] = sa;
 
@@ -2162,7 +2178,15 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         int shifts0[8], np0 = 0;
         for (int b = 0; b < key_bits && np0 < 8; b += kRadixBits) shifts0[np0++] = b;
         ProfScope ps(ctx.profiler(), "sa_sort_initial", s);
-        if (dna_fast) {
+        if (fused) {
+            radix_sort_dna_keys16_fused(text, keys, sa, seg_mem, seg, arena, s, ctx.profiler());
+            cur = 0;
+        } else if (key16) {
+            uint32_t *keys32[2] = {reinterpret_cast<uint32_t *>(keys[0]), reinterpret_cast<uint32_t *>(keys[1])};
+            radix_sort_dna_keys16(text, keys32, vals, seg_mem, seg, arena, s, ctx.profiler());
+            cur = 0;
+            if (vals[cur] != sa) throw HipError("suffix array: key sort did not end in sa");
+        } else if (dna_fast) {
             // plain DNA: partition by the first four bases, then sort the buckets on 8-byte records
             uint32_t *keys32[2] = {reinterpret_cast<uint32_t *>(keys[0]), reinterpret_cast<uint32_t *>(keys[1])};
             radix_sort_dna_keys(text, keys32, vals, seg_mem, seg, arena, s, ctx.profiler());
@@ -2194,6 +2218,10 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     if (rec_fast) {  // bucket = record, [kRecSyms bases][4-bit tag]
         k_syms = kRecSyms;
         tag_bits = kRecTagBits;
+    }
+    if (key16) {  // bucket = first four bases, stored word [24 key bits][8-bit tag]
+        k_syms = kP16Syms;
+        tag_bits = kP16TagBits;
     }
     const bool bucketed = dna_fast || rec_fast;
     if (text.segmented && !dna_fast && !independent) {  // [kSegSyms symbols][5-bit tag][8-bit terminator index]
@@ -2340,16 +2368,43 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     // more members that ALL stay tied takes 170 us per group and round -- 96 genomes of 2^28 bases in all, every suffix
     // in such a group, spent 480 ms here -- and the tiles of small groups 85 ms on 48 genomes, what four doubling rounds cost.
     static const bool no_equalise = getenv("NOLZSS_NO_EQUALISE") != nullptr;  // (A/B switch)
-    const bool full_direct2 = !no_direct2 && m > 0 && h < n && !independent && direct2_div > 0 && m <= n / direct2_div + 1024u;
+    // (NOLZSS_PIVOT_MIN: the tests and the fuzzer send every text with that many tied suffixes through the pivot rounds)
+    static const long long pivot_min = getenv("NOLZSS_PIVOT_MIN") ? atoll(getenv("NOLZSS_PIVOT_MIN")) : -1;
+    const bool force_pivot = pivot_min >= 0 && (long long)m >= pivot_min;
+    const bool full_direct2 = !force_pivot && !no_direct2 && m > 0 && h < n && !independent && direct2_div > 0 && m <= n / direct2_div + 1024u;
     const bool equalise = !full_direct2 && !no_direct2 && !no_equalise && m > 0 && h < n && !independent && text.bits == 2 &&
                           depth_untouched != 0xffffffffu && depth_untouched == h &&
                           depth_compared != 0xffffffffu && depth_compared >= 2 * h && untouched_members <= m / 3;
     if (trace && m > 0 && depth_untouched != 0xffffffffu)
         fprintf(stderr, "[nolzss]   about %llu of the tied suffixes sit in groups the direct round did not compare (depth %u; compared classes: %u)\n",
                 (unsigned long long)untouched_members, depth_untouched, depth_compared);
-    if (full_direct2 || equalise) {
-        const uint32_t max_rounds = equalise ? std::min<uint32_t>(kGroupSortRounds, (depth_compared - (uint32_t)h + 63u) / 64u) : kGroupSortRounds;
-        const uint32_t *lcp_mark = equalise ? lcp : nullptr;
+    // PIVOT rounds (group_sort.hpp, kPivot): a repetitive text whose tied suffixes sit in groups of more than two or three
+    // -- a collection of similar sequences -- has every tied group of up to kGroupSortMax members sorted against pivots,
+    // kPivotDepth symbols deep: what stays tied agrees that far, and the doubling rounds start there instead of at the
+    // key depth.  Texts whose ties are pairs (two copies: the pair-run pass) or runs of a short period (groups as large as
+    // the runs: the periodic pass) are told by a count over the list and skip it.  NOLZSS_NO_PIVOT: A/B switch.
+    static const bool no_pivot = getenv("NOLZSS_NO_PIVOT") != nullptr;
+    static const uint32_t pivot_depth = getenv("NOLZSS_PIVOT_DEPTH") ? (uint32_t)atoi(getenv("NOLZSS_PIVOT_DEPTH")) : 2048u;
+    bool pivot = false;
+    if (!no_pivot && !full_direct2 && m > 0 && h < n && !independent) {
+        uint32_t *d_cnt = arena.alloc<uint32_t>(4);
+        HIP_CHECK(hipMemsetAsync(d_cnt, 0, 4 * sizeof(uint32_t), s));
+        per_count_large_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(act_slot[a_cur], act_grp[a_cur], m, sa, kGroupSortMax,
+                                                                        kPerVerifyMax, d_cnt);
+        KERNEL_CHECK();
+        uint32_t c4[4] = {0, 0, 0, 0};
+        ctx.read_back(d_cnt, c4, 4);
+        const uint64_t huge = (uint64_t)c4[0] + (uint64_t)kGroupSortMax * c4[1];  // members of groups beyond the kernels' reach
+        pivot = force_pivot || ((uint64_t)m * 4 > (uint64_t)c4[2] * 10 && huge <= m / 2 && c4[3] <= m / 2);
+        if (trace) fprintf(stderr, "[nolzss]   %u tied suffixes in %u groups, %llu in groups of more than %u, %u next to a member at most %u symbols away: %s\n",
+                           m, c4[2], (unsigned long long)huge, kGroupSortMax, c4[3], kPerVerifyMax, pivot ? "pivot rounds" : "no pivot rounds");
+    }
+    if (full_direct2 || equalise || pivot) {
+        // (group_sort.hpp carries the terminator index of a suffix that ends inside a comparison in 16 bits)
+        if (text.terms.count > 0x10000u) throw HipError("suffix array: the group-sort rounds take texts of at most 65536 segments");
+        const uint32_t max_rounds = pivot ? kGroupSortRounds : equalise ? std::min<uint32_t>(kGroupSortRounds, (depth_compared - (uint32_t)h + 63u) / 64u) : kGroupSortRounds;
+        const uint32_t *lcp_mark = (equalise && !pivot) ? lcp : nullptr;
+        const uint32_t depth_cap = (uint32_t)std::min<uint64_t>((uint64_t)h + pivot_depth, 0xfffffff0u);
         const uint32_t *slot = act_slot[a_cur], *grp = act_grp[a_cur];
         const size_t d2_mark = arena.mark();
         uint32_t *out_lo = arena.alloc<uint32_t>(m);
@@ -2391,11 +2446,33 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     group_sort_kernel<B, 256, kBigN, false><<<dim3(kQShards, yb), 256, 0, s>>>(q_big, slot, grp, m, sa, text.words,        \
                                                                                text.terms, h32, out_lo, lcp_list,          \
                                                                                d_min_depth, lcp_mark, max_rounds)
-            switch (text.bits) {
-            case 2: NOLZSS_GROUP_SORT(2); break;
-            case 4: NOLZSS_GROUP_SORT(4); break;
-            default: NOLZSS_GROUP_SORT(8); break;
+#define NOLZSS_GROUP_PIVOT(B)                                                                                               \
+    group_sort_kernel<B, 64, kSmallN, true, true><<<tiles, 64, 0, s>>>(q_mid, slot, grp, m, sa, text.words, text.terms,    \
+                                                                        h32, out_lo, lcp_list, d_min_depth, lcp_mark,       \
+                                                                        max_rounds, depth_cap);                             \
+    group_sort_kernel<B, 128, kMid0N, false, true><<<dim3(kQShards, ym), 128, 0, s>>>(                                      \
+        q_mid0, slot, grp, m, sa, text.words, text.terms, h32, out_lo, lcp_list, d_min_depth, lcp_mark, max_rounds,         \
+        depth_cap);                                                                                                         \
+    group_sort_kernel<B, 256, kMidN, false, true><<<dim3(kQShards, ym), 256, 0, s>>>(                                       \
+        q_mid, slot, grp, m, sa, text.words, text.terms, h32, out_lo, lcp_list, d_min_depth, lcp_mark, max_rounds,          \
+        depth_cap);                                                                                                         \
+    group_sort_kernel<B, 256, kBigN, false, true><<<dim3(kQShards, yb), 256, 0, s>>>(                                       \
+        q_big, slot, grp, m, sa, text.words, text.terms, h32, out_lo, lcp_list, d_min_depth, lcp_mark, max_rounds,          \
+        depth_cap)
+            if (pivot) {
+                switch (text.bits) {
+                case 2: NOLZSS_GROUP_PIVOT(2); break;
+                case 4: NOLZSS_GROUP_PIVOT(4); break;
+                default: NOLZSS_GROUP_PIVOT(8); break;
+                }
+            } else {
+                switch (text.bits) {
+                case 2: NOLZSS_GROUP_SORT(2); break;
+                case 4: NOLZSS_GROUP_SORT(4); break;
+                default: NOLZSS_GROUP_SORT(8); break;
+                }
             }
+#undef NOLZSS_GROUP_PIVOT
 #undef NOLZSS_GROUP_SORT
             KERNEL_CHECK();
         }
@@ -2409,12 +2486,12 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
             uint32_t depth = 0;
             ctx.read_back(d_min_depth, &depth, 1);
             // (equalising: the classes the first round compared were not looked at; they keep their depth)
-            if (equalise && depth_compared < depth) depth = depth_compared;
+            if (equalise && !pivot && depth_compared < depth) depth = depth_compared;
             if (depth != 0xffffffffu && depth > h) h = depth;
         }
         arena.rewind(d2_mark);
         if (trace) fprintf(stderr, "[nolzss]   %s: %u of %u finished, %u still tied, on at least %llu symbols\n",
-                           equalise ? "equalising round (untouched groups only)" : "second direct round", before - m, before, m, (unsigned long long)h);
+                           pivot ? "pivot rounds" : equalise ? "equalising round (untouched groups only)" : "second direct round", before - m, before, m, (unsigned long long)h);
     }
     // Nothing is tied any more: no round below needs rank[].  A caller that can wait gets it from the permutation
     // that brings the factor-length codes into text order (pipeline.hpp) -- one full random permutation per

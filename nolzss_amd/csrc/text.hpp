@@ -117,6 +117,17 @@ template <> struct KeyLayout<2> { static constexpr int kSyms = 17, kTagBits = 6;
 template <> struct KeyLayout<4> { static constexpr int kSyms = 15, kTagBits = 4; };
 template <> struct KeyLayout<8> { static constexpr int kSyms = 7, kTagBits = 8; };
 
+// Plain one-segment 2-bit DNA, round 4: the SORTED key is 16 bases = 32 bits and nothing else -- the
+// first four bases are the bucket of the most-significant-digit pass, the other twelve (24 bits) are
+// sorted by three segmented passes: one pass less than the 40-bit key [17 bases][6-bit tag] takes.
+// The length tag still travels, in the low byte of the stored key word [24 key bits][8-bit tag], but
+// OUTSIDE the sorted digits: it only tells the regroup kernel which suffixes end inside the key window
+// (they become groups of their own) and caps the LCPs read off the keys.  What the tag did for the
+// ORDER -- a suffix that ends inside the window sorts in front of the longer suffixes that continue its
+// zero-padded key -- comes from the stability of the sort: the first pass takes the last 16 suffixes of
+// the text first, shortest first (element e < 16 is suffix n - 1 - e, element e >= 16 is suffix e - 16).
+constexpr int kP16Syms = 16, kP16TagBits = 8;
+
 // 64 bits of text starting at symbol `pos` (zero padded past the end).
 template <int BITS>
 __device__ __forceinline__ uint64_t sym_word(const uint64_t *__restrict__ w, uint64_t pos) {

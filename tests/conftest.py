@@ -24,11 +24,39 @@ class _FullsizeOracles:
     per configuration (tests/fullsize_oracle.py) is started as soon as the selected tests are known and works
     while the rest of the suite runs; the tests that need a result wait for it."""
 
+    # host memory one child needs at the full size (tests/fullsize_oracle.py) -- on top of the suite's own arrays
+    NEED_GIB = {"plain": 45, "rc": 24}
+    HEADROOM_GIB = 24
+
     def __init__(self):
         self.dir = None
         self.children = {}
+        self.skip_reason = None  # set when the children are not started: the tests fall back to a prefix of the text
+
+    @staticmethod
+    def mem_available_gib():
+        try:
+            for line in open("/proc/meminfo"):
+                if line.startswith("MemAvailable:"):
+                    return int(line.split()[1]) / (1 << 20)
+        except OSError:
+            pass
+        return None
 
     def start(self, modes):
+        # The children are not started where they cannot finish: an explicit opt-out, a pytest-xdist worker (every
+        # worker would start its own pair), or a host without the memory (the session would be OOM-killed).
+        if os.environ.get("NOLZSS_SKIP_FULLSIZE"):
+            self.skip_reason = "NOLZSS_SKIP_FULLSIZE is set"
+        elif os.environ.get("PYTEST_XDIST_WORKER"):
+            self.skip_reason = "running under pytest-xdist: the full-size oracle children are started by a plain session only"
+        else:
+            need = sum(self.NEED_GIB.get(m, 0) for m in modes) + self.HEADROOM_GIB
+            have = self.mem_available_gib()
+            if have is not None and have < need:
+                self.skip_reason = f"MemAvailable {have:.0f} GiB < {need} GiB needed by the full-size oracle children"
+        if self.skip_reason:
+            return
         base = "/dev/shm" if os.path.isdir("/dev/shm") else None
         self.dir = Path(tempfile.mkdtemp(prefix="nolzss_fullsize_", dir=base))
         for mode in sorted(modes):

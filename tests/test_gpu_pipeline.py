@@ -299,6 +299,77 @@ def test_collections_of_similar_genomes(native, copies, base_len):
     assert np.array_equal(d["isa"].astype(np.int64), isa)
 
 
+@pytest.mark.parametrize("depth", ["2048", "96"])
+def test_pivot_rounds(depth):
+    """Pivot rounds (group_sort.hpp, kPivot): every tied group is sorted against the first member of its segment.
+    One child process with NOLZSS_PIVOT_MIN=1 (every text that leaves ties behind the first direct round takes them)
+    and the cap of the first round lowered to 49 symbols: collections of 3 .. 300 similar sequences (groups in every
+    size class of the kernels: tiles of small groups, one workgroup per group of up to 128 / 256 / 1024 members),
+    exact copies (segments that agree up to the cap stay tied for the doubling rounds; NOLZSS_PIVOT_DEPTH=96 makes
+    that the common case), suffixes that end inside a comparison (copies at the end of the text, prepared strings with
+    sentinels, reverse complement), runs (groups beyond the kernels' reach stay as they are), other alphabets.
+    Factors, suffix array, LCP and inverse suffix array against the oracle."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys
+sys.path.insert(0, "tests")
+import numpy as np
+import gen, oracle_lib as oracle
+from nolzss_amd import _noLZSS as native
+def rnd(n, seed): return gen.random_dna(n, seed)
+def mutate(x, k, seed):
+    y = x.copy(); r = np.random.default_rng(seed)
+    idx = r.integers(0, len(y), size=k); y[idx] = np.frombuffer(b"ACGT", dtype=np.uint8)[r.integers(0, 4, size=k)]
+    return y
+def collection(copies, base_len, per, seed):
+    base = rnd(base_len, seed)
+    return np.concatenate([base] + [mutate(base, max(1, base_len // per), seed * 100 + k) for k in range(copies - 1)])
+a, b, c = rnd(5000, 1), rnd(3000, 2), rnd(777, 3)
+cases = [
+    collection(3, 20000, 1000, 11), collection(5, 20000, 300, 12), collection(17, 6000, 1000, 13),
+    collection(40, 3000, 500, 14), collection(70, 2000, 1000, 15), collection(100, 1500, 200, 16),
+    collection(140, 1200, 1000, 17), collection(300, 700, 500, 18), collection(600, 300, 300, 19),
+    collection(1100, 150, 100, 20),                             # groups beyond 1024 members: left alone
+    np.concatenate([a, a, a, a]),                               # exact copies: tied up to the cap
+    np.concatenate([a, b, a, c, a[:2000], b, a[:2000]]),        # copies that end where the text ends
+    np.concatenate([collection(20, 1000, 100, 21), np.tile(a[:7], 400), collection(9, 900, 50, 22)]),
+    np.tile(a[:300], 40),                                       # period 300: 40 copies, every suffix in a group
+    np.concatenate([np.tile(a[:31], 200), b, np.tile(a[:31], 150)]),
+    gen.repeat_dna(150000, 78, lo=64, hi=9000),
+]
+texts = [bytes(x) for x in cases]
+texts += [b"abracadabra, " * 300 + b"simsalabim" * 100 + b"abracadabra, " * 300,       # 8-bit alphabet
+          bytes(collection(30, 800, 100, 23) + 1),                                       # other symbols, sigma = 4
+          bytes(np.concatenate([np.frombuffer(b"ACGTNRYK", dtype=np.uint8)[np.random.default_rng(5).integers(0, 8, 3000)]] * 12))]  # 4-bit
+for t in texts:
+    got = native.factorize_array(t)
+    exp = oracle.factors_array(t)
+    assert len(got) == len(exp), (len(t), len(got), len(exp))
+    for k in ("start", "length", "ref"):
+        assert np.array_equal(got[k], exp[k]), (len(t), k)
+    d = native.debug_arrays(t)
+    sa = oracle.suffix_array(t)
+    assert np.array_equal(d["sa"].astype(np.int64), sa.astype(np.int64)), len(t)
+    assert np.array_equal(d["lcp"][:len(t)].astype(np.int64), oracle.lcp_array(t, sa).astype(np.int64)), len(t)
+    isa = np.empty(len(t), dtype=np.int64); isa[sa] = np.arange(len(t))
+    assert np.array_equal(d["isa"].astype(np.int64), isa), len(t)
+# prepared strings: sentinels between the sequences, with and without reverse complement
+fam = [bytes(mutate(a[:2500], 3, 40 + k)) for k in range(9)]
+for seqs in (fam, fam[:3], [bytes(a[:3000]), bytes(b), bytes(a[:3000]), bytes(a[:1500])]):
+    S, orig, sent = native.prepare_multiple_dna_sequences_w_rc_bytes(seqs)
+    assert native.factorize_multiple_dna_w_rc(S) == oracle.factorize_multiple_dna_w_rc(S), len(seqs)
+print("ok", len(texts))
+'''
+    env = dict(os.environ, NOLZSS_REFINE_WORDS="1", NOLZSS_PIVOT_MIN="1", NOLZSS_PIVOT_DEPTH=depth, NOLZSS_TRACE="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    done = [int(line.split("pivot rounds:")[1].split()[0]) for line in r.stderr.splitlines() if "pivot rounds:" in line]
+    assert len(done) >= 15 and sum(done) > 100000, done  # the rounds ran and finished suffixes
+
+
 def test_periodic_runs_pass():
     """Runs of a short period tie the suffixes of a run in groups that only log2(run length) doubling
     rounds would resolve; the periodic-run pass orders them arithmetically (suffix_array.hip, "Periodic

@@ -192,6 +192,45 @@ def test_lpt_assignment_is_deterministic_and_balanced():
     assert lpt_assignment([], 2) == []
 
 
+@pytest.mark.parametrize("n_dev", [1, 2, 4, 8])
+@pytest.mark.parametrize("with_rc", [False, True])
+def test_batch_plan_deals_every_record_once(n_dev, with_rc):
+    """The in-process multi-device path of nolzss_factorize_batch (api.hip: plan_batch, lpt_plan_singles) has only ever
+    RUN with one device; its plan is host logic and is checked here for 2, 4 and 8 devices: every non-empty record is
+    dealt exactly once -- to one merged run (taken from one work queue by lane w on device w % n_dev) or to one device
+    for a run of its own --, the runs hold consecutive records, and the single records are balanced within the
+    longest-processing-time bound (no device carries more than the lightest one plus one record)."""
+    import random
+    from nolzss_amd import _noLZSS
+    rng = random.Random(1000 * n_dev + with_rc)
+    shapes = [
+        [1 << 22] * 512,                                                   # BASELINE config 4
+        [rng.randint(1, 5000) for _ in range(3000)],                       # short records only
+        [0, 5, 0, 1 << 28, 7, 1 << 29, 0, 3, 1 << 27, 1 << 21, 1 << 20],   # empty, tiny and very long ones
+        [rng.choice([0, 1, 100, 10_000, 1 << 20, 1 << 22, 1 << 24, 1 << 27, 3 << 27]) for _ in range(400)],
+        [1 << 28] * 17, [3], [], [0, 0],
+    ]
+    for lens in shapes:
+        chunk_of, device_of, n_chunks = _noLZSS.debug_batch_plan(lens, n_dev, with_rc)
+        members = {}
+        for j, L in enumerate(lens):
+            placed = (chunk_of[j] >= 0) + (device_of[j] >= 0)
+            assert placed == (1 if L > 0 else 0), (j, L, chunk_of[j], device_of[j])
+            if chunk_of[j] >= 0:
+                members.setdefault(chunk_of[j], []).append(j)
+            assert device_of[j] < n_dev
+        assert sorted(members) == list(range(n_chunks))
+        for k, js in members.items():
+            assert len(js) >= 2                                            # a run of one record is a single record
+            between = [j for j in range(js[0], js[-1] + 1) if j not in js]
+            # what lies between the members of a run belongs elsewhere: empty records, or records of the other size class
+            assert all(chunk_of[j] != k for j in between)
+        load = [sum(L for j, L in enumerate(lens) if device_of[j] == d) for d in range(n_dev)]
+        singles = [L for j, L in enumerate(lens) if device_of[j] >= 0]
+        if singles:
+            assert max(load) - min(load) <= max(singles), (load, max(singles))
+
+
 def test_v2_reader_against_hand_packed_files(tmp_path):
     """reference: tests/test_utils.py:177-290 -- footers packed by hand"""
     import struct

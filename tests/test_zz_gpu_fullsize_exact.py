@@ -33,11 +33,27 @@ def _assert_equal(got, exp, what):
                         f"{list(zip(*(exp[c][lo:bad + 3].tolist() for c in ('start', 'length', 'ref'))))}")
 
 
+def _prefix_fallback(native, mode, reason):
+    """Where the full-size oracle children cannot run (tests/conftest.py: too little host memory, pytest-xdist, opt-out):
+    the same text at 2^24 bases, every factor against the oracle computed in this process -- then skip with the reason."""
+    import oracle_lib as oracle
+    text = fullsize_oracle.text_of(mode, 24)
+    if mode == "plain":
+        got, exp = native.factorize_array(text), oracle.factors_array(text)
+    else:
+        S, _, _ = oracle.prepare_multiple_dna_w_rc([text.tobytes()])
+        got, exp = native.factorize_dna_w_rc_array(text), oracle.factors_array_multiple_dna_w_rc(S)
+    _assert_equal(got, {k: exp[k] for k in ("start", "length", "ref")}, f"{mode}, 2^24-base fallback")
+    pytest.skip(f"full size not checked ({reason}); the 2^24-base form of the same text is exact")
+
+
 @pytest.mark.timeout(2400)
 @pytest.mark.fullsize_oracle("plain")
 def test_config3_repeat_1Gi_every_factor(native, oracle_children):
     """BASELINE config 3: 2^30 bases, 40 % copied blocks: tiling, sampled true-match checks, count == len,
     and all records equal to the oracle's."""
+    if oracle_children.skip_reason:
+        _prefix_fallback(native, "plain", oracle_children.skip_reason)
     n = 1 << 30
     text = fullsize_oracle.text_of("plain")
     assert len(text) == n
@@ -56,6 +72,8 @@ def test_config3_repeat_1Gi_every_factor(native, oracle_children):
 def test_config5_rc_256Mi_every_factor(native, oracle_children):
     """BASELINE config 5 size: 2^28 bases + reverse-complement strand: tiling, sampled (reverse-complement)
     true-match checks, count == len, and all records (with the RC flag in `ref`) equal to the oracle's."""
+    if oracle_children.skip_reason:
+        _prefix_fallback(native, "rc", oracle_children.skip_reason)
     n = 1 << 28
     text = fullsize_oracle.text_of("rc")
     assert len(text) == n

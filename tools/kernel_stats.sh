@@ -3,6 +3,15 @@
 # (run on the GPU box; the program comes directly after "--": no env / bash -c hop under the profiler; the
 # profiler runs in /tmp, so give script paths relative to the repository root: they are made absolute here)
 name=$1; shift
+GRAFT_REPO_ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+# the program must be a real ELF binary: a shim or a "#!/usr/bin/env" script would exec under the profiler's preloaded
+# runtime (which has initialised the GPU by then), and that is what takes a box down
+prog=$(readlink -f "$(command -v "$1")")
+if [ -z "$prog" ] || [ "$(head -c 4 "$prog" | od -An -c | tr -d ' ')" != "177ELF" ]; then
+  echo "tools/kernel_stats.sh: '$1' does not resolve to an ELF binary ($prog): refusing to run it under rocprofv3" >&2
+  exit 2
+fi
+shift; set -- "$prog" "$@"
 out=$GRAFT_REPO_ROOT/gpurun_out/$name
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
