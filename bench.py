@@ -79,7 +79,6 @@ PMC_FILES = ["r04_pmc_radix_traffic.json", "r03_pmc_radix_traffic.json", "r02_pm
 STEP_PMC_FILE = "r04_pmc_step.json"
 SHADER_CLOCK_HZ = 2.4e9   # MI355X peak engine clock
 SIMDS = 256 * 4           # 256 CUs x 4 SIMDs; a wave64 VALU instruction occupies its SIMD for 4 cycles
-GATHER_LINE_RATE = 44.1e9  # random 256-bit windows per second the chip sustains (tools/gatherbench.hip, profiles/r01_gatherbench.txt)
 
 
 def measure_copy_ceiling(dev, nbytes=1 << 30, reps=6):
@@ -112,54 +111,56 @@ def step_counters():
         return None
 
 
-# library stage name -> (kernel of the counter summary, what bounds it)
+HBM_ACHIEVABLE_GBS = 6300.0  # MI355X_MICROARCH.md: what a streaming kernel reaches of the 8 TB/s spec peak
+
+# library stage name -> (kernels of the counter summary that run inside it, what bounds it)
 KERNEL_OF_STAGE = [
-    ("rs_scatter.u32", "rs_scatter_kernel<u32, u32, ArraySrc<u32>, u32>", "hbm"),
-    ("sa_direct_sort", "group_refine_kernel<2, false>", "valu_issue + random_lines"),
-    ("lpf", "lpf_tile_kernel<false>", "lds + valu_issue"),
-    ("factor_emit", "factor_kernel<false, false>", "random_lines"),
-    ("sa_regroup", "regroup_kernel<true, 3>", "valu_issue"),
-    ("window_scatter", "window_scatter2_kernel", "hbm"),
-    ("rs_scatter.text", "rs_scatter_kernel<u64, u32, Text16Src, u32>", "hbm (writes) + valu_issue"),
-    ("rs_hist", "rs_hist_kernel<u32, ArraySrc<u32> >", "hbm"),
+    ("rs_scatter.u32", ["rs_scatter_kernel<u32, u32, ArraySrc<u32>, u32>", "rs_scatter_kernel<u32, u32, RankSrc, u64>",
+                        "rs_scatter_kernel<u32, u16, PairSrc, u64>"], "hbm"),
+    ("sa_direct_sort", ["group_refine_kernel<2, false>"], "line fills (random windows of the text) + valu_issue"),
+    ("lpf", ["lpf_tile_kernel<false>"], "lds + valu_issue"),
+    ("factor_emit", ["factor_kernel<false, false>"], "line fills (random blocks of the pyramids)"),
+    ("sa_regroup", ["regroup_kernel<true, 3>", "regroup_kernel<false, 0>", "compact_survivors_kernel"], "valu_issue + look-back latency"),
+    ("window_scatter", ["window_scatter2_kernel"], "hbm"),
+    ("rs_scatter.text", ["rs_scatter_kernel<u64, u32, Text16Src, u32>"], "valu_issue + hbm writes"),
+    ("rs_hist", ["rs_hist_kernel<u32, ArraySrc<u32> >", "rs_hist_kernel<u32, PairSrc>", "rs_hist_kernel<u32, RankSrc>",
+                 "rs_hist_kernel<u64, Text16Src>"], "hbm + per-tile latency"),
+    ("chain_exit", ["chain_exit_kernel"], "hbm + lds"),
 ]
 
 
 def kernel_bounds(stats, steps, pmc):
     """roofline.kernels: the largest kernels of the step, each with its own bound.  Durations are this run's HIP events
-    (live); instruction, LDS and HBM byte counts per launch come from the committed counter summary (derived: they do not
-    change unless the kernel does).  valu_issue_frac = VALU wave-instructions x 4 cycles / (1024 SIMDs x clock) over the
-    kernel's time; lds_frac = LDS-active cycles per CU over its time; hbm_frac = counter bytes over its time against the
-    8 TB/s spec peak; random_line_frac = fetched 128-byte lines per second against the gather ceiling of tools/gatherbench."""
+    (live); instruction, LDS and HBM byte counts come from the committed counter summary of ONE factorization of the same
+    text (derived: they do not change unless the kernel does).  valu_issue_frac = VALU wave-instructions x 4 cycles /
+    (1024 SIMDs x clock) over the kernel's time; lds_frac = LDS-active cycles per CU over its time; hbm_GBps = FETCH_SIZE
+    (gfx950-corrected) + WRITE_SIZE over its time, as a fraction of the 8 TB/s spec peak (hbm_frac) and of the 6.3 TB/s a
+    streaming kernel reaches (hbm_frac_of_achievable): for the random-access kernels these bytes are 128-byte line fills."""
     out = []
     ks = (pmc or {}).get("kernels", {})
-    for stage, kernel, bound in KERNEL_OF_STAGE:
+    for stage, kernels, bound in KERNEL_OF_STAGE:
         if stage not in stats or stats[stage][1] <= 0:
             continue
         cnt, ms, nbytes = stats[stage]
-        e = {"stage": stage, "kernel": kernel, "bound": bound, "ms_per_step": ms / steps, "launches_per_step": cnt / steps}
+        e = {"stage": stage, "kernels": kernels, "bound": bound, "ms_per_step": ms / steps, "launches_per_step": cnt / steps}
         if nbytes:
             e["algorithmic_GBps"] = nbytes / (ms * 1e-3) / 1e9
             e["algorithmic_frac_of_hbm_peak"] = e["algorithmic_GBps"] / HBM_PEAK_GBS
-        c = ks.get(kernel)
-        if c and c.get("launches"):
-            per_step_launches = cnt / steps
-            scale = per_step_launches / c["launches"]  # the summary holds one factorization
+        cs = [ks[k] for k in kernels if k in ks]
+        if cs and pmc.get("bases") == stats.get("_bases"):
             t = ms / steps * 1e-3
-            if "SQ_INSTS_VALU" in c:
-                e["valu_issue_frac"] = c["SQ_INSTS_VALU"] * scale * 4.0 / (SIMDS * SHADER_CLOCK_HZ) / t
-            if "SQ_INSTS_SALU" in c and "SQ_INSTS_VALU" in c and c["SQ_INSTS_VALU"]:
-                e["salu_per_valu"] = c["SQ_INSTS_SALU"] / c["SQ_INSTS_VALU"]
-            if "SQ_LDS_IDX_ACTIVE" in c:
-                e["lds_frac"] = c["SQ_LDS_IDX_ACTIVE"] * scale / 256.0 / SHADER_CLOCK_HZ / t
-                if c["SQ_LDS_IDX_ACTIVE"]:
-                    e["lds_bank_conflict_share"] = c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"]
-            hbm = (c.get("fetch_bytes", 0.0) + c.get("write_bytes", 0.0)) * scale
+            tot = lambda name: sum(c.get(name, 0.0) for c in cs)  # noqa: E731  (one factorization = one step)
+            if tot("SQ_INSTS_VALU"):
+                e["valu_issue_frac"] = tot("SQ_INSTS_VALU") * 4.0 / (SIMDS * SHADER_CLOCK_HZ) / t
+                e["salu_per_valu"] = tot("SQ_INSTS_SALU") / tot("SQ_INSTS_VALU")
+            if tot("SQ_LDS_IDX_ACTIVE"):
+                e["lds_frac"] = tot("SQ_LDS_IDX_ACTIVE") / 256.0 / SHADER_CLOCK_HZ / t
+                e["lds_bank_conflict_share"] = tot("SQ_LDS_BANK_CONFLICT") / tot("SQ_LDS_IDX_ACTIVE")
+            hbm = tot("fetch_bytes") + tot("write_bytes")
             if hbm:
                 e["hbm_GBps"] = hbm / t / 1e9
                 e["hbm_frac"] = e["hbm_GBps"] / HBM_PEAK_GBS
-            if "random_lines" in bound and c.get("fetch_bytes"):
-                e["random_line_frac"] = c["fetch_bytes"] * scale / 128.0 / t / GATHER_LINE_RATE
+                e["hbm_frac_of_achievable"] = e["hbm_GBps"] / HBM_ACHIEVABLE_GBS
             e["counters_derived_from"] = f"profiles/{STEP_PMC_FILE}"
         out.append(e)
     out.sort(key=lambda e: -e["ms_per_step"])
@@ -359,7 +360,7 @@ def run_single_sequence(job: Job, a):
                      "avg_launch_ms": (ms / cnt) if cnt else None,
                      "algorithmic_bytes_per_launch": (nbytes / cnt) if cnt else None,
                      "by_class": by_class,
-                     "kernels": kernel_bounds(stats, a.steps, pmc)},
+                     "kernels": kernel_bounds(dict(stats, _bases=n), a.steps, pmc)},
         # SURVEY.md 8d end-to-end figure: 50 B per base of compulsory traffic over the whole pipeline
         "pipeline_hbm": {"algorithmic_bytes_per_base": ALG_BYTES_PER_BASE,
                          "achieved_GBps_per_gpu": ALG_BYTES_PER_BASE * n / step_s / 1e9,

@@ -24,11 +24,8 @@ done
 import csv, glob, json, re, sys, collections
 root, probe_args = sys.argv[1], sys.argv[2:]
 n = None
-for a in probe_args:
-    if a.startswith("2^"):
-        n = 1 << int(a[2:])
-    elif a.isdigit():
-        n = int(a)
+for a in probe_args[1:2]:  # tools/probe.py <kind> <n> ...
+    n = (1 << int(a[2:])) if a.startswith("2^") else int(a)
 
 
 def short(name):
