@@ -6,6 +6,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include "divup.hpp"
+
 #include <cstdint>
 #include <cstdio>
 #include <map>
@@ -33,7 +35,6 @@ inline void hip_check(hipError_t e, const char *what, const char *file, int line
 #define HIP_CHECK(x) ::nolzss::hip_check((x), #x, __FILE__, __LINE__)
 #define KERNEL_CHECK() ::nolzss::hip_check(hipGetLastError(), "kernel launch", __FILE__, __LINE__)
 
-inline size_t div_up(size_t a, size_t b) { return (a + b - 1) / b; }
 
 // Bump allocator over one device slab.  The pipeline sizes the slab once from n (all arrays
 // are 32-bit index arrays over the text, so the footprint is a small multiple of n) and

@@ -17,13 +17,13 @@ namespace nolzss {
 // (equal distance: the lower terminator index) -- the order the reference's unique sentinels give
 // up to a relabelling of symbols, which the factorization does not depend on.
 //
-// INDEPENDENT sequences (the merged per-sequence batch, api.hip): seq_shift != 0 puts the terminator
+// INDEPENDENT sequences (the merged per-sequence batch, batch.hip): seq_shift != 0 puts the terminator
 // index of a suffix -- the number of its sequence -- above bit seq_shift of its round-0 sort key.
 // Suffixes then order by (sequence, suffix): the suffix array is the concatenation of the suffix
 // arrays of the sequences, the LCP between neighbours of different sequences is 0, and every later
 // stage (candidates, cursor, factor records) stays inside one sequence without knowing about it.
 constexpr int kTermBlockShift = 12;
-// their key: [record number][12 bases][4-bit length tag].  Records are short (api.hip merges records
+// their key: [record number][12 bases][4-bit length tag].  Records are short (batch.hip merges records
 // below 2^21 bases), so 12 bases separate as well as 17 do in a 2^30-base text, and every 8 key bits
 // less is a radix pass less.
 constexpr int kIndSyms = 12, kIndTagBits = 4, kIndKeyBits = kIndSyms * 2 + kIndTagBits;

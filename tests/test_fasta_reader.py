@@ -1,4 +1,4 @@
-"""The native FASTA reader (api.hip: parse_fasta; no device needed) against a line-by-line restatement
+"""The native FASTA reader (fasta_reader.cpp: parse_fasta; host only, no device needed) against a line-by-line restatement
 of the reference's rules (parse_fasta_sequences_and_ids, src/cpp/fasta_processor.cpp:28-128):
 records, ids, what is skipped, what is an error and with which text."""
 import random

@@ -1,5 +1,5 @@
 """GPU parity of the MERGED batch: short nucleotide records factorized together in one pipeline run
-as independent sequences (api.hip, run_merged_chunk) must give, record by record, exactly what the
+as independent sequences (batch.hip, run_merged_chunk) must give, record by record, exactly what the
 oracle -- and the one-record-at-a-time path -- gives.
 reference: the per-sequence loop of genomics.read_nucleotide_fasta (src/noLZSS/genomics/fasta.py:110-122)
 """

@@ -378,7 +378,7 @@ def test_native_fasta_shards_and_device_batch(pkg, tmp_path):
 
 def test_concurrent_calls_with_staged_downloads(pkg):
     """factor arrays of 32 MiB and more come down through pinned chunks emptied by several host threads
-    (api.hip, download_bytes), and blocks of 256 MiB and more are released by a detached thread: four callers at
+    (c_abi.hip, download_bytes), and blocks of 256 MiB and more are released by a detached thread: four callers at
     once, each on its own lane, get what a lone caller gets; results of a 2^24-base random text (1.4 M factors,
     34 MB of records) are also checked as a tiling with true earlier occurrences"""
     import threading

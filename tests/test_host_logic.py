@@ -136,7 +136,7 @@ def test_prepare_w_rc_host_side_matches_oracle():
 
 def test_prepare_w_rc_long_sequences_on_several_threads():
     """Sequences of tens of megabytes are validated, case-folded and reverse-complemented in pieces on several host
-    threads (api.hip: host_parallel): same bytes as numpy, and an invalid byte is still reported at its FIRST index."""
+    threads (host_util.hpp: host_parallel): same bytes as numpy, and an invalid byte is still reported at its FIRST index."""
     import numpy as np
     from nolzss_amd import _noLZSS
     rng = np.random.default_rng(7)
@@ -195,7 +195,7 @@ def test_lpt_assignment_is_deterministic_and_balanced():
 @pytest.mark.parametrize("n_dev", [1, 2, 4, 8])
 @pytest.mark.parametrize("with_rc", [False, True])
 def test_batch_plan_deals_every_record_once(n_dev, with_rc):
-    """The in-process multi-device path of nolzss_factorize_batch (api.hip: plan_batch, lpt_plan_singles) has only ever
+    """The in-process multi-device path of nolzss_factorize_batch (batch.hip: plan_batch, lpt_plan_singles) has only ever
     RUN with one device; its plan is host logic and is checked here for 2, 4 and 8 devices: every non-empty record is
     dealt exactly once -- to one merged run (taken from one work queue by lane w on device w % n_dev) or to one device
     for a run of its own --, the runs hold consecutive records, and the single records are balanced within the
