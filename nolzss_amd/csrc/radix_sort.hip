@@ -290,10 +290,23 @@ __global__ __launch_bounds__(kThreads) void rs_hist_kernel(Src src, size_t n, in
     }
 }
 
-template <typename KeyT, typename OutT, typename Src, typename ValT = uint32_t>
+// (kTimed, NOLZSS_SCATTER_PHASES: cycles per phase of a workgroup, summed over every 64th workgroup by its first thread;
+// the timed instantiation waits for its loads before it ranks so that the two can be told apart.  Round 4, a segmented
+// u32 pass at 2^30 pairs, 28.8 k cycles = 12 us per workgroup of which: start-up, descriptor, counters zeroed 2.0 k; the
+// 32 loads ISSUED 5.6 k (the memory pipe takes them at its own pace; they have arrived when the last one is out);
+// ranking 6.9 k; offsets 3.2 k (half of it the gather of the tile's 256 base offsets); keys staged 1.2 k, stored 3.8 k;
+// values staged 0.7 k, stored 2.4 k, drained 2.9 k.  Half memory phases throttled by back-pressure, half compute: nothing
+// to shave off one without the other growing -- asking for the base offsets first made the first key wait behind a
+// gather of 256 lines (+2.7 ms per step), barriers that wait for the LDS only between the two stagings let key and
+// value stores overlap and cost 1 ms, a software-pipelined form with the next tile's loads in flight needs 211 VGPRs
+// (two workgroups per CU: 33.6 instead of 23.4 ms): profiles/r04_ab/scatter_phases_and_variants.txt.)
+template <typename KeyT, typename OutT, typename Src, typename ValT = uint32_t, bool kTimed = false>
 __global__ __launch_bounds__(kThreads, kScatterWavesPerSimd) void rs_scatter_kernel(
     Src src, OutT *__restrict__ keys_out, ValT *__restrict__ vals_out, size_t n, int shift,
-    const uint32_t *__restrict__ tile_base, uint32_t num_tiles, SegView seg) {
+    const uint32_t *__restrict__ tile_base, uint32_t num_tiles, SegView seg, unsigned long long *__restrict__ phases = nullptr) {
+    const bool timed = kTimed && phases != nullptr && (blockIdx.x & 63) == 0 && threadIdx.x == 0;
+    unsigned long long ck[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (kTimed && timed) ck[0] = __builtin_readcyclecounter();
     const uint32_t tile = xcd_tile(blockIdx.x, num_tiles);
     if (tile == 0xffffffffu) return;
     const TileExtent ext = tile_extent(tile, n, num_tiles, seg);
@@ -311,6 +324,7 @@ __global__ __launch_bounds__(kThreads, kScatterWavesPerSimd) void rs_scatter_ker
 
     for (int i = tid; i < kWaves * kBins; i += kThreads) s_whist[i] = 0;
     __syncthreads();
+    if (kTimed && timed) ck[1] = __builtin_readcyclecounter();  // (includes the descriptor load: ext is used above)
 
     const size_t base = ext.first;
     KeyT key[kKeysPerThread];
@@ -342,6 +356,11 @@ __global__ __launch_bounds__(kThreads, kScatterWavesPerSimd) void rs_scatter_ker
     for (int row = 0; row < kKeysPerThread; ++row) {
         const uint32_t local = (uint32_t)w * kWaveSpan + (uint32_t)row * 64 + lane;
         val[row] = local < ext.count ? src.val(base + local) : 0;
+    }
+    if constexpr (kTimed) {
+        if (timed) ck[2] = __builtin_readcyclecounter();  // loads issued
+        __builtin_amdgcn_s_waitcnt(0x0f70);                // vmcnt(0): the whole tile has arrived
+        if (timed) ck[3] = __builtin_readcyclecounter();
     }
     // rank inside the wavefront: rows of 64 keys in input order (keeps the sort stable).  The lowest
     // lane of every digit group adds the group's size to the wave's counter with ONE returning LDS
@@ -378,6 +397,7 @@ __global__ __launch_bounds__(kThreads, kScatterWavesPerSimd) void rs_scatter_ker
         const uint32_t packed = lrank[row];
         lrank[row] = ((uint32_t)__shfl((int)packed, (int)(packed >> 17), 64) & 0x7ffu) + ((packed >> 11) & 63u);
     }
+    if (kTimed && timed) ck[4] = __builtin_readcyclecounter();  // ranked
     __syncthreads();
 
     // thread = bin (the first kBins threads): turn per-wave counts into tile-local start positions
@@ -403,6 +423,7 @@ __global__ __launch_bounds__(kThreads, kScatterWavesPerSimd) void rs_scatter_ker
         }
     }
     __syncthreads();
+    if (kTimed && timed) ck[5] = __builtin_readcyclecounter();  // tile-local offsets (and the tile's bases from the table)
 
     // tile-local sorted position of every element (reuses lrank)
 #pragma unroll
@@ -415,6 +436,7 @@ __global__ __launch_bounds__(kThreads, kScatterWavesPerSimd) void rs_scatter_ker
         if ((uint32_t)w * kWaveSpan + (uint32_t)row * 64 + lane < ext.count) s_keys[lrank[row]] = key[row];
     }
     __syncthreads();
+    if (kTimed && timed) ck[6] = __builtin_readcyclecounter();  // keys staged
 
     const uint32_t count = ext.count;
     uint32_t gpos[kKeysPerThread];
@@ -429,15 +451,26 @@ __global__ __launch_bounds__(kThreads, kScatterWavesPerSimd) void rs_scatter_ker
         }
     }
     __syncthreads();
+    if (kTimed && timed) ck[7] = __builtin_readcyclecounter();  // key stores issued (and, through the barrier, drained)
 #pragma unroll
     for (int row = 0; row < kKeysPerThread; ++row) {
         if ((uint32_t)w * kWaveSpan + (uint32_t)row * 64 + lane < ext.count) s_vals[lrank[row]] = val[row];
     }
     __syncthreads();
+    if (kTimed && timed) ck[8] = __builtin_readcyclecounter();  // values staged
 #pragma unroll
     for (int j = 0; j < kKeysPerThread; ++j) {
         const uint32_t p = (uint32_t)j * kThreads + tid;
         if (p < count) vals_out[gpos[j]] = s_vals[p];
+    }
+    if constexpr (kTimed) {
+        if (timed) {
+            ck[9] = __builtin_readcyclecounter();  // value stores issued
+            for (int k = 0; k < 9; ++k) atomicAdd(phases + k, ck[k + 1] - ck[k]);
+            __builtin_amdgcn_s_waitcnt(0x0f70);
+            atomicAdd(phases + 9, (unsigned long long)__builtin_readcyclecounter() - ck[9]);  // value stores drained
+            atomicAdd(phases + 10, 1ull);
+        }
     }
 }
 
@@ -656,9 +689,27 @@ void radix_pass(Src src, OutT *keys_out, ValT *vals_out, size_t n, int shift, ui
         // per CU -- and separate LDS buffers for keys and values: the u32 passes stayed at 3.9 TB/s at 2^30
         // pairs either way.  The pass is bound by its scattered 64-byte write runs, not by latency hiding.)
         const uint32_t grid = xcd_grid(num_tiles);
-        rs_scatter_kernel<KeyT, OutT, Src, ValT><<<grid, kThreads, 0, stream>>>(src, keys_out, vals_out, n, shift, hist,
-                                                                                num_tiles, seg);
-        KERNEL_CHECK();
+        static const bool want_phases = getenv("NOLZSS_SCATTER_PHASES") != nullptr;
+        if (want_phases && n >= (size_t(1) << 24) && std::is_same<Src, ArraySrc<KeyT>>::value) {
+            unsigned long long *d_ph = arena.alloc<unsigned long long>(12);
+            HIP_CHECK(hipMemsetAsync(d_ph, 0, 12 * sizeof(unsigned long long), stream));
+            rs_scatter_kernel<KeyT, OutT, Src, ValT, true><<<grid, kThreads, 0, stream>>>(src, keys_out, vals_out, n, shift, hist,
+                                                                                          num_tiles, seg, d_ph);
+            KERNEL_CHECK();
+            unsigned long long h[12];
+            HIP_CHECK(hipMemcpyAsync(h, d_ph, sizeof(h), hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+            const double wn = h[10] ? (double)h[10] : 1.0;
+            fprintf(stderr, "[nolzss] rs_scatter phases (cycles per workgroup, %llu sampled, shift %d, %s): start-up + descriptor + zero %.0f  "
+                            "loads issued %.0f  loads arrive %.0f  ranking %.0f  offsets %.0f  stage keys %.0f  store keys %.0f  stage values %.0f  "
+                            "store values %.0f  drain %.0f\n",
+                    h[10], shift, seg.desc ? "segmented" : "whole array", h[0] / wn, h[1] / wn, h[2] / wn, h[3] / wn, h[4] / wn, h[5] / wn,
+                    h[6] / wn, h[7] / wn, h[8] / wn, h[9] / wn);
+        } else {
+            rs_scatter_kernel<KeyT, OutT, Src, ValT><<<grid, kThreads, 0, stream>>>(src, keys_out, vals_out, n, shift, hist,
+                                                                                    num_tiles, seg);
+            KERNEL_CHECK();
+        }
     }
 }
 
