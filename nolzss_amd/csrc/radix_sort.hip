@@ -38,7 +38,10 @@ constexpr int kWaves = kThreads / 64;
 constexpr int kBins = 1 << kRadixBits;
 constexpr int kWaveSpan = 64 * kKeysPerThread;  // 1024 keys per wavefront, 16 rows of 64
 // blocks per CU the scatter kernel is compiled for: 3 x 256 or 2 x 512 threads (128 VGPRs at most for the latter)
-constexpr int kScatterWavesPerSimd = kThreads == 256 ? 1 : 4;  // (1 = no register cap: the 256-thread form as it always was)
+#ifndef NOLZSS_SCATTER_BLOCKS
+#define NOLZSS_SCATTER_BLOCKS 1
+#endif
+constexpr int kScatterWavesPerSimd = kThreads == 256 ? NOLZSS_SCATTER_BLOCKS : 4;  // (1 = no register cap: the 256-thread form as it always was)
 
 static_assert(kThreads % kBins == 0, "the first kBins threads own one bin each in the offset phase");
 
@@ -180,6 +183,67 @@ struct Text16Src {
         const int jj = idx0 == 0 ? 15 - j : j;
         return (uint32_t)((w >> (64 - kRadixBits - 2 * jj)) & (uint64_t)(kBins - 1));
     }
+};
+// The same pass for a SEGMENTED text with a short terminator table (at most kTermFew entries: a prepared reverse-
+// complement string T $ rc(T) $ has three).  Every terminator in front of the end has 16 suffixes that end inside the key
+// window (0 .. 15 symbols: the terminator's own suffix is the one of 0 symbols), the end of the text 15 (1 .. 15) unless the
+// text ends with a terminator.  They come first, ordered by (symbols, terminator) -- the order text.hpp gives suffixes that
+// agree up to the nearer terminator -- and the others follow in text order, the removed stretches skipped.  Symbols behind
+// the terminator of a suffix belong to the next segment and are masked out of its key.  (Segments of at least 16 symbols:
+// key16_applicable.)
+struct Text16SegSrc {
+    using Raw = SymWords;
+    const uint64_t *__restrict__ words;
+    uint32_t n;
+    uint32_t treal;       // terminators in front of the end of the text
+    uint32_t end_shorts;  // 15 or 0
+    uint32_t nshort;      // 16 * treal + end_shorts
+    uint32_t pos[kTermFew];  // pos[treal] = n
+    __device__ __forceinline__ uint32_t suffix_of(size_t idx) const {
+        if (idx < nshort) {
+            const uint32_t c0 = treal, c1 = treal + (end_shorts ? 1u : 0u);
+            uint32_t L = 0, j = (uint32_t)idx;
+            if (idx >= c0) {
+                L = 1u + ((uint32_t)idx - c0) / c1;
+                j = ((uint32_t)idx - c0) % c1;
+            }
+            const uint32_t pj = j == 0 ? pos[0] : (j == 1 ? pos[1] : (j == 2 ? pos[2] : pos[3]));
+            return pj - L;
+        }
+        uint32_t p = (uint32_t)idx - nshort;
+#pragma unroll
+        for (uint32_t k = 0; k + 1 < kTermFew; ++k)
+            if (k < treal && p + 15u >= pos[k]) p += 16u;
+        return p;
+    }
+    // symbols in front of the next terminator of suffix s
+    __device__ __forceinline__ uint32_t limit_of(uint32_t s) const {
+        uint32_t next = n;
+#pragma unroll
+        for (int k = (int)kTermFew - 2; k >= 0; --k)
+            if ((uint32_t)k < treal && pos[k] >= s) next = pos[k];
+        return next - s;
+    }
+    __device__ __forceinline__ uint32_t masked(const Raw &raw, uint32_t s, uint32_t &tag) const {
+        const uint32_t lim = limit_of(s);
+        tag = lim < (uint32_t)kP16Syms ? lim : (uint32_t)kP16Syms;
+        uint32_t sym = (uint32_t)(sym_word_of<2>(raw, s) >> 32);
+        if (tag < (uint32_t)kP16Syms) sym = tag == 0 ? 0u : (sym & ~((1u << (2 * ((uint32_t)kP16Syms - tag))) - 1u));
+        return sym;
+    }
+    __device__ __forceinline__ Raw load(size_t idx, const TileExtent &) const { return sym_words<2>(words, suffix_of(idx)); }
+    __device__ __forceinline__ uint64_t key_of(const Raw &raw, size_t idx, const TileExtent &) const {
+        uint32_t tag;
+        const uint32_t sym = masked(raw, suffix_of(idx), tag);
+        return ((uint64_t)sym << kP16TagBits) | tag;
+    }
+    __device__ __forceinline__ uint32_t val(size_t idx) const { return suffix_of(idx); }
+    __device__ __forceinline__ uint32_t hist_digit_of(const Raw &raw, size_t idx, int, const TileExtent &) const {
+        uint32_t tag;
+        return masked(raw, suffix_of(idx), tag) >> (32 - kRadixBits);
+    }
+    __device__ __forceinline__ bool digits_from_window(int) const { return false; }
+    __device__ __forceinline__ uint64_t window(size_t) const { return 0; }
 };
 // Independent records, one BUCKET per record (radix_sort_record_keys): the pairs of a tile are the suffixes at
 // the tile's own text positions, the key [kRecSyms bases][4-bit length tag] of a suffix needs the end of its
@@ -1326,10 +1390,43 @@ void radix_sort_dna_keys(const PackedText &text, uint32_t *keys32[2], uint32_t *
     arena.rewind(m);  // (cur == 1 again)
 }
 
+bool key16_applicable(const PackedText &text) {
+    if (text.bits != 2 || text.terms.seq_shift != 0) return false;
+    if (!text.segmented) return text.terms.count == 1 && text.n >= 32;
+    // a short terminator table whose segments all hold at least 16 symbols (the text may end with a terminator)
+    const uint32_t cnt = text.terms.nfew;
+    if (cnt < 2 || cnt > kTermFew || text.n < 64) return false;
+    uint32_t start = 0;
+    for (uint32_t k = 0; k < cnt; ++k) {
+        const uint32_t p = text.terms.few[k];
+        const bool last = k + 1 == cnt;
+        if (p < start) return false;
+        const uint32_t len = p - start;
+        if (!(len >= 16 || (last && len == 0))) return false;
+        start = p + 1;
+    }
+    return text.terms.few[cnt - 1] == text.n;
+}
+
+namespace {
+Text16SegSrc make_text16_seg(const PackedText &text) {
+    Text16SegSrc src{};
+    src.words = text.words;
+    src.n = text.n;
+    const uint32_t cnt = text.terms.nfew;
+    src.treal = cnt - 1;
+    for (uint32_t k = 0; k < kTermFew; ++k) src.pos[k] = k < cnt ? text.terms.few[k] : text.n;
+    // (the text ends with a terminator: the last segment is empty and the end of the text has no suffixes of its own)
+    src.end_shorts = text.terms.few[cnt - 2] + 1 == text.n ? 0u : 15u;
+    src.nshort = 16u * src.treal + src.end_shorts;
+    return src;
+}
+}  // namespace
+
 void radix_sort_dna_keys16(const PackedText &text, uint32_t *keys32[2], uint32_t *vals[2], uint32_t *seg_mem,
                            SegView &seg_out, Arena &arena, hipStream_t stream, Profiler *prof) {
     const size_t n = text.n;
-    if (text.bits != 2 || text.segmented || text.terms.count != 1 || n < 32) throw HipError("radix_sort_dna_keys16: plain 2-bit texts only");
+    if (!key16_applicable(text)) throw HipError("radix_sort_dna_keys16: plain 2-bit texts, or segmented ones with a short terminator table");
     const size_t m = arena.mark();
     const uint32_t tiles0 = (uint32_t)div_up(n, kTile);
     uint32_t *hist = arena.alloc<uint32_t>((size_t)kBins * ((size_t)tiles0 + kBins));
@@ -1337,8 +1434,12 @@ void radix_sort_dna_keys16(const PackedText &text, uint32_t *keys32[2], uint32_t
     uint32_t *bstart = tabs, *tile0 = tabs + 257, *prev_ne = tabs + 2 * 257, *next_ne = tabs + 3 * 257;
     const double text_bytes = (double)n * 2 / 8.0;
     // most significant digit first: the first four bases (bits 32..39 of [32 key bits][8-bit tag])
-    radix_pass<uint64_t, uint32_t>(Text16Src{text.words, (uint32_t)n}, keys32[1], vals[1], n, 32, hist, tiles0, text_bytes,
-                                   text_bytes + 8.0 * (double)n, arena, stream, prof);
+    if (text.segmented)
+        radix_pass<uint64_t, uint32_t>(make_text16_seg(text), keys32[1], vals[1], n, 32, hist, tiles0, text_bytes,
+                                       text_bytes + 8.0 * (double)n, arena, stream, prof);
+    else
+        radix_pass<uint64_t, uint32_t>(Text16Src{text.words, (uint32_t)n}, keys32[1], vals[1], n, 32, hist, tiles0, text_bytes,
+                                       text_bytes + 8.0 * (double)n, arena, stream, prof);
     bucket_starts_kernel<<<1, kBins, 0, stream>>>(hist, tiles0, (uint32_t)n, bstart);
     KERNEL_CHECK();
     uint32_t h_start[kBins + 1], h_tab[3 * 257];

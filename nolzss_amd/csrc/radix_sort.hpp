@@ -97,6 +97,9 @@ void radix_sort_dna_keys(const PackedText &text, uint32_t *keys32[2], uint32_t *
 // Plain one-segment 2-bit DNA, 16-base key (text.hpp, kP16Syms): the most-significant-digit pass from the text
 // and THREE segmented passes over the 24 key bits above the tag byte of the stored word [24 key bits][8-bit tag].
 // The sorted words end in keys32[0], the suffixes in vals[0].  8 + 3 * 16 bytes of scatter traffic per suffix.
+// (also segmented texts with a terminator table of at most kTermFew entries and segments of at least 16 symbols -- a
+// prepared reverse-complement string --: key16_applicable says whether a text takes this sort)
+bool key16_applicable(const PackedText &text);
 void radix_sort_dna_keys16(const PackedText &text, uint32_t *keys32[2], uint32_t *vals[2], uint32_t *seg_mem,
                            SegView &seg_out, Arena &arena, hipStream_t stream, Profiler *prof = nullptr);
 

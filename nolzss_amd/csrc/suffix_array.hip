@@ -2086,7 +2086,8 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     // plain one-segment DNA: the 16-base key whose tag is not sorted (text.hpp, kP16Syms) -- one radix pass less
     // (NOLZSS_NO_KEY16: A/B switch back to the 40-bit key [17 bases][6-bit tag])
     static const bool no_key16 = getenv("NOLZSS_NO_KEY16") != nullptr;
-    const bool key16 = dna_fast && !no_key16 && !text.segmented && text.terms.count == 1 && n >= 32;
+    // (segmented texts with a short terminator table take it too: the reverse-complement string of one sequence)
+    const bool key16 = dna_fast && !no_key16 && key16_applicable(text);
     // independent LONG records (text.hpp, kRecSyms): the records are the buckets of the segmented sort
     // (NOLZSS_REC_BUCKET_MIN: smallest average record that takes it; partial tiles cost 4096 / that)
     static const uint64_t rec_bucket_min =
@@ -2137,7 +2138,7 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     uint64_t *keys[2];
     // (NOLZSS_FUSED_SORT: the 16-base key sort on fused 64-bit records, radix_sort.hip -- A/B switch)
     static const bool fused_sort = getenv("NOLZSS_FUSED_SORT") != nullptr && atoi(getenv("NOLZSS_FUSED_SORT")) != 0;
-    const bool fused = key16 && fused_sort;
+    const bool fused = key16 && fused_sort && !text.segmented;
     if (fused) {
         keys[0] = arena.alloc<uint64_t>(n);
         keys[1] = arena.alloc<uint64_t>(n);
