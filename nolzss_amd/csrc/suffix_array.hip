@@ -2400,12 +2400,17 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         if (trace) fprintf(stderr, "[nolzss]   %u tied suffixes in %u groups, %llu in groups of more than %u, %u next to a member at most %u symbols away: %s\n",
                            m, c4[2], (unsigned long long)huge, kGroupSortMax, c4[3], kPerVerifyMax, pivot ? "pivot rounds" : "no pivot rounds");
     }
-    if (full_direct2 || equalise || pivot) {
+    // (pivot rounds come in PASSES: what a pass leaves tied agrees on its cap, and while a pass finishes at least half of what
+    // it was given the next one goes four times as deep over what is left -- 96 genomes 0.1 % apart: 2.65e8 -> 5.9e7 -> 1e6
+    // tied suffixes after caps of 2048 and 8192 symbols, where the doubling rounds would take four rounds and the rank scatter
+    // in front of them.  A pass that finishes less than half -- exact copies -- hands over to the doubling rounds.)
+    uint32_t pass_depth = pivot_depth;
+    for (int pivot_pass = 0; (pivot_pass == 0 && (full_direct2 || equalise || pivot)) || (pivot_pass > 0 && pivot); ++pivot_pass) {
         // (group_sort.hpp carries the terminator index of a suffix that ends inside a comparison in 16 bits)
         if (text.terms.count > 0x10000u) throw HipError("suffix array: the group-sort rounds take texts of at most 65536 segments");
         const uint32_t max_rounds = pivot ? kGroupSortRounds : equalise ? std::min<uint32_t>(kGroupSortRounds, (depth_compared - (uint32_t)h + 63u) / 64u) : kGroupSortRounds;
         const uint32_t *lcp_mark = (equalise && !pivot) ? lcp : nullptr;
-        const uint32_t depth_cap = (uint32_t)std::min<uint64_t>((uint64_t)h + pivot_depth, 0xfffffff0u);
+        const uint32_t depth_cap = (uint32_t)std::min<uint64_t>((uint64_t)h + pass_depth, 0xfffffff0u);
         const uint32_t *slot = act_slot[a_cur], *grp = act_grp[a_cur];
         const size_t d2_mark = arena.mark();
         uint32_t *out_lo = arena.alloc<uint32_t>(m);
@@ -2493,6 +2498,10 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         arena.rewind(d2_mark);
         if (trace) fprintf(stderr, "[nolzss]   %s: %u of %u finished, %u still tied, on at least %llu symbols\n",
                            pivot ? "pivot rounds" : equalise ? "equalising round (untouched groups only)" : "second direct round", before - m, before, m, (unsigned long long)h);
+        // another pass?  only pivot passes repeat: while they make progress, something is left, and the depth has room
+        static const int pivot_passes = getenv("NOLZSS_PIVOT_PASSES") ? atoi(getenv("NOLZSS_PIVOT_PASSES")) : 3;
+        if (!pivot || m == 0 || h >= n || pivot_pass + 1 >= pivot_passes || (uint64_t)(before - m) * 2 < before) break;
+        pass_depth = pass_depth < (1u << 28) ? pass_depth * 4 : pass_depth;
     }
     // Nothing is tied any more: no round below needs rank[].  A caller that can wait gets it from the permutation
     // that brings the factor-length codes into text order (pipeline.hpp) -- one full random permutation per
