@@ -103,13 +103,23 @@ __global__ __launch_bounds__(kThreads) void presence_kernel(const uint8_t *__res
 // recorded; the count keeps running)
 constexpr uint32_t kMaxTermScan = 512;
 
+// kCountOnly: no positions, and ONE atomic per wavefront at the end.  pack_text asks for the count first: a text over
+// another alphabet that happens to contain A, C, G and T -- a protein -- has 10^8 bytes that are "not a nucleotide", and
+// one returning atomic per such byte on a single counter took 47 ms of the 80 ms of a 2^28-symbol protein text (round 4,
+// tools/alphabet_probe.py); the positions are recorded by a second launch only when there are at most 250 of them.
+template <bool kCountOnly>
 __global__ __launch_bounds__(kThreads) void find_terminators_kernel(const uint8_t *__restrict__ text, uint32_t n,
                                                                     uint32_t *__restrict__ count,
                                                                     uint32_t *__restrict__ pos_out) {
+    uint32_t local = 0;
     auto check = [&](uint8_t c, size_t i) {
         if (c != 'A' && c != 'C' && c != 'G' && c != 'T') {
-            const uint32_t k = atomicAdd(count, 1u);
-            if (k < kMaxTermScan) pos_out[k] = (uint32_t)i;
+            if (kCountOnly) {
+                ++local;
+            } else {
+                const uint32_t k = atomicAdd(count, 1u);
+                if (k < kMaxTermScan) pos_out[k] = (uint32_t)i;
+            }
         }
     };
     // 16 bytes per load from the first 16-byte boundary on; a 32-bit word is tested against the four
@@ -141,6 +151,12 @@ __global__ __launch_bounds__(kThreads) void find_terminators_kernel(const uint8_
     }
     const size_t tail0 = h + vecs * 16;
     if (tail0 + tid < n) check(text[tail0 + tid], tail0 + tid);
+    if (kCountOnly) {
+        // (saturating: the caller only asks whether the count is one of at most 250, and 2^15 wavefronts x 1024 fits 32 bits)
+        local = local < 1024u ? local : 1024u;
+        const uint32_t total = wave_reduce(local, OpAdd<uint32_t>());
+        if (lane_id() == 0 && total) atomicAdd(count, total < 1024u ? total : 1024u);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1923,11 +1939,15 @@ PackedText pack_text(Context &ctx, const uint8_t *d_text, size_t n) {
             HIP_CHECK(hipMemsetAsync(count, 0, sizeof(uint32_t), s));
             size_t g = div_up(n, kThreads);
             if (g > 8192) g = 8192;
-            find_terminators_kernel<<<(unsigned)g, kThreads, 0, s>>>(d_text, (uint32_t)n, count, pos);
+            find_terminators_kernel<true><<<(unsigned)g, kThreads, 0, s>>>(d_text, (uint32_t)n, count, pos);
             KERNEL_CHECK();
             uint32_t h_count = 0;
             ctx.read_back(count, &h_count, 1);
             if (h_count == (uint32_t)others) {  // every non-nucleotide byte value occurs exactly once
+                HIP_CHECK(hipMemsetAsync(count, 0, sizeof(uint32_t), s));
+                find_terminators_kernel<false><<<(unsigned)g, kThreads, 0, s>>>(d_text, (uint32_t)n, count, pos);
+                KERNEL_CHECK();
+                HIP_CHECK(hipStreamSynchronize(s));
                 terminators.resize(h_count);
                 HIP_CHECK(hipMemcpy(terminators.data(), pos, h_count * sizeof(uint32_t), hipMemcpyDeviceToHost));
                 std::sort(terminators.begin(), terminators.end());
@@ -2013,7 +2033,7 @@ bool pack_independent_text(Context &ctx, const uint8_t *d_text, size_t n, const 
     HIP_CHECK(hipMemsetAsync(count, 0, sizeof(uint32_t), s));
     size_t g = div_up(n, kThreads);
     if (g > 8192) g = 8192;
-    find_terminators_kernel<<<(unsigned)g, kThreads, 0, s>>>(d_text, (uint32_t)n, count, pos);
+    find_terminators_kernel<false><<<(unsigned)g, kThreads, 0, s>>>(d_text, (uint32_t)n, count, pos);
     KERNEL_CHECK();
     uint32_t h_count = 0;
     ctx.read_back(count, &h_count, 1);
@@ -2404,7 +2424,9 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     // it was given the next one goes four times as deep over what is left -- 96 genomes 0.1 % apart: 2.65e8 -> 5.9e7 -> 1e6
     // tied suffixes after caps of 2048 and 8192 symbols, where the doubling rounds would take four rounds and the rank scatter
     // in front of them.  A pass that finishes less than half -- exact copies -- hands over to the doubling rounds.)
-    uint32_t pass_depth = pivot_depth;
+    // (the depth is given in symbols of 2-bit DNA; wider symbols get proportionally fewer, so that a member reads the same
+    // number of text words whatever the alphabet: 2048 bases = 512 bytes)
+    uint32_t pass_depth = std::max<uint32_t>(64u, pivot_depth * 2u / (uint32_t)text.bits);
     for (int pivot_pass = 0; (pivot_pass == 0 && (full_direct2 || equalise || pivot)) || (pivot_pass > 0 && pivot); ++pivot_pass) {
         // (group_sort.hpp carries the terminator index of a suffix that ends inside a comparison in 16 bits)
         if (text.terms.count > 0x10000u) throw HipError("suffix array: the group-sort rounds take texts of at most 65536 segments");
