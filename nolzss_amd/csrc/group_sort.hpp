@@ -127,12 +127,6 @@ __device__ __forceinline__ void group_window(const uint64_t *__restrict__ words,
     tt = (tag << 16) | (tag < 2 * kPer ? (term & 0xffffu) : 0u);
 }
 
-// kTiled = false: one workgroup per queue entry (a group of up to NMAX members), grid (kQShards, Y).
-// kTiled = true: one workgroup per tile of NMAX / 2 list positions; it takes the groups of up to NMAX / 2 members
-//   that START in its tile -- all of them at once, as the segments the rounds begin with: sequence data leaves
-//   hundreds of thousands of groups of two to eight members, and a wavefront per group would idle on their
-//   round trips to the text.  List positions are sorted positions: a group's members hold consecutive list
-//   positions (and slots), and sorting only ever moves members inside their group.
 // pivot rounds: the sort key of a member relative to its pivot, one 64-bit word (one LDS read and one comparison per
 // step of the ranking): [side : 2 | l - D, descending above the pivot : 11 | symbol : 9] in the high half, the
 // terminator index + 1 of a suffix that ends at l in the low half (D = depth of the segment, l - D <= kPivotWords
@@ -169,7 +163,13 @@ __device__ __forceinline__ void pivot_fetch(const uint64_t *__restrict__ words, 
     for (uint32_t k = 0; k < 2 * kPivotBatch; ++k) win[k] = o ? __builtin_amdgcn_alignbit(q[k], q[k + 1], 32 - o) : q[k];
 }
 
-
+// kTiled = false: one workgroup per queue entry (a group of up to NMAX members), grid (kQShards, Y).
+// kTiled = true: one workgroup per tile of NMAX / 2 list positions; it takes the groups of up to NMAX / 2 members
+//   that START in its tile -- all of them at once, as the segments the rounds begin with: sequence data leaves
+//   hundreds of thousands of groups of two to eight members, and a wavefront per group would idle on their
+//   round trips to the text.  List positions are sorted positions: a group's members hold consecutive list
+//   positions (and slots), and sorting only ever moves members inside their group.
+// kPivot: pivot rounds instead of window rounds (above); depth_cap: segments that agree that far stay tied.
 template <int BITS, int THREADS, int NMAX, bool kTiled, bool kPivot = false>
 __global__ __launch_bounds__(THREADS) void group_sort_kernel(ShardQueue q, const uint32_t *__restrict__ act_slot,
                                                              const uint32_t *__restrict__ act_grp, uint32_t m,
