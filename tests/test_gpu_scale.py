@@ -250,6 +250,34 @@ def test_pathological_repeats(native, name):
 
 
 @pytest.mark.timeout(900)
+@pytest.mark.parametrize("copies,base_log2", [(24, 21), (96, 19)])
+def test_collection_of_similar_genomes_at_scale(native, copies, base_log2):
+    """24 genomes of 2 Mi bases and 96 of 512 Ki, 0.1 % apart (the reference's use case for collections,
+    /root/reference/src/cpp/fasta_processor.cpp:298-341) at a size where the default thresholds decide the path: the
+    16-base key sort, the first direct round, the pivot PASSES (2048, 8192, 32768 symbols deep: group_sort.hpp, kPivot)
+    and the inverse suffix array delivered by the permutation of the codes -- no environment switch.  Every factor,
+    the suffix array and the LCP array against the oracle."""
+    rng = np.random.default_rng(7000 + copies)
+    base = gen.random_dna(1 << base_log2, 600 + copies)
+    parts = [base]
+    for _ in range(copies - 1):
+        y = base.copy()
+        idx = rng.integers(0, len(y), size=len(y) // 1000)
+        y[idx] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=len(idx))]
+        parts.append(y)
+    t = np.concatenate(parts)
+    got = native.factorize_array(t)
+    exp = oracle.factors_array(t)
+    assert len(got) == len(exp)
+    for k in ("start", "length", "ref"):
+        assert np.array_equal(got[k], exp[k]), k
+    d = native.debug_arrays(t)
+    sa = oracle.suffix_array(t)
+    assert np.array_equal(d["sa"].astype(np.int64), sa.astype(np.int64))
+    assert np.array_equal(d["lcp"][:len(t)].astype(np.int64), oracle.lcp_array(t, sa).astype(np.int64))
+
+
+@pytest.mark.timeout(900)
 def test_rc_long_palindromic_repeat(native):
     """reverse-complement mode with a long exact inverted repeat (LCP in the joint text ~ 1 Mi)"""
     x = gen.random_dna(1 << 20, 73)
