@@ -1583,6 +1583,49 @@ void radix_sort_record_keys(const PackedText &text, const std::vector<uint32_t> 
     arena.rewind(m);  // (cur == 0: the sorted pairs are in keys32[0] / vals[0])
 }
 
+int radix_sort_segments_u32(uint32_t *keys[2], uint32_t *vals[2], size_t n, const std::vector<uint32_t> &h_start, int npasses,
+                            Arena &arena, hipStream_t stream, Profiler *prof) {
+    const uint32_t nb = (uint32_t)h_start.size() - 1;  // segments [h_start[k], h_start[k + 1])
+    if (n == 0 || npasses == 0) return 0;
+    if (nb == 0 || h_start[0] != 0 || h_start[nb] != n) throw HipError("radix_sort_segments_u32: bad segment table");
+    const size_t m = arena.mark();
+    std::vector<uint32_t> tab(4 * ((size_t)nb + 1));
+    uint32_t *t_start = tab.data(), *t_tile0 = t_start + nb + 1, *t_prev = t_tile0 + nb + 1, *t_next = t_prev + nb + 1;
+    for (uint32_t k = 0; k <= nb; ++k) t_start[k] = h_start[k];
+    t_tile0[0] = 0;
+    for (uint32_t k = 0; k < nb; ++k) t_tile0[k + 1] = t_tile0[k] + (uint32_t)div_up((size_t)(t_start[k + 1] - t_start[k]), kTile);
+    uint32_t last = 0xffffffffu;
+    for (uint32_t k = 0; k < nb; ++k) {
+        t_prev[k] = last;
+        if (t_start[k + 1] > t_start[k]) last = k;
+    }
+    last = 0xffffffffu;
+    for (uint32_t k = nb; k-- > 0;) {
+        t_next[k] = last;
+        if (t_start[k + 1] > t_start[k]) last = k;
+    }
+    t_prev[nb] = t_next[nb] = 0;
+    uint32_t *d_tab = arena.alloc<uint32_t>(tab.size());
+    HIP_CHECK(hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));  // tab is a local vector
+    SegView seg;
+    seg.num_tiles = t_tile0[nb];
+    uint32_t *seg_mem = arena.alloc<uint32_t>((size_t)kSegDescWords * seg.num_tiles + 4);
+    seg_desc_kernel<<<(unsigned)div_up(seg.num_tiles, kThreads), kThreads, 0, stream>>>(
+        d_tab, d_tab + (nb + 1), d_tab + 2 * ((size_t)nb + 1), d_tab + 3 * ((size_t)nb + 1), seg.num_tiles, seg_mem, nb);
+    KERNEL_CHECK();
+    seg.desc = seg_mem;
+    uint32_t *hist = arena.alloc<uint32_t>((size_t)kBins * seg.num_tiles);
+    int cur = 0;
+    for (int p = 0; p < npasses; ++p) {
+        radix_pass<uint32_t, uint32_t>(ArraySrc<uint32_t>{keys[cur], vals[cur]}, keys[cur ^ 1], vals[cur ^ 1], n, 8 * p, hist,
+                                       seg.num_tiles, 4.0 * (double)n, 16.0 * (double)n, arena, stream, prof, seg);
+        cur ^= 1;
+    }
+    arena.rewind(m);
+    return cur;
+}
+
 int radix_sort_initial_keys(const PackedText &text, uint64_t *keys[2], uint32_t *vals[2], const int *shifts,
                             int npasses, Arena &arena, hipStream_t stream, Profiler *prof) {
     const size_t n = text.n;

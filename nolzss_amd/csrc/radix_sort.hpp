@@ -118,6 +118,14 @@ void radix_sort_record_keys(const PackedText &text, const std::vector<uint32_t> 
                             uint32_t *vals[2], uint32_t *seg_mem, SegView &seg_out, Arena &arena, hipStream_t stream,
                             Profiler *prof = nullptr);
 
+// (u32 key, u32 value) pairs that lie in SEGMENTS [h_start[k], h_start[k + 1]) (h_start[0] = 0, the last entry = n), each
+// segment sorted for itself by the low 8 * npasses key bits: the segments are the buckets of bucket-segmented passes on
+// 8-byte records -- what the doubling rounds need for the members of their LARGE groups, whose group is known from where
+// they lie (round 4: they used to sort 12-byte records by (group, key), eight passes instead of four).  Returns the
+// index of the buffer pair that holds the result.
+int radix_sort_segments_u32(uint32_t *keys[2], uint32_t *vals[2], size_t n, const std::vector<uint32_t> &h_start, int npasses,
+                            Arena &arena, hipStream_t stream, Profiler *prof = nullptr);
+
 // out[idx[k]] = val[k] for k < count, idx[k] < n_out (entries with idx >= n_out are dropped).
 // A random 4-byte scatter over an array much larger than the caches costs a read-modify-write
 // of a whole line per element at HBM.  For large targets the pairs are therefore first

@@ -1259,11 +1259,19 @@ __global__ __launch_bounds__(kMidThreads) void mid_sort_kernel(const uint32_t *_
     for (uint32_t e = threadIdx.x; e < kMidGroup; e += kMidThreads) s_size[e] = 0;
     if (threadIdx.x == 0) s_taken = 0;
     __syncthreads();
+    // group sizes first: a tile in which no group of the kernel's size class starts has nothing to do and leaves before it
+    // reads a key (a text whose suffixes all sit in a few huge groups -- a Fibonacci word -- ran this kernel for twenty
+    // rounds at 4.8 ms each)
+    bool any = false;
     for (uint32_t e = threadIdx.x; e < span; e += kMidThreads) {
         const uint32_t a = base + e, g = act_grp[a], j = act_slot[a] - g;
-        s_lo[e] = lo[a];
-        if ((a + 1 == m || act_grp[a + 1] != g) && j <= e && e - j < kMidGroup) s_size[e - j] = j + 1;  // the last member
+        if ((a + 1 == m || act_grp[a + 1] != g) && j <= e && e - j < kMidGroup) {  // the last member
+            s_size[e - j] = j + 1;
+            any |= j + 1 > kSmallGroup && j + 1 <= kMidGroup;
+        }
     }
+    if (__syncthreads_or(any) == 0) return;
+    for (uint32_t e = threadIdx.x; e < span; e += kMidThreads) s_lo[e] = lo[base + e];
     __syncthreads();
     uint32_t taken = 0;
     for (uint32_t e = threadIdx.x; e < span; e += kMidThreads) {
@@ -1794,6 +1802,51 @@ __global__ __launch_bounds__(kThreads) void gather_large_kernel(const uint32_t *
             lvals[k] = vals[a];
             lidx[k] = (uint32_t)a;
         }
+}
+
+// The same for the segmented sort of the large groups (radix_sort_segments_u32): 32-bit keys, the group of every
+// gathered element beside them; then the first gathered element of every group (heads -> scan -> starts).
+__global__ __launch_bounds__(kThreads) void gather_large32_kernel(const uint32_t *__restrict__ large_flag,
+                                                                  const uint32_t *__restrict__ idx,
+                                                                  const uint32_t *__restrict__ act_grp,
+                                                                  const uint32_t *__restrict__ lo,
+                                                                  const uint32_t *__restrict__ vals, uint32_t m,
+                                                                  uint32_t *__restrict__ lkeys, uint32_t *__restrict__ lvals,
+                                                                  uint32_t *__restrict__ lidx, uint32_t *__restrict__ lgrp) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x; a < m; a += stride)
+        if (large_flag[a]) {
+            const uint32_t k = idx[a];
+            lkeys[k] = lo[a];
+            lvals[k] = vals[a];
+            lidx[k] = (uint32_t)a;
+            lgrp[k] = act_grp[a];
+        }
+}
+__global__ __launch_bounds__(kThreads) void large_heads_kernel(const uint32_t *__restrict__ lgrp, uint32_t count,
+                                                               uint32_t *__restrict__ head) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < count; k += stride)
+        head[k] = (k == 0 || lgrp[k] != lgrp[k - 1]) ? 1u : 0u;
+}
+__global__ __launch_bounds__(kThreads) void large_starts_kernel(const uint32_t *__restrict__ head,
+                                                                const uint32_t *__restrict__ pos, uint32_t count,
+                                                                uint32_t *__restrict__ starts) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < count; k += stride)
+        if (head[k]) starts[pos[k]] = (uint32_t)k;
+}
+__global__ __launch_bounds__(kThreads) void scatter_large32_kernel(const uint32_t *__restrict__ lkeys,
+                                                                   const uint32_t *__restrict__ lvals,
+                                                                   const uint32_t *__restrict__ lidx, uint32_t count,
+                                                                   uint32_t *__restrict__ out_lo,
+                                                                   uint32_t *__restrict__ out_vals) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < count; k += stride) {
+        const uint32_t a = lidx[k];
+        out_lo[a] = lkeys[k];
+        out_vals[a] = lvals[k];
+    }
 }
 
 // the k-th smallest large element goes to the k-th list position owned by a large group
@@ -2786,7 +2839,46 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
             n_large = h2[0];
             if (mid_groups && h2[1] == 0 && n_large == 0) mid_groups = false;
         }
-        if (n_large > 0) {  // members of groups larger than kSmallGroup: global radix sort
+        // (NOLZSS_NO_SEG_LARGE: A/B switch back to the global sort of 12-byte (group, key) records)
+        static const bool no_seg_large = getenv("NOLZSS_NO_SEG_LARGE") != nullptr;
+        bool large_done = false;
+        if (n_large > 0 && !no_seg_large) {
+            // Members of the large groups: the group of an element is known from where it lies (a group's members are
+            // consecutive in the list, so also in the gathered array), so the groups are the BUCKETS of a segmented
+            // sort by the key alone -- four passes on 8-byte records instead of eight on 12-byte ones.
+            ProfScope ps(ctx.profiler(), "sa_sort_large", s);
+            const size_t lmark = arena.mark();
+            uint32_t *lk[2] = {arena.alloc<uint32_t>(n_large), arena.alloc<uint32_t>(n_large)};
+            uint32_t *lv[2] = {arena.alloc<uint32_t>(n_large), arena.alloc<uint32_t>(n_large)};
+            uint32_t *lgrp = arena.alloc<uint32_t>(n_large);
+            uint32_t *lidx = tmp_c;
+            gather_large32_kernel<<<grid_for(m, kThreads), kThreads, 0, s>>>(tmp_a, tmp_b, grp, lo, rvals, m, lk[0], lv[0], lidx, lgrp);
+            KERNEL_CHECK();
+            // first element of every group -> segment table on the host
+            uint32_t *head = lk[1], *pos = lv[1];  // (free until the first pass)
+            large_heads_kernel<<<grid_for(n_large, kThreads), kThreads, 0, s>>>(lgrp, n_large, head);
+            KERNEL_CHECK();
+            scan_exclusive_add_u32(head, pos, n_large, d_total + 3, arena, s);
+            uint32_t nb = 0;
+            ctx.read_back(d_total + 3, &nb, 1);
+            // (a tile of the segmented passes never straddles a group: groups of a few hundred members would leave the
+            // 4096-pair tiles mostly empty -- those keep the global sort)
+            if ((uint64_t)nb * 2048u <= (uint64_t)n_large) {
+            uint32_t *d_starts = arena.alloc<uint32_t>((size_t)nb + 1);
+            large_starts_kernel<<<grid_for(n_large, kThreads), kThreads, 0, s>>>(head, pos, n_large, d_starts);
+            KERNEL_CHECK();
+            std::vector<uint32_t> h_start((size_t)nb + 1);
+            HIP_CHECK(hipMemcpyAsync(h_start.data(), d_starts, (size_t)nb * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+            h_start[nb] = n_large;
+            const int c = radix_sort_segments_u32(lk, lv, n_large, h_start, half_passes, arena, s, ctx.profiler());
+            scatter_large32_kernel<<<grid_for(n_large, kThreads), kThreads, 0, s>>>(lk[c], lv[c], lidx, n_large, out_lo, out_vals);
+            KERNEL_CHECK();
+            large_done = true;
+            }
+            arena.rewind(lmark);
+        }
+        if (n_large > 0 && !large_done) {  // members of groups larger than kSmallGroup: global radix sort
             ProfScope ps(ctx.profiler(), "sa_sort_large", s);
             const size_t lmark = arena.mark();
             uint64_t *lk[2] = {arena.alloc<uint64_t>(n_large), arena.alloc<uint64_t>(n_large)};
