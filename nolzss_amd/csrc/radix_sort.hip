@@ -25,6 +25,9 @@
 
 #include "scan.hpp"
 
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -364,6 +367,10 @@ __global__ __launch_bounds__(kThreads) void rs_hist_kernel(Src src, size_t n, in
 // gather of 256 lines (+2.7 ms per step), barriers that wait for the LDS only between the two stagings let key and
 // value stores overlap and cost 1 ms, a software-pipelined form with the next tile's loads in flight needs 211 VGPRs
 // (two workgroups per CU: 33.6 instead of 23.4 ms): profiles/r04_ab/scatter_phases_and_variants.txt.)
+// (One returning LDS atomic per key instead of the ballots -- what local_sort_kernel does -- loses here: the u32 passes
+// 5.2 -> 6.2 ms each at 2^30 pairs, three workgroups per CU already hide the ballots' VALU work behind each other's
+// memory phases while the conflicting atomics queue up in the one LDS; only the pass that makes its keys from the text
+// gained, 4.8 -> 4.45 ms.  gpurun_out/r4_satom, profiles/r04_ab/local_sort.txt.)
 template <typename KeyT, typename OutT, typename Src, typename ValT = uint32_t, bool kTimed = false>
 __global__ __launch_bounds__(kThreads, kScatterWavesPerSimd) void rs_scatter_kernel(
     Src src, OutT *__restrict__ keys_out, ValT *__restrict__ vals_out, size_t n, int shift,
@@ -1337,6 +1344,314 @@ __global__ __launch_bounds__(kThreads) void seg_desc_kernel(const uint32_t *__re
     d[8] = next_ne[lo];
     d[9] = d[10] = d[11] = 0;
 }
+
+// the same for segments given by a first and an end element each (the large sub-buckets of local_sort_kernel)
+__global__ __launch_bounds__(kThreads) void seg_desc_list_kernel(const uint32_t *__restrict__ first_of,
+                                                                 const uint32_t *__restrict__ end_of,
+                                                                 const uint32_t *__restrict__ tile0, uint32_t num_tiles,
+                                                                 uint32_t *__restrict__ desc, uint32_t num_segs) {
+    const uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tile >= num_tiles) return;
+    uint32_t lo = 0, hi = num_segs;  // the segment of the tile (segments of the list are never empty)
+    while (lo + 1 < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (tile0[mid] <= tile)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    const uint32_t t0 = tile0[lo], local = tile - t0;
+    const uint32_t first = first_of[lo] + local * (uint32_t)kTile, end = end_of[lo];
+    uint32_t *d = desc + (size_t)tile * kSegDescWords;
+    d[0] = first;
+    d[1] = end - first < (uint32_t)kTile ? end - first : (uint32_t)kTile;
+    d[2] = lo;
+    d[3] = t0 * (uint32_t)kBins + local;
+    d[4] = tile0[lo + 1] - t0;
+    d[5] = first_of[lo];
+    d[6] = end;
+    d[7] = lo ? lo - 1 : 0xffffffffu;
+    d[8] = lo + 1 < num_segs ? lo + 1 : 0xffffffffu;
+    d[9] = d[10] = d[11] = 0;
+}
+
+// The scanned table of a pass over such a list counts from the first segment of the LIST: every entry of segment k
+// is moved by shift[k] = (first element of the segment) - (elements of the list in front of it).
+__global__ __launch_bounds__(kThreads) void seg_table_shift_kernel(uint32_t *__restrict__ table, const uint32_t *__restrict__ tile0,
+                                                                  const uint32_t *__restrict__ shift, uint32_t num_segs) {
+    const uint32_t k = blockIdx.x;
+    const size_t lo = (size_t)tile0[k] * kBins, hi = (size_t)tile0[k + 1] * kBins;
+    const uint32_t sh = shift[k];
+    for (size_t i = lo + threadIdx.x; i < hi; i += kThreads) table[i] += sh;
+}
+
+// the elements of the tiles of a SegView copied from one pair of arrays to another
+__global__ __launch_bounds__(kThreads) void seg_copy_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+                                                            uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
+                                                            SegView seg) {
+    const TileExtent ext = tile_extent(blockIdx.x, 0, seg.num_tiles, seg);
+    for (uint32_t p = threadIdx.x; p < ext.count; p += kThreads) {
+        keys_out[ext.first + p] = keys_in[ext.first + p];
+        vals_out[ext.first + p] = vals_in[ext.first + p];
+    }
+}
+
+// ---- sub-buckets sorted in LDS (round 4) -----------------------------------------------------------------
+// After TWO most-significant-digit passes a text of 2^27 .. 2^30 suffixes lies in 65 536 sub-buckets of a few thousand
+// pairs each: small enough for ONE workgroup to hold in registers and order by the remaining key digits through LDS --
+// read once, written once in full lines -- where every further bucket-segmented pass over HBM costs a histogram
+// (4 B per pair) and a scatter (16 B per pair, in runs of 64 bytes).  One workgroup of kLocalThreads threads per CU
+// takes every gridDim-th sub-bucket, kLocalRows pairs per thread at most; a larger sub-bucket (skewed texts) is put on
+// a list and goes through segmented passes afterwards.  With one workgroup per CU nothing else hides its memory
+// phases: the pairs of the NEXT sub-bucket are loaded while this one is ranked, the stores of the last one drain
+// meanwhile, and the barriers wait for the LDS only.
+//
+// Ranking: rows of 64 pairs in input order, ONE returning LDS atomic per pair on the wave's counter of its digit.
+// That is stable only if the LDS serves the lanes of an instruction that meet at one address in lane order.  gfx950
+// does (every wave checks it on its first row of every pass against the ballot form rs_scatter_kernel uses: the
+// counters start at zero there, so a lane must be handed the number of lanes below it with its digit); if a check ever
+// fails the kernel says so, the sub-buckets are redone by the segmented passes and the path is switched off.  The
+// ballot form costs ~60 VALU instructions per row and made this kernel issue-bound at 7.2 ms per 2^30 pairs.
+#ifndef NOLZSS_LOCAL_THREADS
+#define NOLZSS_LOCAL_THREADS 768
+#endif
+#ifndef NOLZSS_LOCAL_ROWS
+#define NOLZSS_LOCAL_ROWS 25
+#endif
+constexpr int kLocalThreads = NOLZSS_LOCAL_THREADS;
+constexpr int kLocalWaves = kLocalThreads / 64;
+constexpr int kLocalRows = NOLZSS_LOCAL_ROWS;
+constexpr uint32_t kLocalCap = (uint32_t)kLocalThreads * kLocalRows;
+static_assert(kLocalThreads >= kBins && kLocalThreads % 64 == 0, "the first kBins threads own one bin each in the offset phase");
+
+// first element of every sub-bucket (bucket b, digit d) from the scanned table of the pass that made them
+__global__ __launch_bounds__(kBins) void sub_starts_kernel(const uint32_t *__restrict__ scanned, const uint32_t *__restrict__ tile0,
+                                                           const uint32_t *__restrict__ bstart, uint32_t n,
+                                                           uint32_t *__restrict__ sub_start) {
+    const uint32_t b = blockIdx.x, d = threadIdx.x;
+    const uint32_t t0 = tile0[b], nt = tile0[b + 1] - t0;
+    sub_start[b * kBins + d] = nt ? scanned[(size_t)t0 * kBins + (size_t)d * nt] : bstart[b];
+    if (b == 0 && d == 0) sub_start[(size_t)gridDim.x * kBins] = n;
+}
+
+// A barrier that waits for the wave's LDS operations only.  __syncthreads() also waits for every global load and store
+// the wave has in flight -- the prefetched pairs and the draining stores this kernel wants to leave in flight.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// block_scan_exclusive (common.hpp) on lds_barrier(); w / lane: the caller's wave number and lane
+template <int NW>
+__device__ __forceinline__ uint32_t block_scan_exclusive_add_lds(uint32_t v, uint32_t *lds, int w, int lane) {
+    const uint32_t inc = wave_scan_inclusive_dpp(v, 0u, OpAdd<uint32_t>());
+    if (lane == 63) lds[w] = inc;
+    lds_barrier();
+    uint32_t prefix = 0;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        const uint32_t t = lds[k];
+        if (k < w) prefix += t;
+    }
+    lds_barrier();
+    return prefix + inc - v;
+}
+
+// the next sub-bucket of this workgroup that fits it (empty ones skipped, larger ones put on the list); count = 0: none left
+__device__ __forceinline__ void local_next(const uint32_t *__restrict__ sub_start, uint32_t num_sub, uint32_t &sub, uint32_t &first,
+                                           uint32_t &count, uint32_t *__restrict__ ctl, uint32_t *__restrict__ large_list, int tid) {
+    count = 0;
+    first = 0;
+    while (sub < num_sub) {
+        const uint32_t a = sub_start[sub], c = sub_start[sub + 1] - a;
+        const uint32_t this_sub = sub;
+        sub += gridDim.x;
+        if (c == 0) continue;
+        if (c > kLocalCap) {
+            if (tid == 0) large_list[atomicAdd(&ctl[1], 1u)] = this_sub;
+            continue;
+        }
+        first = a;
+        count = c;
+        return;
+    }
+}
+
+// one array of a sub-bucket's pairs into registers: a wave's stretch is rows * 64 pairs, row r of it the 64 pairs from
+// r * 64.  (the places behind the end load the first pair again; their keys are set to all ones when they are ranked)
+__device__ __forceinline__ void local_load(const uint32_t *__restrict__ in, uint32_t first, uint32_t count, int rows,
+                                           uint32_t (&reg)[kLocalRows], int tid) {
+    const uint32_t wbase = (uint32_t)(tid >> 6) * (uint32_t)(rows * 64) + (uint32_t)(tid & 63);
+#pragma unroll
+    for (int r = 0; r < kLocalRows; ++r)
+        if (r < rows) {
+            const uint32_t local = wbase + (uint32_t)r * 64u;
+            reg[r] = in[first + (local < count ? local : 0u)];
+        }
+}
+
+// elements [lo, hi) of the staging buffer to the same elements of out (out 16-byte aligned): whole quads with one store
+__device__ __forceinline__ void local_store(const uint32_t *s_stage, uint32_t *__restrict__ out, uint32_t lo, uint32_t hi, int tid) {
+    constexpr int kQuadIters = (int)((kLocalCap / 4 + 1 + kLocalThreads - 1) / kLocalThreads);
+#pragma unroll
+    for (int j = 0; j < kQuadIters; ++j) {
+        const uint32_t i0 = 4u * ((uint32_t)j * kLocalThreads + (uint32_t)tid);
+        if (i0 >= lo && i0 + 4u <= hi) {
+            *reinterpret_cast<uint4 *>(out + i0) = *reinterpret_cast<const uint4 *>(s_stage + i0);
+        } else if (i0 < hi && i0 + 4u > lo) {
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k)
+                if (i0 + k >= lo && i0 + k < hi) out[i0 + k] = s_stage[i0 + k];
+        }
+    }
+}
+
+template <int NPASS>
+__global__ __launch_bounds__(kLocalThreads) void local_sort_kernel(
+    const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint32_t *__restrict__ keys_out,
+    uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ sub_start, uint32_t num_sub, int shift0,
+    uint32_t *__restrict__ ctl /* [1] sub-buckets on the list, [2] a lane-order check failed */, uint32_t *__restrict__ large_list,
+    unsigned long long *__restrict__ phases) {
+#ifdef NOLZSS_LOCAL_TIMED
+    unsigned long long ck_last = __builtin_readcyclecounter();
+#define LOCAL_CK(slot)                                               \
+    if (tid == 0) {                                                  \
+        const unsigned long long now = __builtin_readcyclecounter(); \
+        atomicAdd(phases + (slot), now - ck_last);                   \
+        ck_last = now;                                               \
+    }
+#else
+#define LOCAL_CK(slot)
+#endif
+    __shared__ __align__(16) uint32_t s_stage[kLocalCap + 4];  // keys, then values, take turns
+    __shared__ __align__(16) uint32_t s_whist[kLocalWaves * kBins];
+    __shared__ uint32_t s_scan[kLocalWaves];
+    const int tid = threadIdx.x;
+    const int w = tid >> 6;
+    const int lane = tid & 63;
+    uint32_t *wcount = s_whist + w * kBins;  // this wave's counters: zeroed by the wave itself after every use
+    reinterpret_cast<uint4 *>(wcount)[lane] = make_uint4(0, 0, 0, 0);
+    static_assert(kBins == 256, "four counters per lane");
+
+    uint32_t sub = blockIdx.x, first, count;
+    local_next(sub_start, num_sub, sub, first, count, ctl, large_list, tid);
+    uint32_t key[kLocalRows];
+    if (count) local_load(keys_in, first, count, (int)((count + kLocalThreads - 1) / kLocalThreads), key, tid);
+    bool order_ok = true;
+    while (count) {  // (uniform)
+        // this sub-bucket's values (wanted when its keys have been ranked once) and the NEXT one's keys are asked for
+        // before anything else (the values of the next one, too, took the registers over the edge: a prefetched value
+        // that is spilled is a value waited for)
+        const int rows = (int)((count + kLocalThreads - 1) / kLocalThreads);
+        uint32_t val[kLocalRows];
+        local_load(vals_in, first, count, rows, val, tid);
+        uint32_t nfirst, ncount;
+        local_next(sub_start, num_sub, sub, nfirst, ncount, ctl, large_list, tid);
+        uint32_t nkey[kLocalRows];
+        LOCAL_CK(0)  // values asked for, the next sub-bucket found
+        if (ncount) local_load(keys_in, nfirst, ncount, (int)((ncount + kLocalThreads - 1) / kLocalThreads), nkey, tid);
+        LOCAL_CK(1)  // its keys asked for
+
+        const uint32_t wbase = (uint32_t)w * (uint32_t)(rows * 64) + (uint32_t)lane;
+        // the sorted pairs lie in the staging buffer from element `skew` = first & 3 on: a 16-byte quad of the buffer is a
+        // 16-byte quad of the output, and a thread stores four pairs with one instruction (50 single stores per thread and
+        // sub-bucket filled the queue of the memory pipeline that the loads behind them wait in)
+        const uint32_t skew = first & 3u;
+        uint32_t *stage = s_stage + skew;
+        uint32_t lrank[kLocalRows];
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const int shift = shift0 + pass * kRadixBits;
+            // (keys of all ones behind the end of the sub-bucket: last in input order and in the last bin of every digit,
+            // they stay behind its pairs through every stable pass -- no masks)
+            if (pass == 0) {
+#pragma unroll
+                for (int r = 0; r < kLocalRows; ++r)
+                    if (r < rows && wbase + (uint32_t)r * 64u >= count) key[r] = 0xffffffffu;
+            }
+#pragma unroll
+            for (int r = 0; r < kLocalRows; ++r)
+                if (r < rows) lrank[r] = atomicAdd(&wcount[digit_of(key[r], shift)], 1u);
+            {  // the lane-order check on row 0 (its counters started at zero)
+                const uint32_t d = digit_of(key[0], shift);
+                uint32_t diff_lo = 0, diff_hi = 0;
+#pragma unroll
+                for (int b = 0; b < kRadixBits; ++b) {
+                    const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)d, (unsigned)b, 1u);
+                    const uint64_t bal = __ballot((int)m < 0);
+                    diff_lo = __builtin_amdgcn_bitop3_b32(m, diff_lo, (uint32_t)bal, 0xde);
+                    diff_hi = __builtin_amdgcn_bitop3_b32(m, diff_hi, (uint32_t)(bal >> 32), 0xde);
+                }
+                const uint64_t below = ~(((uint64_t)diff_hi << 32) | diff_lo) & ((1ull << lane) - 1ull);
+                order_ok = order_ok && lrank[0] == (uint32_t)__popcll(below);
+            }
+            LOCAL_CK(2 + 8 * pass)  // ranked (wave 0)
+            lds_barrier();
+            LOCAL_CK(3 + 8 * pass)  // ... everybody
+            {  // thread = bin (the first kBins threads): per-wave counts -> start positions in the sub-bucket
+                const int d = tid & (kBins - 1);
+                const bool owner = tid < kBins;
+                uint32_t c[kLocalWaves], total = 0;
+#pragma unroll
+                for (int k = 0; k < kLocalWaves; ++k) {
+                    c[k] = owner ? s_whist[k * kBins + d] : 0u;
+                    total += c[k];
+                }
+                const uint32_t bin_start = block_scan_exclusive_add_lds<kLocalWaves>(total, s_scan, w, lane);
+                if (owner) {
+                    uint32_t run = bin_start;
+#pragma unroll
+                    for (int k = 0; k < kLocalWaves; ++k) {
+                        s_whist[k * kBins + d] = run;
+                        run += c[k];
+                    }
+                }
+            }
+            lds_barrier();
+            LOCAL_CK(4 + 8 * pass)  // offsets
+#pragma unroll
+            for (int r = 0; r < kLocalRows; ++r)
+                if (r < rows) lrank[r] += wcount[digit_of(key[r], shift)];
+            reinterpret_cast<uint4 *>(wcount)[lane] = make_uint4(0, 0, 0, 0);  // (after the wave's own reads, before its next atomics)
+            // keys through the staging buffer: back into the registers in the new order, or out; then the values
+#pragma unroll
+            for (int r = 0; r < kLocalRows; ++r)
+                if (r < rows) stage[lrank[r]] = key[r];
+            lds_barrier();
+            LOCAL_CK(5 + 8 * pass)  // keys staged
+            if (pass + 1 < NPASS) {
+#pragma unroll
+                for (int r = 0; r < kLocalRows; ++r)
+                    if (r < rows) key[r] = stage[wbase + (uint32_t)r * 64u];
+            } else {
+                local_store(s_stage, keys_out + (first - skew), skew, skew + count, tid);
+            }
+            lds_barrier();
+            LOCAL_CK(6 + 8 * pass)  // keys back / out
+#pragma unroll
+            for (int r = 0; r < kLocalRows; ++r)
+                if (r < rows) stage[lrank[r]] = val[r];
+            lds_barrier();
+            LOCAL_CK(7 + 8 * pass)  // values staged
+            if (pass + 1 < NPASS) {
+#pragma unroll
+                for (int r = 0; r < kLocalRows; ++r)
+                    if (r < rows) val[r] = stage[wbase + (uint32_t)r * 64u];
+            } else {
+                local_store(s_stage, vals_out + (first - skew), skew, skew + count, tid);
+            }
+            lds_barrier();  // (the staging buffer is free again)
+            LOCAL_CK(8 + 8 * pass)  // values back / out
+        }
+#pragma unroll
+        for (int r = 0; r < kLocalRows; ++r) key[r] = nkey[r];
+        first = nfirst;
+        count = ncount;
+        LOCAL_CK(30)  // registers handed over
+#ifdef NOLZSS_LOCAL_TIMED
+        if (tid == 0) atomicAdd(phases + 31, 1ull);
+#endif
+    }
+#undef LOCAL_CK
+    if (!order_ok) atomicOr(&ctl[2], 1u);
+}
 }  // namespace
 
 void radix_sort_dna_keys(const PackedText &text, uint32_t *keys32[2], uint32_t *vals[2], uint32_t *seg_mem,
@@ -1390,6 +1705,128 @@ void radix_sort_dna_keys(const PackedText &text, uint32_t *keys32[2], uint32_t *
     arena.rewind(m);  // (cur == 1 again)
 }
 
+namespace {
+std::atomic<bool> local_sort_off{false};  // a lane-order check of local_sort_kernel failed on this machine
+
+// The buckets of a bucketed view (first elements bstart[0 .. num_buckets], first tiles tile0[]) have just been partitioned
+// by one more digit (scanned = the scanned table of that pass, its result in keys_in / vals_in): every sub-bucket is sorted
+// by npass further digits from shift0 up, into keys_out / vals_out.  local_sort_kernel does it in LDS; sub-buckets beyond
+// a workgroup's capacity go through segmented passes.  keys_in / vals_in are scratch afterwards.
+void local_sort_sub_buckets(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out, const uint32_t *scanned,
+                            const uint32_t *tile0, const uint32_t *bstart, uint32_t num_buckets, int shift0, int npass, size_t n,
+                            Arena &arena, hipStream_t stream, Profiler *prof) {
+    const uint32_t num_sub = num_buckets * (uint32_t)kBins;
+    uint32_t *sub_start = arena.alloc<uint32_t>((size_t)num_sub + 1);
+    uint32_t *large_list = arena.alloc<uint32_t>(num_sub);
+    uint32_t *ctl = arena.alloc<uint32_t>(4);
+    sub_starts_kernel<<<num_buckets, kBins, 0, stream>>>(scanned, tile0, bstart, (uint32_t)n, sub_start);
+    KERNEL_CHECK();
+    HIP_CHECK(hipMemsetAsync(ctl, 0, 4 * sizeof(uint32_t), stream));
+    int dev = 0, cus = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const unsigned grid = (unsigned)std::min<uint32_t>(num_sub, (uint32_t)(cus > 0 ? cus : 256));
+    unsigned long long *d_ph = nullptr;
+#ifdef NOLZSS_LOCAL_TIMED
+    d_ph = arena.alloc<unsigned long long>(32);
+    HIP_CHECK(hipMemsetAsync(d_ph, 0, 32 * sizeof(unsigned long long), stream));
+#endif
+    {
+        ProfScope ps(prof, "rs_local_sort", stream, 16.0 * (double)n);
+        if (npass == 2)
+            local_sort_kernel<2><<<grid, kLocalThreads, 0, stream>>>(keys_in, vals_in, keys_out, vals_out, sub_start, num_sub, shift0, ctl,
+                                                                     large_list, d_ph);
+        else if (npass == 3)
+            local_sort_kernel<3><<<grid, kLocalThreads, 0, stream>>>(keys_in, vals_in, keys_out, vals_out, sub_start, num_sub, shift0, ctl,
+                                                                     large_list, d_ph);
+        else
+            throw HipError("local_sort_sub_buckets: two or three digits");
+        KERNEL_CHECK();
+    }
+#ifdef NOLZSS_LOCAL_TIMED
+    {
+        unsigned long long h[32];
+        HIP_CHECK(hipMemcpyAsync(h, d_ph, sizeof(h), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        const double wn = h[31] ? (double)h[31] : 1.0;
+        fprintf(stderr, "[nolzss] local_sort phases (cycles per sub-bucket, %llu sub-buckets): next found %.0f its loads issued %.0f |", h[31], h[0] / wn, h[1] / wn);
+        for (int p = 0; p < npass; ++p)
+            fprintf(stderr, " pass %d: rank(wave 0) %.0f rank(all) %.0f offsets %.0f stage keys %.0f keys back/out %.0f stage values %.0f values back/out %.0f |",
+                    p, h[2 + 8 * p] / wn, h[3 + 8 * p] / wn, h[4 + 8 * p] / wn, h[5 + 8 * p] / wn, h[6 + 8 * p] / wn,
+                    h[7 + 8 * p] / wn, h[8 + 8 * p] / wn);
+        fprintf(stderr, " hand-over %.0f\n", h[30] / wn);
+    }
+#endif
+    uint32_t h_ctl[4];
+    HIP_CHECK(hipMemcpyAsync(h_ctl, ctl, sizeof(h_ctl), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    static const bool fail_order = getenv("NOLZSS_TEST_LOCAL_ORDER_FAILS") != nullptr;  // (test hook: the redo path)
+    const bool redo_all = h_ctl[2] != 0 || fail_order;
+    if (h_ctl[2]) {
+        // the lane-order check failed somewhere: nothing the kernel wrote is trusted, and it is not asked again
+        local_sort_off.store(true);
+        fprintf(stderr, "[nolzss] local_sort_kernel: LDS atomics not served in lane order on this device; sorted by segmented passes instead\n");
+    }
+    const uint32_t nl = redo_all ? num_sub : h_ctl[1];
+    if (nl == 0) return;
+    // sub-buckets beyond a workgroup's capacity (skewed texts): segmented passes over them alone, in -> out -> in ..,
+    // and (an even number of passes) their pairs copied to where the others already are
+    std::vector<uint32_t> h_list(nl), h_sub((size_t)num_sub + 1);
+    if (!redo_all) HIP_CHECK(hipMemcpyAsync(h_list.data(), large_list, sizeof(uint32_t) * nl, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipMemcpyAsync(h_sub.data(), sub_start, sizeof(uint32_t) * h_sub.size(), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    if (redo_all) {
+        h_list.clear();
+        for (uint32_t k = 0; k < num_sub; ++k)
+            if (h_sub[k + 1] > h_sub[k]) h_list.push_back(k);
+    }
+    std::sort(h_list.begin(), h_list.end());
+    const uint32_t ns = (uint32_t)h_list.size();
+    if (ns == 0) return;
+    // first element, end, distance to its place among the segments of the list, first tile of every segment (+ the tile count)
+    std::vector<uint32_t> h_seg(4 * (size_t)ns + 1);
+    uint32_t *h_first = h_seg.data(), *h_end = h_first + ns, *h_shift = h_end + ns, *h_t0 = h_shift + ns;
+    h_t0[0] = 0;
+    uint32_t in_front = 0;
+    for (uint32_t k = 0; k < ns; ++k) {
+        h_first[k] = h_sub[h_list[k]];
+        h_end[k] = h_sub[h_list[k] + 1];
+        h_shift[k] = h_first[k] - in_front;
+        in_front += h_end[k] - h_first[k];
+        h_t0[k + 1] = h_t0[k] + (uint32_t)div_up((size_t)(h_end[k] - h_first[k]), kTile);
+    }
+    uint32_t *d_seg = arena.alloc<uint32_t>(h_seg.size());
+    HIP_CHECK(hipMemcpyAsync(d_seg, h_seg.data(), sizeof(uint32_t) * h_seg.size(), hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));  // h_seg is a local vector
+    SegView big;
+    big.num_tiles = h_t0[ns];
+    uint32_t *big_mem = arena.alloc<uint32_t>((size_t)kSegDescWords * big.num_tiles + 4);
+    const uint32_t *d_t0 = d_seg + 3 * (size_t)ns;
+    seg_desc_list_kernel<<<(unsigned)div_up(big.num_tiles, kThreads), kThreads, 0, stream>>>(d_seg, d_seg + ns, d_t0, big.num_tiles, big_mem, ns);
+    KERNEL_CHECK();
+    big.desc = big_mem;
+    uint32_t *big_hist = arena.alloc<uint32_t>((size_t)kBins * big.num_tiles);
+    uint32_t *kbuf[2] = {keys_in, keys_out}, *vbuf[2] = {vals_in, vals_out};
+    for (int p = 0; p < npass; ++p) {
+        const ArraySrc<uint32_t> src{kbuf[p & 1], vbuf[p & 1]};
+        const int shift = shift0 + 8 * p;
+        rs_hist_kernel<uint32_t, ArraySrc<uint32_t>><<<xcd_grid(big.num_tiles), kThreads, 0, stream>>>(src, n, shift, big_hist, big.num_tiles, big);
+        KERNEL_CHECK();
+        scan_exclusive_add_u32(big_hist, big_hist, (size_t)kBins * big.num_tiles, nullptr, arena, stream);
+        seg_table_shift_kernel<<<ns, kThreads, 0, stream>>>(big_hist, d_t0, d_seg + 2 * (size_t)ns, ns);
+        KERNEL_CHECK();
+        rs_scatter_kernel<uint32_t, uint32_t, ArraySrc<uint32_t>, uint32_t><<<xcd_grid(big.num_tiles), kThreads, 0, stream>>>(
+            src, kbuf[(p & 1) ^ 1], vbuf[(p & 1) ^ 1], n, shift, big_hist, big.num_tiles, big);
+        KERNEL_CHECK();
+    }
+    if ((npass & 1) == 0) {
+        seg_copy_kernel<<<big.num_tiles, kThreads, 0, stream>>>(keys_in, vals_in, keys_out, vals_out, big);
+        KERNEL_CHECK();
+    }
+}
+}  // namespace
+
+
 bool key16_applicable(const PackedText &text) {
     if (text.bits != 2 || text.terms.seq_shift != 0) return false;
     if (!text.segmented) return text.terms.count == 1 && text.n >= 32;
@@ -1433,12 +1870,19 @@ void radix_sort_dna_keys16(const PackedText &text, uint32_t *keys32[2], uint32_t
     uint32_t *tabs = arena.alloc<uint32_t>(4 * 257);
     uint32_t *bstart = tabs, *tile0 = tabs + 257, *prev_ne = tabs + 2 * 257, *next_ne = tabs + 3 * 257;
     const double text_bytes = (double)n * 2 / 8.0;
+    // Two ways from here (both end in keys32[0] / vals[0]): three bucket-segmented passes, or ONE and the sub-buckets it
+    // makes sorted in LDS (local_sort_kernel) -- for texts whose 65 536 sub-buckets are large enough to pay for a
+    // workgroup each and small enough to fit one (NOLZSS_NO_LOCAL_SORT, NOLZSS_LOCAL_SORT_MIN = smallest such text).
+    static const bool no_local = getenv("NOLZSS_NO_LOCAL_SORT") != nullptr;
+    static const size_t local_min = getenv("NOLZSS_LOCAL_SORT_MIN") ? (size_t)atoll(getenv("NOLZSS_LOCAL_SORT_MIN")) : (size_t(1) << 28);
+    const bool local = !no_local && !local_sort_off.load() && n >= local_min && n <= (size_t)kBins * kBins * kLocalCap / 8 * 7;
+    const int msd_to = local ? 0 : 1;
     // most significant digit first: the first four bases (bits 32..39 of [32 key bits][8-bit tag])
     if (text.segmented)
-        radix_pass<uint64_t, uint32_t>(make_text16_seg(text), keys32[1], vals[1], n, 32, hist, tiles0, text_bytes,
+        radix_pass<uint64_t, uint32_t>(make_text16_seg(text), keys32[msd_to], vals[msd_to], n, 32, hist, tiles0, text_bytes,
                                        text_bytes + 8.0 * (double)n, arena, stream, prof);
     else
-        radix_pass<uint64_t, uint32_t>(Text16Src{text.words, (uint32_t)n}, keys32[1], vals[1], n, 32, hist, tiles0, text_bytes,
+        radix_pass<uint64_t, uint32_t>(Text16Src{text.words, (uint32_t)n}, keys32[msd_to], vals[msd_to], n, 32, hist, tiles0, text_bytes,
                                        text_bytes + 8.0 * (double)n, arena, stream, prof);
     bucket_starts_kernel<<<1, kBins, 0, stream>>>(hist, tiles0, (uint32_t)n, bstart);
     KERNEL_CHECK();
@@ -1466,6 +1910,14 @@ void radix_sort_dna_keys16(const PackedText &text, uint32_t *keys32[2], uint32_t
                                                                                        seg_out.num_tiles, seg_mem, (uint32_t)kBins);
     KERNEL_CHECK();
     seg_out.desc = seg_mem;
+    if (local) {
+        // the digit below the bucket's (four more bases) first, then every sub-bucket by the 16 bits between it and the tag
+        radix_pass<uint32_t, uint32_t>(ArraySrc<uint32_t>{keys32[0], vals[0]}, keys32[1], vals[1], n, kP16TagBits + 16, hist,
+                                       seg_out.num_tiles, 4.0 * (double)n, 16.0 * (double)n, arena, stream, prof, seg_out);
+        local_sort_sub_buckets(keys32[1], vals[1], keys32[0], vals[0], hist, tile0, bstart, (uint32_t)kBins, kP16TagBits, 2, n, arena, stream, prof);
+        arena.rewind(m);
+        return;
+    }
     // every bucket by the 24 key bits above the tag byte, least significant digit first: THREE passes
     int cur = 1;
     for (int p = 0; p < 3; ++p) {
@@ -1570,6 +2022,18 @@ void radix_sort_record_keys(const PackedText &text, const std::vector<uint32_t> 
     seg_out.desc = seg_mem;
     uint32_t *hist = arena.alloc<uint32_t>((size_t)kBins * seg_out.num_tiles);
     const double text_bytes = (double)n * 2 / 8.0;
+    // Long records (a megabase and more on average): the pass from the text takes the MOST significant digit, and the
+    // 256 sub-buckets it makes of every record -- 16 Ki pairs of a 4-megabase record -- are sorted by the other three in
+    // LDS (local_sort_kernel): one pass over HBM and one read + write instead of four passes.
+    static const bool no_local = getenv("NOLZSS_NO_LOCAL_SORT") != nullptr;
+    static const size_t local_min = getenv("NOLZSS_LOCAL_SORT_MIN") ? (size_t)atoll(getenv("NOLZSS_LOCAL_SORT_MIN")) : (size_t(1) << 20);
+    if (!no_local && !local_sort_off.load() && n / nb >= local_min) {
+        radix_pass<uint32_t, uint32_t>(RecordTextSrc{text.words, text.terms.pos}, keys32[1], vals[1], n, 24, hist,
+                                       seg_out.num_tiles, text_bytes, text_bytes + 8.0 * (double)n, arena, stream, prof, seg_out);
+        local_sort_sub_buckets(keys32[1], vals[1], keys32[0], vals[0], hist, d_tab + (nb + 1), d_tab, nb, 0, 3, n, arena, stream, prof);
+        arena.rewind(m);
+        return;
+    }
     // least significant digit first inside every record; the first pass makes its pairs from the text
     radix_pass<uint32_t, uint32_t>(RecordTextSrc{text.words, text.terms.pos}, keys32[1], vals[1], n, 0, hist,
                                    seg_out.num_tiles, text_bytes, text_bytes + 8.0 * (double)n, arena, stream, prof, seg_out);

@@ -341,13 +341,19 @@ def test_several_runs_in_flight(native):
         assert _same(arc[j], _rc_expected(recs[j])), j
 
 
-def test_record_bucket_sort_on_small_records():
+@pytest.mark.parametrize("extra_env", [{}, {"NOLZSS_LOCAL_SORT_MIN": "1"},
+                                       {"NOLZSS_LOCAL_SORT_MIN": "1", "NOLZSS_TEST_LOCAL_ORDER_FAILS": "1"}],
+                         ids=["segmented-passes", "sub-buckets-in-lds", "sub-buckets-redone"])
+def test_record_bucket_sort_on_small_records(extra_env):
     """Runs of LONG records (on average >= 2^16 bases) sort with the records as the buckets of the segmented
     key sort (radix_sort.hip, radix_sort_record_keys; key = 14 bases + length tag).  One child process with
     NOLZSS_REC_BUCKET_MIN=1 and NOLZSS_DNA_FAST_MIN=1 sends small runs through it: records shorter than a tile
     and shorter than the key, records that end inside the key window, copies of each other, one-base records,
     record counts around 256; host-buffer batch (every factor against the oracle) and the device-resident
-    batch (counts, with and without records built in device memory)."""
+    batch (counts, with and without records built in device memory).  NOLZSS_LOCAL_SORT_MIN=1: the form for
+    records of a megabase and more (most significant digit from the text, the 256 sub-buckets of every record
+    sorted in LDS by local_sort_kernel; a record of 30 000 A's overflows a workgroup and takes the segmented
+    passes); NOLZSS_TEST_LOCAL_ORDER_FAILS: every sub-bucket redone by those passes."""
     import subprocess
     import sys
     code = r'''
@@ -370,6 +376,7 @@ sets.append([base, base.copy(), base[:3000].copy(), base[100:].copy(), np.frombu
              np.frombuffer(b"ACGT" * 1100, dtype=np.uint8), np.frombuffer(b"ACGTTGCATTGACC", dtype=np.uint8),
              np.frombuffer(b"ACGTTGCATTGAC", dtype=np.uint8), np.frombuffer(b"ACGTTGCATTGACCA", dtype=np.uint8)]
             + [np.frombuffer(c, dtype=np.uint8) for c in (b"A", b"C", b"G", b"T", b"AA", b"T" * 29)])
+sets.append([np.frombuffer(b"A" * 30000, dtype=np.uint8), gen.repeat_dna(40000, seed=6), np.frombuffer(b"AC" * 25000, dtype=np.uint8)])
 total = 0
 for recs in sets:
     m0, s0 = native.debug_batch_counters()
@@ -392,7 +399,7 @@ for recs in sets:
     total += len(recs)
 print("ok", total)
 '''
-    env = dict(os.environ, NOLZSS_DNA_FAST_MIN="1", NOLZSS_REC_BUCKET_MIN="1", NOLZSS_TEST_INJECT_PENDING="1")
+    env = dict(os.environ, NOLZSS_DNA_FAST_MIN="1", NOLZSS_REC_BUCKET_MIN="1", NOLZSS_TEST_INJECT_PENDING="1", **extra_env)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr

@@ -146,10 +146,17 @@ def test_sizes_around_tile_boundaries(native, n):
     assert native.factorize(t) == oracle.factorize(t)
 
 
-def test_bucketed_key_sort_on_small_texts():
+@pytest.mark.parametrize("extra_env", [{}, {"NOLZSS_LOCAL_SORT_MIN": "1"},
+                                       {"NOLZSS_LOCAL_SORT_MIN": "1", "NOLZSS_TEST_LOCAL_ORDER_FAILS": "1"}],
+                         ids=["segmented-passes", "sub-buckets-in-lds", "sub-buckets-redone"])
+def test_bucketed_key_sort_on_small_texts(extra_env):
     """The bucketed (most-significant-digit first) key sort normally starts at 2^20 bases; one child
     process with NOLZSS_DNA_FAST_MIN=1 runs it on small DNA cases: empty buckets, buckets smaller
-    than a tile, suffixes near the end of the text."""
+    than a tile, suffixes near the end of the text.  NOLZSS_LOCAL_SORT_MIN=1 sends the same cases through
+    the form for 2^28 bases and more -- two most-significant-digit passes, the 65 536 sub-buckets sorted
+    in LDS (local_sort_kernel) --, with sub-buckets beyond a workgroup's capacity (a run of 30 000 A's, a
+    period-4 text) on the list for the segmented passes; NOLZSS_TEST_LOCAL_ORDER_FAILS pretends the
+    kernel's lane-order check failed, so every sub-bucket is redone by those passes."""
     import os
     import subprocess
     import sys
@@ -162,7 +169,8 @@ from nolzss_amd import _noLZSS as native
 sizes = [1, 2, 3, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 4095, 4096, 4097, 8191, 8192, 8193, 65535, 65536, 65537]
 cases = [gen.repeat_dna(m, 40 + m % 7, lo=8, hi=512).tobytes() for m in sizes] + [b"ACGT", b"A" * 5000, (b"ACGTTGA" * 2000)[:13001], gen.random_dna(100, 1).tobytes(),
          gen.random_dna(70_000, 3).tobytes(), gen.repeat_dna(300_000, 5, lo=16, hi=4096).tobytes(),
-         b"AC" * 40000 + b"G", gen.random_dna(3000, 12).tobytes() * 64, b"T" * 4097 + gen.random_dna(5000, 9).tobytes()]
+         b"AC" * 40000 + b"G", gen.random_dna(3000, 12).tobytes() * 64, b"T" * 4097 + gen.random_dna(5000, 9).tobytes(),
+         b"A" * 30000 + gen.random_dna(20000, 4).tobytes(), b"ACGT" * 25000 + b"T"]
 for t in cases:
     got = native.factorize_array(t)
     exp = oracle.factors_array(t)
@@ -188,7 +196,7 @@ print("ok", len(cases))
 '''
     # (NOLZSS_TEST_INJECT_PENDING: one LCP entry per text is left "pending" on purpose, so the safety
     # net that compares those suffixes in the packed text runs as well)
-    env = dict(os.environ, NOLZSS_DNA_FAST_MIN="1", NOLZSS_TEST_INJECT_PENDING="1")
+    env = dict(os.environ, NOLZSS_DNA_FAST_MIN="1", NOLZSS_TEST_INJECT_PENDING="1", **extra_env)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
