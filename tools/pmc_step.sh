@@ -33,6 +33,8 @@ def short(name):
     name = re.sub(r"unsigned int", "u32", name)
     name = re.sub(r"unsigned long", "u64", name)
     name = re.sub(r"unsigned short", "u16", name)
+    if name.startswith("rs_scatter_kernel<"):
+        name = re.sub(r", false>", ">", name)  # (its kTimed parameter)
     return re.sub(r"\(.*", "", name).strip()
 
 

@@ -38,7 +38,7 @@ def main():
         rep_stats = native.profile_report()
         print(f"rep {rep}: z={z} wall={dt*1e3:.1f} ms  {n/dt/1e6:.1f} Mbases/s", flush=True)
     tot = 0.0
-    nested = {"rs_hist", "rs_scan", "bucket_scatter", "window_scatter"}
+    nested = {"rs_hist", "rs_scan", "bucket_scatter", "window_scatter", "rs_local_sort"}
     for name, (cnt, ms, nbytes) in sorted(rep_stats.items(), key=lambda kv: -kv[1][1]):
         extra = f"  {nbytes/ms/1e6:8.1f} GB/s" if nbytes else ""
         print(f"  {name:18s} x{cnt:4d} {ms:10.3f} ms{extra}")
