@@ -1475,32 +1475,35 @@ __device__ __forceinline__ void local_next(const uint32_t *__restrict__ sub_star
 }
 
 // one array of a sub-bucket's pairs into registers: a wave's stretch is rows * 64 pairs, row r of it the 64 pairs from
-// r * 64.  (the places behind the end load the first pair again; their keys are set to all ones when they are ranked)
+// r * 64.  ALL kLocalRows loads are issued whatever `rows` is (the places behind the end load the first pair again; their
+// keys are set to all ones when they are ranked): a load inside a branch leaves the compiler unable to count what is in
+// flight, and every wait for memory became a wait for everything -- the stores of the last sub-bucket included.
 __device__ __forceinline__ void local_load(const uint32_t *__restrict__ in, uint32_t first, uint32_t count, int rows,
                                            uint32_t (&reg)[kLocalRows], int tid) {
     const uint32_t wbase = (uint32_t)(tid >> 6) * (uint32_t)(rows * 64) + (uint32_t)(tid & 63);
 #pragma unroll
-    for (int r = 0; r < kLocalRows; ++r)
-        if (r < rows) {
-            const uint32_t local = wbase + (uint32_t)r * 64u;
-            reg[r] = in[first + (local < count ? local : 0u)];
-        }
+    for (int r = 0; r < kLocalRows; ++r) {
+        const uint32_t local = wbase + (uint32_t)r * 64u;
+        reg[r] = in[first + (local < count ? local : 0u)];
+    }
 }
 
-// elements [lo, hi) of the staging buffer to the same elements of out (out 16-byte aligned): whole quads with one store
+// elements [lo, hi) of the staging buffer to the same elements of out (out 16-byte aligned): whole quads with one store,
+// the up to three elements in front of the first whole quad and behind the last one by the first six threads.  No
+// branch around a store (a lane without work is masked off): the number of stores in flight stays countable.
 __device__ __forceinline__ void local_store(const uint32_t *s_stage, uint32_t *__restrict__ out, uint32_t lo, uint32_t hi, int tid) {
     constexpr int kQuadIters = (int)((kLocalCap / 4 + 1 + kLocalThreads - 1) / kLocalThreads);
+    const uint32_t qlo = (lo + 3u) & ~3u, qhi = hi & ~3u;  // whole quads: [qlo, qhi)
 #pragma unroll
     for (int j = 0; j < kQuadIters; ++j) {
         const uint32_t i0 = 4u * ((uint32_t)j * kLocalThreads + (uint32_t)tid);
-        if (i0 >= lo && i0 + 4u <= hi) {
-            *reinterpret_cast<uint4 *>(out + i0) = *reinterpret_cast<const uint4 *>(s_stage + i0);
-        } else if (i0 < hi && i0 + 4u > lo) {
-#pragma unroll
-            for (uint32_t k = 0; k < 4; ++k)
-                if (i0 + k >= lo && i0 + k < hi) out[i0 + k] = s_stage[i0 + k];
-        }
+        if (i0 >= qlo && i0 + 4u <= qhi) *reinterpret_cast<uint4 *>(out + i0) = *reinterpret_cast<const uint4 *>(s_stage + i0);
     }
+    // (qlo > qhi only for a sub-bucket inside one quad: then [lo, hi) is its head)
+    const uint32_t head_end = qlo < hi ? qlo : hi;
+    const uint32_t e = (uint32_t)tid < 3u ? lo + (uint32_t)tid : (qhi > head_end ? qhi : head_end) + (uint32_t)tid - 3u;
+    const bool on = (uint32_t)tid < 3u ? e < head_end : ((uint32_t)tid < 6u && e < hi && e >= head_end);
+    if (on) out[e] = s_stage[e];
 }
 
 template <int NPASS>
@@ -1533,7 +1536,7 @@ __global__ __launch_bounds__(kLocalThreads) void local_sort_kernel(
     uint32_t sub = blockIdx.x, first, count;
     local_next(sub_start, num_sub, sub, first, count, ctl, large_list, tid);
     uint32_t key[kLocalRows];
-    if (count) local_load(keys_in, first, count, (int)((count + kLocalThreads - 1) / kLocalThreads), key, tid);
+    local_load(keys_in, first, count, (int)((count + kLocalThreads - 1) / kLocalThreads), key, tid);
     bool order_ok = true;
     while (count) {  // (uniform)
         // this sub-bucket's values (wanted when its keys have been ranked once) and the NEXT one's keys are asked for
@@ -1546,7 +1549,7 @@ __global__ __launch_bounds__(kLocalThreads) void local_sort_kernel(
         local_next(sub_start, num_sub, sub, nfirst, ncount, ctl, large_list, tid);
         uint32_t nkey[kLocalRows];
         LOCAL_CK(0)  // values asked for, the next sub-bucket found
-        if (ncount) local_load(keys_in, nfirst, ncount, (int)((ncount + kLocalThreads - 1) / kLocalThreads), nkey, tid);
+        local_load(keys_in, nfirst, ncount, (int)((ncount + kLocalThreads - 1) / kLocalThreads), nkey, tid);  // (ncount = 0: the first key of the array, 25 times)
         LOCAL_CK(1)  // its keys asked for
 
         const uint32_t wbase = (uint32_t)w * (uint32_t)(rows * 64) + (uint32_t)lane;
@@ -1621,6 +1624,10 @@ __global__ __launch_bounds__(kLocalThreads) void local_sort_kernel(
                 for (int r = 0; r < kLocalRows; ++r)
                     if (r < rows) key[r] = stage[wbase + (uint32_t)r * 64u];
             } else {
+                // the next sub-bucket's keys take over the registers HERE, before this one's stores are issued: waiting for
+                // them later would mean waiting for every store in front of them (the memory counter runs in order)
+#pragma unroll
+                for (int r = 0; r < kLocalRows; ++r) key[r] = nkey[r];
                 local_store(s_stage, keys_out + (first - skew), skew, skew + count, tid);
             }
             lds_barrier();
@@ -1640,8 +1647,6 @@ __global__ __launch_bounds__(kLocalThreads) void local_sort_kernel(
             lds_barrier();  // (the staging buffer is free again)
             LOCAL_CK(8 + 8 * pass)  // values back / out
         }
-#pragma unroll
-        for (int r = 0; r < kLocalRows; ++r) key[r] = nkey[r];
         first = nfirst;
         count = ncount;
         LOCAL_CK(30)  // registers handed over
