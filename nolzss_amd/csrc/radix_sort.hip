@@ -23,6 +23,7 @@
 // L2 and their partial cache lines merge there: without it the scatter runs at HALF the speed.
 #include "radix_sort.hpp"
 
+#include "lookback.hpp"
 #include "scan.hpp"
 
 #include <algorithm>
@@ -1464,9 +1465,11 @@ __device__ __forceinline__ uint32_t block_scan_exclusive_add_lds(uint32_t v, uin
 
 // the next sub-bucket of this workgroup that fits it (empty ones skipped, larger ones put on the list); count = 0: none left
 __device__ __forceinline__ void local_next(const uint32_t *__restrict__ sub_start, uint32_t num_sub, uint32_t &sub, uint32_t &first,
-                                           uint32_t &count, uint32_t *__restrict__ ctl, uint32_t *__restrict__ large_list, int tid) {
+                                           uint32_t &count, uint32_t *__restrict__ ctl, uint32_t *__restrict__ large_list, int tid,
+                                           uint32_t &which) {
     count = 0;
     first = 0;
+    which = 0;
     while (sub < num_sub) {
         const uint32_t a = sub_start[sub], c = sub_start[sub + 1] - a;
         const uint32_t this_sub = sub;
@@ -1478,6 +1481,7 @@ __device__ __forceinline__ void local_next(const uint32_t *__restrict__ sub_star
         }
         first = a;
         count = c;
+        which = this_sub;
         return;
     }
 }
@@ -1514,12 +1518,92 @@ __device__ __forceinline__ void local_store(const uint32_t *s_stage, uint32_t *_
     if (on) out[e] = s_stage[e];
 }
 
-template <int NPASS>
+// ---- the regroup of round 0 inside local_sort_kernel ---------------------------------------------------------
+// After its last digit a sub-bucket lies sorted in LDS: everything regroup_kernel<true, 3> (suffix_array.hip) would read
+// back from HBM is at hand.  Groups never span two sub-buckets (their members differ in the first eight bases), so a
+// workgroup finds the group heads, the LCP of every boundary the keys decide and the elements that stay tied by itself;
+// what it needs from the others is the number of tied elements in front (a decoupled look-back over one descriptor per
+// non-empty sub-bucket, lookback.hpp) and, for the LCP of its first boundary, the last key of the sub-bucket in front.
+// The keys are not written at all: 4 bytes per suffix less out, 4 less in, and a kernel less.
+constexpr uint32_t kLcpPendingCode = 0xffffffffu;  // (suffix_array.hip: kLcpPending)
+struct LocalFuse {
+    uint32_t *lcp = nullptr, *new_slot = nullptr, *new_grp = nullptr, *d_total = nullptr;
+    uint64_t *desc = nullptr;     // [non-empty sub-buckets] look-back descriptors of the numbers of tied elements
+    uint64_t *lastkey = nullptr;  // [non-empty sub-buckets] [ready : 32 | last key : 32]
+    const uint32_t *dense = nullptr;     // [sub-buckets] index among the non-empty ones
+    const uint32_t *prev_sub = nullptr;  // [sub-buckets] nearest non-empty sub-bucket in front
+    uint32_t nq = 0;
+};
+
+// dense index and predecessor of every non-empty sub-bucket; info = {sub-buckets beyond a workgroup's capacity,
+// non-empty sub-buckets}.  One workgroup; num_sub is a multiple of its 1024 threads.
+__global__ __launch_bounds__(1024) void sub_classify_kernel(const uint32_t *__restrict__ sub_start, uint32_t num_sub,
+                                                            uint32_t *__restrict__ dense, uint32_t *__restrict__ prev_sub,
+                                                            uint32_t *__restrict__ info) {
+    __shared__ uint32_t s_scan[16];
+    __shared__ uint32_t s_large;
+    const uint32_t per = num_sub / 1024u, lo = threadIdx.x * per;
+    if (threadIdx.x == 0) s_large = 0;
+    __syncthreads();
+    uint32_t ne = 0, last = 0, large = 0;  // last: index + 1 of the last non-empty sub-bucket of my stretch
+    for (uint32_t k = lo; k < lo + per; ++k) {
+        const uint32_t c = sub_start[k + 1] - sub_start[k];
+        if (c) {
+            ++ne;
+            last = k + 1;
+        }
+        if (c > kLocalCap) ++large;
+    }
+    if (large) atomicAdd(&s_large, large);
+    uint32_t all_ne, all_last;
+    uint32_t q = block_scan_exclusive<16>(ne, OpAdd<uint32_t>(), s_scan, all_ne);
+    uint32_t prev = block_scan_exclusive<16>(last, OpMax<uint32_t>(), s_scan, all_last);
+    for (uint32_t k = lo; k < lo + per; ++k) {
+        const uint32_t c = sub_start[k + 1] - sub_start[k];
+        dense[k] = q;
+        prev_sub[k] = prev - 1u;  // (0xffffffff: none in front)
+        if (c) {
+            ++q;
+            prev = k + 1;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        info[0] = s_large;
+        info[1] = all_ne;
+    }
+}
+
+// local_store with buffer stores: a lane without work is sent out of bounds (the hardware drops the store) instead of being
+// branched around -- straight-line code, a number of stores the compiler knows
+__device__ __forceinline__ void local_store_buf(const uint32_t *s_stage, uint32_t *out, uint32_t lo, uint32_t hi, int tid) {
+    constexpr int kQuadIters = (int)((kLocalCap / 4 + 1 + kLocalThreads - 1) / kLocalThreads);
+    // (the addresses below depend on the thread alone: hoisted out of the loop over the sub-buckets they were spilled, and
+    // a reload from scratch is a memory operation the wave then waits for with everything else in flight)
+    asm volatile("" : "+v"(tid));
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)(hi * 4u), 0x00020000);
+    const uint32_t qlo = (lo + 3u) & ~3u, qhi = hi & ~3u;  // whole quads: [qlo, qhi)
+    constexpr uint32_t kOut = 0xfffffff0u;
+#pragma unroll
+    for (int j = 0; j < kQuadIters; ++j) {
+        const uint32_t i0 = 4u * ((uint32_t)j * kLocalThreads + (uint32_t)tid);
+        const bool on = i0 >= qlo && i0 + 4u <= qhi;
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(s_stage + (on ? i0 : 0u));
+        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, on ? i0 * 4u : kOut, 0, 0);
+    }
+    const uint32_t head_end = qlo < hi ? qlo : hi;
+    const uint32_t e = (uint32_t)tid < 3u ? lo + (uint32_t)tid : (qhi > head_end ? qhi : head_end) + (uint32_t)tid - 3u;
+    const bool on = (uint32_t)tid < 3u ? e < head_end : ((uint32_t)tid < 6u && e < hi && e >= head_end);
+    __builtin_amdgcn_raw_buffer_store_b32(s_stage[on ? e : 0u], rsrc, on ? e * 4u : kOut, 0, 0);
+}
+
+template <int NPASS, bool kFuse = false>
 __global__ __launch_bounds__(kLocalThreads) void local_sort_kernel(
     const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint32_t *__restrict__ keys_out,
     uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ sub_start, uint32_t num_sub, int shift0,
     uint32_t *__restrict__ ctl /* [1] sub-buckets on the list, [2] a lane-order check failed */, uint32_t *__restrict__ large_list,
-    unsigned long long *__restrict__ phases) {
+    unsigned long long *__restrict__ phases, LocalFuse F = LocalFuse{}) {
 #ifdef NOLZSS_LOCAL_TIMED
     unsigned long long ck_last = __builtin_readcyclecounter();
 #define LOCAL_CK(slot)                                               \
@@ -1534,6 +1618,9 @@ __global__ __launch_bounds__(kLocalThreads) void local_sort_kernel(
     __shared__ __align__(16) uint32_t s_stage[kLocalCap + 4];  // keys, then values, take turns
     __shared__ __align__(16) uint32_t s_whist[kLocalWaves * kBins];
     __shared__ uint32_t s_scan[kLocalWaves];
+    // (kFuse) per 64 places in place order: tied elements, place of the last head + 1 (then their exclusive prefixes);
+    // first key, last key, tied elements in front of the sub-bucket
+    __shared__ uint32_t s_cnt[kFuse ? (kLocalRows + 4) * kLocalWaves + 64 : 1], s_lh[kFuse ? (kLocalRows + 4) * kLocalWaves + 64 : 1], s_edge[3];
     const int tid = threadIdx.x;
     const int w = tid >> 6;
     const int lane = tid & 63;
@@ -1541,8 +1628,8 @@ __global__ __launch_bounds__(kLocalThreads) void local_sort_kernel(
     reinterpret_cast<uint4 *>(wcount)[lane] = make_uint4(0, 0, 0, 0);
     static_assert(kBins == 256, "four counters per lane");
 
-    uint32_t sub = blockIdx.x, first, count;
-    local_next(sub_start, num_sub, sub, first, count, ctl, large_list, tid);
+    uint32_t sub = blockIdx.x, first, count, cur_sub;
+    local_next(sub_start, num_sub, sub, first, count, ctl, large_list, tid, cur_sub);
     uint32_t key[kLocalRows];
     local_load(keys_in, first, count, (int)((count + kLocalThreads - 1) / kLocalThreads), key, tid);
     bool order_ok = true;
@@ -1553,8 +1640,8 @@ __global__ __launch_bounds__(kLocalThreads) void local_sort_kernel(
         const int rows = (int)((count + kLocalThreads - 1) / kLocalThreads);
         uint32_t val[kLocalRows];
         local_load(vals_in, first, count, rows, val, tid);
-        uint32_t nfirst, ncount;
-        local_next(sub_start, num_sub, sub, nfirst, ncount, ctl, large_list, tid);
+        uint32_t nfirst, ncount, next_sub;
+        local_next(sub_start, num_sub, sub, nfirst, ncount, ctl, large_list, tid, next_sub);
         uint32_t nkey[kLocalRows];
         LOCAL_CK(0)  // values asked for, the next sub-bucket found
         local_load(keys_in, nfirst, ncount, (int)((ncount + kLocalThreads - 1) / kLocalThreads), nkey, tid);  // (ncount = 0: the first key of the array, 25 times)
@@ -1621,6 +1708,168 @@ __global__ __launch_bounds__(kLocalThreads) void local_sort_kernel(
             for (int r = 0; r < kLocalRows; ++r)
                 if (r < rows) lrank[r] += wcount[digit_of(key[r], shift)];
             reinterpret_cast<uint4 *>(wcount)[lane] = make_uint4(0, 0, 0, 0);  // (after the wave's own reads, before its next atomics)
+            if constexpr (kFuse) {
+                if (pass + 1 == NPASS) {
+                    // The last digit with the regroup of round 0 on the way.  The VALUES go first: their stores are
+                    // buffer stores a lane without work sends out of bounds (no branch: the compiler can count them, and the
+                    // wait for the next sub-bucket's keys below lets them drain).
+#pragma unroll
+                    for (int r = 0; r < kLocalRows; ++r)
+                        if (r < rows) stage[lrank[r]] = val[r];
+                    lds_barrier();
+                    LOCAL_CK(18)  // (fused) values staged
+                    local_store_buf(s_stage, vals_out + (first - skew), skew, skew + count, tid);
+                    lds_barrier();
+                    LOCAL_CK(19)  // values out
+#pragma unroll
+                    for (int r = 0; r < kLocalRows; ++r)
+                        if (r < rows) stage[lrank[r]] = key[r];
+#pragma unroll
+                    for (int r = 0; r < kLocalRows; ++r) key[r] = nkey[r];  // (the next sub-bucket's keys take over)
+                    lds_barrier();
+                    LOCAL_CK(20)  // keys staged, next keys taken over
+                    // What follows walks the sorted keys in the staging buffer in plain loops (place p = p0 + thread): no
+                    // arrays in registers -- an unrolled form with 25 more registers spilled whatever was tried.
+                    // Loop 1: heads, LCP of the boundaries, and per 64 places the tied elements and the last head.
+                    const uint32_t bucket = cur_sub >> 8;
+                    constexpr int kU = 4;  // (places of four rows per turn: their LDS reads go out together)
+                    for (uint32_t p0 = 0, e0 = (uint32_t)w; p0 < count; p0 += kU * kLocalThreads, e0 += kU * kLocalWaves) {
+                        uint32_t k[kU], pk[kU], nk[kU];
+#pragma unroll
+                        for (int u = 0; u < kU; ++u) {
+                            const uint32_t pl = p0 + (uint32_t)u * kLocalThreads + (uint32_t)tid;
+                            const bool valid = pl < count;
+                            k[u] = stage[valid ? pl : 0u];
+                            pk[u] = stage[(valid && pl > 0u) ? pl - 1u : 0u];
+                            nk[u] = stage[(valid && pl + 1u < count) ? pl + 1u : 0u];
+                        }
+#pragma unroll
+                        for (int u = 0; u < kU; ++u) {
+                            const uint32_t pl = p0 + (uint32_t)u * kLocalThreads + (uint32_t)tid;
+                            const bool valid = pl < count;
+                            // (a suffix that ends inside the key window -- tag < 16 -- ties with nobody: a head, and so is
+                            // whoever follows it; the first place of a sub-bucket is a head, and so is the one behind its last)
+                            const bool head = valid && (pl == 0u || k[u] != pk[u] || (k[u] & 0xffu) < (uint32_t)kP16Syms);
+                            const bool nhead = pl + 1u >= count || nk[u] != k[u] || (nk[u] & 0xffu) < (uint32_t)kP16Syms;
+                            const bool keep = valid && !(head && nhead);
+                            if (valid && pl > 0u) {  // (place 0: below, with the last key of the sub-bucket in front)
+                                uint32_t l = kLcpPendingCode;
+                                if (head) {
+                                    const uint32_t y = (k[u] ^ pk[u]) >> kP16TagBits, ta = k[u] & 0xffu, tb = pk[u] & 0xffu;
+                                    uint32_t ls = y ? (uint32_t)__builtin_clz(y) >> 1 : 0xffffffffu;
+                                    ls = ls < ta ? ls : ta;
+                                    l = ls < tb ? ls : tb;
+                                }
+                                F.lcp[first + pl] = l;
+                            }
+                            const uint64_t hmask = __ballot(head), kmask = __ballot(keep);
+                            if (lane == 0) {
+                                const uint32_t e = e0 + (uint32_t)u * kLocalWaves;
+                                s_cnt[e] = (uint32_t)__popcll(kmask);
+                                s_lh[e] = hmask ? p0 + (uint32_t)u * kLocalThreads + (uint32_t)w * 64u + (uint32_t)(63 - __builtin_clzll(hmask)) + 1u : 0u;
+                            }
+                            if (valid && pl == 0u) s_edge[0] = k[u];
+                            if (valid && pl + 1u == count) s_edge[1] = k[u];
+                        }
+                    }
+                    LOCAL_CK(21)  // loop 1 (wave 0)
+                    lds_barrier();
+                    LOCAL_CK(22)  // ... everybody
+                    if (w == 0) {
+                        // the first wave: prefixes over the (rows x waves) entries in place order, the look-back for the tied
+                        // elements in front of the sub-bucket, the first boundary
+                        const uint32_t ne = (uint32_t)rows * kLocalWaves;
+                        constexpr int kPer = (kLocalRows * kLocalWaves + 63) / 64;
+                        uint32_t c[kPer], h[kPer], sum = 0, mx = 0;
+#pragma unroll
+                        for (int j = 0; j < kPer; ++j) {
+                            const uint32_t e = (uint32_t)lane * kPer + (uint32_t)j;
+                            c[j] = e < ne ? s_cnt[e] : 0u;
+                            h[j] = e < ne ? s_lh[e] : 0u;
+                            sum += c[j];
+                            mx = h[j] ? h[j] : mx;  // (positions grow along the entries: the last one that has a head)
+                        }
+                        const uint32_t isum = wave_scan_inclusive_dpp(sum, 0u, OpAdd<uint32_t>());
+                        const uint32_t imax = wave_scan_inclusive_dpp(mx, 0u, OpMax<uint32_t>());
+                        uint32_t run = isum - sum, lasth = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)imax, 0x138, 0xf, 0xf, false);  // (wave_shr:1)
+                        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)isum, 63);
+#pragma unroll
+                        for (int j = 0; j < kPer; ++j) {
+                            const uint32_t e = (uint32_t)lane * kPer + (uint32_t)j;
+                            if (e < ne) {
+                                s_cnt[e] = run;
+                                s_lh[e] = lasth;
+                            }
+                            run += c[j];
+                            lasth = h[j] ? h[j] : lasth;
+                        }
+                        const uint32_t q = F.dense[cur_sub];
+                        if (lane == 0) desc_store(F.lastkey + q, (1ull << 32) | (uint64_t)s_edge[1]);
+                        const uint32_t xs = lookback_exclusive_add_wide<4>(F.desc, q, total, F.d_total + 1);
+                        if (lane == 0) {
+                            s_edge[2] = xs;
+                            if (q + 1u == F.nq) F.d_total[0] = xs + total;
+                            uint32_t l0 = 0;  // (the very first suffix of the order)
+                            if (q > 0u) {
+                                uint64_t d;
+                                uint32_t spins = 0;
+                                while (((d = desc_load(F.lastkey + (q - 1u))) >> 32) == 0) {
+                                    if (++spins > kSpinLimit) {  // (never hang the GPU)
+                                        atomicExch(F.d_total + 1, 1u);
+                                        break;
+                                    }
+                                    __builtin_amdgcn_s_sleep(1);
+                                }
+                                const uint32_t pk = (uint32_t)d, k = s_edge[0];
+                                const uint32_t y = ((bucket ^ (F.prev_sub[cur_sub] >> 8)) << 24) | ((k ^ pk) >> kP16TagBits);
+                                const uint32_t ta = k & 0xffu, tb = pk & 0xffu;
+                                uint32_t ls = y ? (uint32_t)__builtin_clz(y) >> 1 : 0xffffffffu;
+                                ls = ls < ta ? ls : ta;
+                                l0 = ls < tb ? ls : tb;
+                            }
+                            F.lcp[first] = l0;
+                        }
+                    }
+                    LOCAL_CK(23)  // prefixes + look-back + first boundary (wave 0)
+                    lds_barrier();
+                    LOCAL_CK(24)  // ... everybody
+                    // Loop 2: the tied elements -- slot and slot of the group's head, in slot order
+                    const uint32_t xsum = s_edge[2];
+                    for (uint32_t p0 = 0, e0 = (uint32_t)w; p0 < count; p0 += kU * kLocalThreads, e0 += kU * kLocalWaves) {
+                        uint32_t k[kU], pk[kU], nk[kU], base[kU], lh[kU];
+#pragma unroll
+                        for (int u = 0; u < kU; ++u) {
+                            const uint32_t pl = p0 + (uint32_t)u * kLocalThreads + (uint32_t)tid;
+                            const bool valid = pl < count;
+                            k[u] = stage[valid ? pl : 0u];
+                            pk[u] = stage[(valid && pl > 0u) ? pl - 1u : 0u];
+                            nk[u] = stage[(valid && pl + 1u < count) ? pl + 1u : 0u];
+                            base[u] = s_cnt[e0 + (uint32_t)u * kLocalWaves];
+                            lh[u] = s_lh[e0 + (uint32_t)u * kLocalWaves];
+                        }
+#pragma unroll
+                        for (int u = 0; u < kU; ++u) {
+                            const uint32_t pl = p0 + (uint32_t)u * kLocalThreads + (uint32_t)tid;
+                            const bool valid = pl < count;
+                            const bool head = valid && (pl == 0u || k[u] != pk[u] || (k[u] & 0xffu) < (uint32_t)kP16Syms);
+                            const bool nhead = pl + 1u >= count || nk[u] != k[u] || (nk[u] & 0xffu) < (uint32_t)kP16Syms;
+                            const bool keep = valid && !(head && nhead);
+                            const uint64_t hmask = __ballot(head), kmask = __ballot(keep);
+                            if (keep) {
+                                const uint64_t upto = hmask & ((2ull << lane) - 1ull);
+                                const uint32_t hidx = upto ? p0 + (uint32_t)u * kLocalThreads + (uint32_t)w * 64u + (uint32_t)(63 - __builtin_clzll(upto)) : lh[u] - 1u;
+                                const uint32_t pos = xsum + base[u] + (uint32_t)__popcll(kmask & ((1ull << lane) - 1ull));
+                                F.new_slot[pos] = first + pl;
+                                F.new_grp[pos] = first + hidx;
+                            }
+                        }
+                    }
+                    LOCAL_CK(25)  // loop 2 (wave 0)
+                    lds_barrier();  // (the staging buffer is free again)
+                    LOCAL_CK(26)  // ... everybody
+                    continue;
+                }
+            }
             // keys through the staging buffer: back into the registers in the new order, or out; then the values
 #pragma unroll
             for (int r = 0; r < kLocalRows; ++r)
@@ -1657,6 +1906,7 @@ __global__ __launch_bounds__(kLocalThreads) void local_sort_kernel(
         }
         first = nfirst;
         count = ncount;
+        cur_sub = next_sub;
         LOCAL_CK(30)  // registers handed over
 #ifdef NOLZSS_LOCAL_TIMED
         if (tid == 0) atomicAdd(phases + 31, 1ull);
@@ -1727,7 +1977,7 @@ std::atomic<bool> local_sort_off{false};  // a lane-order check of local_sort_ke
 // a workgroup's capacity go through segmented passes.  keys_in / vals_in are scratch afterwards.
 void local_sort_sub_buckets(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out, const uint32_t *scanned,
                             const uint32_t *tile0, const uint32_t *bstart, uint32_t num_buckets, int shift0, int npass, size_t n,
-                            Arena &arena, hipStream_t stream, Profiler *prof) {
+                            Arena &arena, hipStream_t stream, Profiler *prof, Round0Regroup *rg = nullptr) {
     const uint32_t num_sub = num_buckets * (uint32_t)kBins;
     uint32_t *sub_start = arena.alloc<uint32_t>((size_t)num_sub + 1);
     uint32_t *large_list = arena.alloc<uint32_t>(num_sub);
@@ -1744,6 +1994,62 @@ void local_sort_sub_buckets(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys
     d_ph = arena.alloc<unsigned long long>(32);
     HIP_CHECK(hipMemsetAsync(d_ph, 0, 32 * sizeof(unsigned long long), stream));
 #endif
+#ifdef NOLZSS_LOCAL_TIMED
+    auto print_phases = [&] {
+        unsigned long long h[32];
+        HIP_CHECK(hipMemcpyAsync(h, d_ph, sizeof(h), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        const double wn = h[31] ? (double)h[31] : 1.0;
+        fprintf(stderr, "[nolzss] local_sort phases (cycles per sub-bucket, %llu sub-buckets): next found %.0f its loads issued %.0f |", h[31], h[0] / wn, h[1] / wn);
+        for (int p = 0; p < npass; ++p)
+            fprintf(stderr, " pass %d: rank(wave 0) %.0f rank(all) %.0f offsets %.0f stage keys %.0f keys back/out %.0f stage values %.0f values back/out %.0f |",
+                    p, h[2 + 8 * p] / wn, h[3 + 8 * p] / wn, h[4 + 8 * p] / wn, h[5 + 8 * p] / wn, h[6 + 8 * p] / wn,
+                    h[7 + 8 * p] / wn, h[8 + 8 * p] / wn);
+        fprintf(stderr, " fused: stage values %.0f values out %.0f stage keys + take over %.0f loop1 %.0f (all %.0f) look-back %.0f (all %.0f) loop2 %.0f (all %.0f) |",
+                h[18] / wn, h[19] / wn, h[20] / wn, h[21] / wn, h[22] / wn, h[23] / wn, h[24] / wn, h[25] / wn, h[26] / wn);
+        fprintf(stderr, " hand-over %.0f\n", h[30] / wn);
+    };
+#endif
+    static const bool fail_order = getenv("NOLZSS_TEST_LOCAL_ORDER_FAILS") != nullptr;  // (test hook: the redo path)
+    static const bool no_fuse = getenv("NOLZSS_NO_LOCAL_REGROUP") != nullptr;            // (A/B switch)
+    if (rg && !no_fuse && !fail_order && npass == 2 && num_sub % 1024u == 0) {
+        // the regroup of round 0 on the way -- if no sub-bucket overflows a workgroup (the segmented passes that finish
+        // those come after the kernel) and the kernel's checks hold; otherwise the plain form below runs from the same input
+        uint32_t *dense = arena.alloc<uint32_t>(num_sub), *prev_sub = arena.alloc<uint32_t>(num_sub), *info = arena.alloc<uint32_t>(2);
+        sub_classify_kernel<<<1, 1024, 0, stream>>>(sub_start, num_sub, dense, prev_sub, info);
+        KERNEL_CHECK();
+        uint32_t h_info[2];
+        HIP_CHECK(hipMemcpyAsync(h_info, info, sizeof(h_info), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        if (h_info[0] == 0 && h_info[1] > 0) {
+            LocalFuse F;
+            F.lcp = rg->lcp; F.new_slot = rg->new_slot; F.new_grp = rg->new_grp; F.d_total = rg->d_total;
+            F.nq = h_info[1];
+            uint64_t *dd = arena.alloc<uint64_t>(2 * (size_t)F.nq);
+            HIP_CHECK(hipMemsetAsync(dd, 0, 2 * (size_t)F.nq * sizeof(uint64_t), stream));
+            HIP_CHECK(hipMemsetAsync(rg->d_total, 0, 2 * sizeof(uint32_t), stream));
+            F.desc = dd; F.lastkey = dd + F.nq; F.dense = dense; F.prev_sub = prev_sub;
+            {
+                ProfScope ps(prof, "rs_local_sort", stream, 16.0 * (double)n);  // (pairs in; suffixes and LCP out; the tied elements come on top)
+                local_sort_kernel<2, true><<<grid, kLocalThreads, 0, stream>>>(keys_in, vals_in, keys_out, vals_out, sub_start, num_sub, shift0,
+                                                                               ctl, large_list, d_ph, F);
+                KERNEL_CHECK();
+            }
+            uint32_t h_c[4], h_t[2];
+            HIP_CHECK(hipMemcpyAsync(h_c, ctl, sizeof(h_c), hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipMemcpyAsync(h_t, rg->d_total, sizeof(h_t), hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+#ifdef NOLZSS_LOCAL_TIMED
+            print_phases();
+#endif
+            if (h_c[2] == 0 && h_t[1] == 0) {
+                rg->done = true;
+                return;
+            }
+            if (h_t[1]) fprintf(stderr, "[nolzss] local_sort_kernel: look-back timed out; sorted again without the regroup on the way\n");
+            HIP_CHECK(hipMemsetAsync(ctl, 0, 4 * sizeof(uint32_t), stream));  // (a failed lane-order check shows again below)
+        }
+    }
     {
         ProfScope ps(prof, "rs_local_sort", stream, 16.0 * (double)n);
         if (npass == 2)
@@ -1757,23 +2063,11 @@ void local_sort_sub_buckets(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys
         KERNEL_CHECK();
     }
 #ifdef NOLZSS_LOCAL_TIMED
-    {
-        unsigned long long h[32];
-        HIP_CHECK(hipMemcpyAsync(h, d_ph, sizeof(h), hipMemcpyDeviceToHost, stream));
-        HIP_CHECK(hipStreamSynchronize(stream));
-        const double wn = h[31] ? (double)h[31] : 1.0;
-        fprintf(stderr, "[nolzss] local_sort phases (cycles per sub-bucket, %llu sub-buckets): next found %.0f its loads issued %.0f |", h[31], h[0] / wn, h[1] / wn);
-        for (int p = 0; p < npass; ++p)
-            fprintf(stderr, " pass %d: rank(wave 0) %.0f rank(all) %.0f offsets %.0f stage keys %.0f keys back/out %.0f stage values %.0f values back/out %.0f |",
-                    p, h[2 + 8 * p] / wn, h[3 + 8 * p] / wn, h[4 + 8 * p] / wn, h[5 + 8 * p] / wn, h[6 + 8 * p] / wn,
-                    h[7 + 8 * p] / wn, h[8 + 8 * p] / wn);
-        fprintf(stderr, " hand-over %.0f\n", h[30] / wn);
-    }
+    print_phases();
 #endif
     uint32_t h_ctl[4];
     HIP_CHECK(hipMemcpyAsync(h_ctl, ctl, sizeof(h_ctl), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
-    static const bool fail_order = getenv("NOLZSS_TEST_LOCAL_ORDER_FAILS") != nullptr;  // (test hook: the redo path)
     const bool redo_all = h_ctl[2] != 0 || fail_order;
     if (h_ctl[2]) {
         // the lane-order check failed somewhere: nothing the kernel wrote is trusted, and it is not asked again
@@ -1874,7 +2168,8 @@ Text16SegSrc make_text16_seg(const PackedText &text) {
 }  // namespace
 
 void radix_sort_dna_keys16(const PackedText &text, uint32_t *keys32[2], uint32_t *vals[2], uint32_t *seg_mem,
-                           SegView &seg_out, Arena &arena, hipStream_t stream, Profiler *prof) {
+                           SegView &seg_out, Arena &arena, hipStream_t stream, Profiler *prof, Round0Regroup *regroup) {
+    if (regroup) regroup->done = false;
     const size_t n = text.n;
     if (!key16_applicable(text)) throw HipError("radix_sort_dna_keys16: plain 2-bit texts, or segmented ones with a short terminator table");
     const size_t m = arena.mark();
@@ -1927,7 +2222,7 @@ void radix_sort_dna_keys16(const PackedText &text, uint32_t *keys32[2], uint32_t
         // the digit below the bucket's (four more bases) first, then every sub-bucket by the 16 bits between it and the tag
         radix_pass<uint32_t, uint32_t>(ArraySrc<uint32_t>{keys32[0], vals[0]}, keys32[1], vals[1], n, kP16TagBits + 16, hist,
                                        seg_out.num_tiles, 4.0 * (double)n, 16.0 * (double)n, arena, stream, prof, seg_out);
-        local_sort_sub_buckets(keys32[1], vals[1], keys32[0], vals[0], hist, tile0, bstart, (uint32_t)kBins, kP16TagBits, 2, n, arena, stream, prof);
+        local_sort_sub_buckets(keys32[1], vals[1], keys32[0], vals[0], hist, tile0, bstart, (uint32_t)kBins, kP16TagBits, 2, n, arena, stream, prof, regroup);
         arena.rewind(m);
         return;
     }

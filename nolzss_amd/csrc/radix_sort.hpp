@@ -100,8 +100,19 @@ void radix_sort_dna_keys(const PackedText &text, uint32_t *keys32[2], uint32_t *
 // (also segmented texts with a terminator table of at most kTermFew entries and segments of at least 16 symbols -- a
 // prepared reverse-complement string --: key16_applicable says whether a text takes this sort)
 bool key16_applicable(const PackedText &text);
+// What the regroup kernel of round 0 produces from the sorted keys (suffix_array.hip: regroup_kernel<true, 3>), asked of the
+// sort itself: where the sub-buckets are finished in LDS the sorted keys are at hand -- LCP of every boundary the keys
+// decide (0xffffffff = pending elsewhere), the elements that stay tied (slot and slot of their group's head, in slot
+// order) and their number.  `done` says whether the sort did it (the keys are then NOT written).
+struct Round0Regroup {
+    uint32_t *lcp = nullptr;
+    uint32_t *new_slot = nullptr, *new_grp = nullptr;
+    uint32_t *d_total = nullptr;  // device: [0] survivors, [1] look-back error flag
+    bool done = false;
+};
 void radix_sort_dna_keys16(const PackedText &text, uint32_t *keys32[2], uint32_t *vals[2], uint32_t *seg_mem,
-                           SegView &seg_out, Arena &arena, hipStream_t stream, Profiler *prof = nullptr);
+                           SegView &seg_out, Arena &arena, hipStream_t stream, Profiler *prof = nullptr,
+                           Round0Regroup *regroup = nullptr);
 
 // The same sort on FUSED records [stored key word : 32 | suffix : 32] (round 4, A/B: NOLZSS_FUSED_SORT): rec[0] and rec[1]
 // hold n 64-bit words each; the last pass writes the suffixes to sa_out and the key words to rec[0] (as 32-bit words).

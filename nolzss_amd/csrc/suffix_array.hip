@@ -17,6 +17,7 @@
 // All arrays are 32-bit; rank[i] holds (index of the first slot of i's group) + 1, and 0 means
 // "past the end of the text", which sorts before every real suffix exactly as the reference's
 // appended terminator does.
+#include "lookback.hpp"
 #include "pipeline.hpp"
 #include "pyramid.hpp"
 #include "queues.hpp"
@@ -250,56 +251,6 @@ constexpr uint32_t kLcpPendingCompared = kLcpPending - 1u;  // pending, inside a
 constexpr int kFuseThreads = 512;  // 8 items per thread keep the registers low: 4 workgroups = 32 waves per CU
 constexpr int kFuseItems = 8;
 constexpr int kFuseTile = kFuseThreads * kFuseItems;
-constexpr uint32_t kSpinLimit = 1u << 24;  // look-back polls before the kernel gives up (sets err)
-
-__device__ __forceinline__ uint64_t desc_load(const uint64_t *p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void desc_store(uint64_t *p, uint64_t v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Run by the first wavefront of a workgroup: publishes the tile's aggregate, combines the
-// descriptors of the tiles in front (64 per step, nearest first) up to the first inclusive one,
-// publishes the tile's inclusive prefix and returns its exclusive prefix.
-template <typename Op>
-__device__ __forceinline__ uint32_t lookback_exclusive(uint64_t *desc, uint32_t tile, uint32_t aggregate, Op op,
-                                                       uint32_t *err) {
-    const int lane = lane_id();
-    if (tile == 0) {
-        if (lane == 0) desc_store(desc, (2ull << 32) | aggregate);
-        return Op::identity();
-    }
-    if (lane == 0) desc_store(desc + tile, (1ull << 32) | aggregate);
-    uint32_t excl = Op::identity();
-    int64_t look = (int64_t)tile - 1;
-    for (;;) {
-        const int64_t idx = look - lane;
-        uint64_t d, need, inc;
-        uint32_t spins = 0;
-        for (;;) {
-            d = idx >= 0 ? desc_load(desc + idx) : (2ull << 32);  // in front of tile 0: inclusive identity
-            const uint32_t st = (uint32_t)(d >> 32);
-            inc = __ballot(st == 2);
-            // every lane up to and including the first inclusive one must have been published
-            need = inc ? (((inc & (~inc + 1ull)) << 1) - 1ull) : ~0ull;
-            const uint64_t missing = __ballot(st == 0) & need;
-            if (!missing) break;
-            if (++spins > kSpinLimit) {  // cannot happen with ticket order; never hang the GPU
-                if (lane == 0) atomicExch(err, 1u);
-                return excl;
-            }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        const uint32_t v = ((need >> lane) & 1ull) ? (uint32_t)d : Op::identity();
-        excl = op(excl, wave_reduce(v, op));
-        if (inc) break;  // an inclusive prefix was reached
-        look -= 64;
-    }
-    if (lane == 0) desc_store(desc + tile, (2ull << 32) | op(excl, aggregate));
-    return excl;
-}
-
 // Both running values in ONE descriptor, [status:2 | last head slot:31 | kept:31], for lists shorter
 // than 2^31: one walk over the tiles in front instead of two.  (The walk is what a regroup tile
 // waits for -- with ~1800 small tiles in flight, most of them published but not yet finished, it
@@ -2239,6 +2190,7 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
     }
     int cur;
     SegView seg;
+    Round0Regroup round0;
     {
         // only the low key_bits of the key are populated
         int key_bits = k_syms * text.bits;
@@ -2257,7 +2209,13 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
             cur = 0;
         } else if (key16) {
             uint32_t *keys32[2] = {reinterpret_cast<uint32_t *>(keys[0]), reinterpret_cast<uint32_t *>(keys[1])};
-            radix_sort_dna_keys16(text, keys32, vals, seg_mem, seg, arena, s, ctx.profiler());
+            // (where the sort finishes its sub-buckets in LDS it does the regroup of round 0 on the way, if nobody needs
+            // the ranks it would store: the sorted keys are then never written)
+            round0.lcp = lcp;
+            round0.new_slot = act_slot[0];
+            round0.new_grp = act_grp[0];
+            round0.d_total = d_total;
+            radix_sort_dna_keys16(text, keys32, vals, seg_mem, seg, arena, s, ctx.profiler(), store_ranks ? nullptr : &round0);
             cur = 0;
             if (vals[cur] != sa) throw HipError("suffix array: key sort did not end in sa");
         } else if (dna_fast) {
@@ -2303,7 +2261,13 @@ int build_suffix_array(Context &ctx, const PackedText &text, uint32_t *sa, uint3
         tag_bits = kSegTagBits;
         low_bits = kSegTermBits;
     }
-    uint32_t m = regroup<true>(ctx, keys[cur], nullptr, nullptr, vals[cur], nullptr, n, n, sa, rank, act_slot[0],
+    uint32_t m = 0;
+    if (round0.done) {
+        uint32_t total2[2] = {0, 0};
+        ctx.read_back(d_total, total2, 2);
+        m = total2[0];
+    } else
+    m = regroup<true>(ctx, keys[cur], nullptr, nullptr, vals[cur], nullptr, n, n, sa, rank, act_slot[0],
                                act_grp[0], nullptr, nullptr, nullptr, d_total, lcp,
                                k_syms * text.bits, tag_bits, text.bits, nullptr, low_bits, 0, rank_by_slot, nullptr,
                                bucketed ? reinterpret_cast<const uint32_t *>(keys[cur]) : nullptr,
