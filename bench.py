@@ -132,7 +132,8 @@ KERNEL_OF_STAGE = [
     ("sa_regroup", ["regroup_kernel<true, 3>", "regroup_kernel<false, 0>", "compact_survivors_kernel"], "valu_issue + look-back latency"),
     ("window_scatter", ["window_scatter2_kernel"], "hbm"),
     ("rs_scatter.text", ["rs_scatter_kernel<u64, u32, Text16Src, u32>"], "valu_issue + hbm writes"),
-    ("rs_local_sort", ["local_sort_kernel<2>"], "lds (returning atomics, staging) + hbm; one workgroup per CU"),
+    ("rs_local_sort", ["local_sort_kernel<2, true>", "local_sort_kernel<2, false>"],
+     "valu_issue + lds at 12 waves per CU (sort and the regroup of round 0 in one kernel) + hbm"),
     ("rs_hist", ["rs_hist_kernel<u32, ArraySrc<u32> >", "rs_hist_kernel<u32, PairSrc>", "rs_hist_kernel<u32, RankSrc>",
                  "rs_hist_kernel<u64, Text16Src>"], "hbm + per-tile latency"),
     ("chain_exit", ["chain_exit_kernel"], "hbm + lds"),

@@ -111,6 +111,16 @@ class Profiler {
         (void)hipEventRecord(e.b, s);  // called from a destructor: never throws
         done_.push_back(e);
     }
+    // algorithmic bytes that are only known after the launch (the latest finished scope of that name)
+    void add_bytes(const char *name, double bytes) {
+        if (!on_) return;
+        for (size_t k = done_.size(); k-- > 0;)
+            if (done_[k].name == name) {
+                done_[k].bytes += bytes;
+                return;
+            }
+        stats_[name].bytes += bytes;
+    }
     // call after the stream has been synchronised
     void collect() {
         for (auto &e : done_) {

@@ -2043,6 +2043,7 @@ void local_sort_sub_buckets(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys
             print_phases();
 #endif
             if (h_c[2] == 0 && h_t[1] == 0) {
+                if (prof) prof->add_bytes("rs_local_sort", 8.0 * (double)h_t[0]);  // (slot and group of every tied element)
                 rg->done = true;
                 return;
             }
