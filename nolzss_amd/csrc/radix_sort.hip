@@ -1621,6 +1621,7 @@ __global__ __launch_bounds__(kLocalThreads) void local_sort_kernel(
     // (kFuse) per 64 places in place order: tied elements, place of the last head + 1 (then their exclusive prefixes);
     // first key, last key, tied elements in front of the sub-bucket
     __shared__ uint32_t s_cnt[kFuse ? (kLocalRows + 4) * kLocalWaves + 64 : 1], s_lh[kFuse ? (kLocalRows + 4) * kLocalWaves + 64 : 1], s_edge[3];
+    __shared__ uint64_t s_mask[kFuse ? 2 * ((kLocalRows + 4) * kLocalWaves + 64) : 1];  // (kFuse) heads / tied elements of the 64 places, as lane masks
     const int tid = threadIdx.x;
     const int w = tid >> 6;
     const int lane = tid & 63;
@@ -1734,28 +1735,32 @@ __global__ __launch_bounds__(kLocalThreads) void local_sort_kernel(
                     const uint32_t bucket = cur_sub >> 8;
                     constexpr int kU = 4;  // (places of four rows per turn: their LDS reads go out together)
                     for (uint32_t p0 = 0, e0 = (uint32_t)w; p0 < count; p0 += kU * kLocalThreads, e0 += kU * kLocalWaves) {
-                        uint32_t k[kU], pk[kU], nk[kU];
+                        uint32_t k[kU], edge[kU];
 #pragma unroll
                         for (int u = 0; u < kU; ++u) {
                             const uint32_t pl = p0 + (uint32_t)u * kLocalThreads + (uint32_t)tid;
                             const bool valid = pl < count;
                             k[u] = stage[valid ? pl : 0u];
-                            pk[u] = stage[(valid && pl > 0u) ? pl - 1u : 0u];
-                            nk[u] = stage[(valid && pl + 1u < count) ? pl + 1u : 0u];
+                            // (the neighbours are the neighbouring lanes' keys; lane 0 reads the place in front of the wave's
+                            // 64, lane 63 the one behind them)
+                            const uint32_t ep = lane == 0 ? pl - 1u : pl + 1u;
+                            edge[u] = stage[(valid && ep < count) ? ep : 0u];
                         }
 #pragma unroll
                         for (int u = 0; u < kU; ++u) {
                             const uint32_t pl = p0 + (uint32_t)u * kLocalThreads + (uint32_t)tid;
                             const bool valid = pl < count;
+                            const uint32_t pk = (uint32_t)__builtin_amdgcn_update_dpp((int)edge[u], (int)k[u], 0x138, 0xf, 0xf, false);  // wave_shr:1
+                            const uint32_t nk = (uint32_t)__builtin_amdgcn_update_dpp((int)edge[u], (int)k[u], 0x130, 0xf, 0xf, false);  // wave_shl:1
                             // (a suffix that ends inside the key window -- tag < 16 -- ties with nobody: a head, and so is
                             // whoever follows it; the first place of a sub-bucket is a head, and so is the one behind its last)
-                            const bool head = valid && (pl == 0u || k[u] != pk[u] || (k[u] & 0xffu) < (uint32_t)kP16Syms);
-                            const bool nhead = pl + 1u >= count || nk[u] != k[u] || (nk[u] & 0xffu) < (uint32_t)kP16Syms;
+                            const bool head = valid && (pl == 0u || k[u] != pk || (k[u] & 0xffu) < (uint32_t)kP16Syms);
+                            const bool nhead = pl + 1u >= count || nk != k[u] || (nk & 0xffu) < (uint32_t)kP16Syms;
                             const bool keep = valid && !(head && nhead);
                             if (valid && pl > 0u) {  // (place 0: below, with the last key of the sub-bucket in front)
                                 uint32_t l = kLcpPendingCode;
                                 if (head) {
-                                    const uint32_t y = (k[u] ^ pk[u]) >> kP16TagBits, ta = k[u] & 0xffu, tb = pk[u] & 0xffu;
+                                    const uint32_t y = (k[u] ^ pk) >> kP16TagBits, ta = k[u] & 0xffu, tb = pk & 0xffu;
                                     uint32_t ls = y ? (uint32_t)__builtin_clz(y) >> 1 : 0xffffffffu;
                                     ls = ls < ta ? ls : ta;
                                     l = ls < tb ? ls : tb;
@@ -1767,6 +1772,8 @@ __global__ __launch_bounds__(kLocalThreads) void local_sort_kernel(
                                 const uint32_t e = e0 + (uint32_t)u * kLocalWaves;
                                 s_cnt[e] = (uint32_t)__popcll(kmask);
                                 s_lh[e] = hmask ? p0 + (uint32_t)u * kLocalThreads + (uint32_t)w * 64u + (uint32_t)(63 - __builtin_clzll(hmask)) + 1u : 0u;
+                                s_mask[2 * e] = hmask;  // (the second loop reads the masks, not the keys)
+                                s_mask[2 * e + 1] = kmask;
                             }
                             if (valid && pl == 0u) s_edge[0] = k[u];
                             if (valid && pl + 1u == count) s_edge[1] = k[u];
@@ -1835,33 +1842,15 @@ __global__ __launch_bounds__(kLocalThreads) void local_sort_kernel(
                     LOCAL_CK(24)  // ... everybody
                     // Loop 2: the tied elements -- slot and slot of the group's head, in slot order
                     const uint32_t xsum = s_edge[2];
-                    for (uint32_t p0 = 0, e0 = (uint32_t)w; p0 < count; p0 += kU * kLocalThreads, e0 += kU * kLocalWaves) {
-                        uint32_t k[kU], pk[kU], nk[kU], base[kU], lh[kU];
-#pragma unroll
-                        for (int u = 0; u < kU; ++u) {
-                            const uint32_t pl = p0 + (uint32_t)u * kLocalThreads + (uint32_t)tid;
-                            const bool valid = pl < count;
-                            k[u] = stage[valid ? pl : 0u];
-                            pk[u] = stage[(valid && pl > 0u) ? pl - 1u : 0u];
-                            nk[u] = stage[(valid && pl + 1u < count) ? pl + 1u : 0u];
-                            base[u] = s_cnt[e0 + (uint32_t)u * kLocalWaves];
-                            lh[u] = s_lh[e0 + (uint32_t)u * kLocalWaves];
-                        }
-#pragma unroll
-                        for (int u = 0; u < kU; ++u) {
-                            const uint32_t pl = p0 + (uint32_t)u * kLocalThreads + (uint32_t)tid;
-                            const bool valid = pl < count;
-                            const bool head = valid && (pl == 0u || k[u] != pk[u] || (k[u] & 0xffu) < (uint32_t)kP16Syms);
-                            const bool nhead = pl + 1u >= count || nk[u] != k[u] || (nk[u] & 0xffu) < (uint32_t)kP16Syms;
-                            const bool keep = valid && !(head && nhead);
-                            const uint64_t hmask = __ballot(head), kmask = __ballot(keep);
-                            if (keep) {
-                                const uint64_t upto = hmask & ((2ull << lane) - 1ull);
-                                const uint32_t hidx = upto ? p0 + (uint32_t)u * kLocalThreads + (uint32_t)w * 64u + (uint32_t)(63 - __builtin_clzll(upto)) : lh[u] - 1u;
-                                const uint32_t pos = xsum + base[u] + (uint32_t)__popcll(kmask & ((1ull << lane) - 1ull));
-                                F.new_slot[pos] = first + pl;
-                                F.new_grp[pos] = first + hidx;
-                            }
+                    for (uint32_t p0 = 0, e = (uint32_t)w; p0 < count; p0 += kLocalThreads, e += kLocalWaves) {
+                        const uint64_t hmask = s_mask[2 * e], kmask = s_mask[2 * e + 1];  // (wave-uniform)
+                        if ((kmask >> lane) & 1ull) {
+                            const uint32_t pl = p0 + (uint32_t)tid;
+                            const uint64_t upto = hmask & ((2ull << lane) - 1ull);
+                            const uint32_t hidx = upto ? p0 + (uint32_t)w * 64u + (uint32_t)(63 - __builtin_clzll(upto)) : s_lh[e] - 1u;
+                            const uint32_t pos = xsum + s_cnt[e] + (uint32_t)__popcll(kmask & ((1ull << lane) - 1ull));
+                            F.new_slot[pos] = first + pl;
+                            F.new_grp[pos] = first + hidx;
                         }
                     }
                     LOCAL_CK(25)  // loop 2 (wave 0)
