@@ -1425,7 +1425,7 @@ __global__ __launch_bounds__(kThreads) void seg_copy_kernel(const uint32_t *__re
 #define NOLZSS_LOCAL_THREADS 768
 #endif
 #ifndef NOLZSS_LOCAL_ROWS
-#define NOLZSS_LOCAL_ROWS 25
+#define NOLZSS_LOCAL_ROWS 24
 #endif
 constexpr int kLocalThreads = NOLZSS_LOCAL_THREADS;
 constexpr int kLocalWaves = kLocalThreads / 64;
@@ -1451,7 +1451,11 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 template <int NW>
 __device__ __forceinline__ uint32_t block_scan_exclusive_add_lds(uint32_t v, uint32_t *lds, int w, int lane) {
     const uint32_t inc = wave_scan_inclusive_dpp(v, 0u, OpAdd<uint32_t>());
-    if (lane == 63) lds[w] = inc;
+    // (the address is made anew every time: hoisted out of the loop over the sub-buckets it was spilled, and the reload from
+    // scratch made the wave wait for every memory operation it had in flight, twice per sub-bucket)
+    int ww = w;
+    asm volatile("" : "+v"(ww));
+    if (lane == 63) lds[ww] = inc;
     lds_barrier();
     uint32_t prefix = 0;
 #pragma unroll
@@ -2173,7 +2177,7 @@ void radix_sort_dna_keys16(const PackedText &text, uint32_t *keys32[2], uint32_t
     // workgroup each and small enough to fit one (NOLZSS_NO_LOCAL_SORT, NOLZSS_LOCAL_SORT_MIN = smallest such text).
     static const bool no_local = getenv("NOLZSS_NO_LOCAL_SORT") != nullptr;
     static const size_t local_min = getenv("NOLZSS_LOCAL_SORT_MIN") ? (size_t)atoll(getenv("NOLZSS_LOCAL_SORT_MIN")) : (size_t(1) << 28);
-    const bool local = !no_local && !local_sort_off.load() && n >= local_min && n <= (size_t)kBins * kBins * kLocalCap / 8 * 7;
+    const bool local = !no_local && !local_sort_off.load() && n >= local_min && n <= (size_t)kBins * kBins * kLocalCap / 16 * 15;
     const int msd_to = local ? 0 : 1;
     // most significant digit first: the first four bases (bits 32..39 of [32 key bits][8-bit tag])
     if (text.segmented)
