@@ -58,8 +58,11 @@ __device__ __forceinline__ uint32_t lookback_exclusive(uint64_t *desc, uint32_t 
 
 // The same for sums with kWin windows of 64 descriptors per round trip, nearest first: a walk that goes back over a few
 // hundred tiles in flight (one workgroup per CU, every one of them a predecessor) takes one trip instead of four.
+// (spin_limit: polls before it gives up and sets err -- a caller whose tiles are NOT dealt out in start order passes a small
+// one: a tile in front may belong to a workgroup that is not resident yet, and the walk then has to end in a fallback)
 template <int kWin>
-__device__ __forceinline__ uint32_t lookback_exclusive_add_wide(uint64_t *desc, uint32_t tile, uint32_t aggregate, uint32_t *err) {
+__device__ __forceinline__ uint32_t lookback_exclusive_add_wide(uint64_t *desc, uint32_t tile, uint32_t aggregate, uint32_t *err,
+                                                                uint32_t spin_limit = kSpinLimit, bool *gave_up = nullptr) {
     const int lane = lane_id();
     if (tile == 0) {
         if (lane == 0) desc_store(desc, (2ull << 32) | aggregate);
@@ -95,8 +98,9 @@ __device__ __forceinline__ uint32_t lookback_exclusive_add_wide(uint64_t *desc, 
         }
         if (done) break;
         if (stalled) {
-            if (++spins > kSpinLimit) {  // (never hang the GPU)
+            if (++spins > spin_limit) {  // (never hang the GPU)
                 if (lane == 0) atomicExch(err, 1u);
+                if (gave_up) *gave_up = true;
                 return excl;
             }
             __builtin_amdgcn_s_sleep(1);

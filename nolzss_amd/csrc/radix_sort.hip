@@ -1530,6 +1530,11 @@ __device__ __forceinline__ void local_store(const uint32_t *s_stage, uint32_t *_
 // non-empty sub-bucket, lookback.hpp) and, for the LCP of its first boundary, the last key of the sub-bucket in front.
 // The keys are not written at all: 4 bytes per suffix less out, 4 less in, and a kernel less.
 constexpr uint32_t kLcpPendingCode = 0xffffffffu;  // (suffix_array.hip: kLcpPending)
+// The sub-buckets are dealt out statically (that is what lets a workgroup ask for the next one's keys a turn ahead), so a
+// look-back can wait for a workgroup that is not resident -- if another process or stream holds CUs with a kernel of its
+// own that waits the same way, for as long as it likes.  The walk therefore gives up after ~0.2 s (2^17 polls of a
+// microsecond and more); the host then sorts the text again with the plain kernel and the regroup kernel.
+constexpr uint32_t kLocalSpinLimit = 1u << 17;
 struct LocalFuse {
     uint32_t *lcp = nullptr, *new_slot = nullptr, *new_grp = nullptr, *d_total = nullptr;
     uint64_t *desc = nullptr;     // [non-empty sub-buckets] look-back descriptors of the numbers of tied elements
@@ -1602,6 +1607,14 @@ __device__ __forceinline__ void local_store_buf(const uint32_t *s_stage, uint32_
     __builtin_amdgcn_raw_buffer_store_b32(s_stage[on ? e : 0u], rsrc, on ? e * 4u : kOut, 0, 0);
 }
 
+// four zeros to LDS, the zeros made on the spot: kept in four registers from the start of the kernel they were spilled, and
+// the reload from scratch made the wave wait for every memory operation it had in flight, in every pass
+__device__ __forceinline__ void local_zero4(uint4 *p) {
+    uint32_t z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    *p = make_uint4(z, z, z, z);
+}
+
 template <int NPASS, bool kFuse = false>
 __global__ __launch_bounds__(kLocalThreads) void local_sort_kernel(
     const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint32_t *__restrict__ keys_out,
@@ -1625,12 +1638,13 @@ __global__ __launch_bounds__(kLocalThreads) void local_sort_kernel(
     // (kFuse) per 64 places in place order: tied elements, place of the last head + 1 (then their exclusive prefixes);
     // first key, last key, tied elements in front of the sub-bucket
     __shared__ uint32_t s_cnt[kFuse ? (kLocalRows + 4) * kLocalWaves + 64 : 1], s_lh[kFuse ? (kLocalRows + 4) * kLocalWaves + 64 : 1], s_edge[3];
+    __shared__ uint32_t s_giveup;
     __shared__ uint64_t s_mask[kFuse ? 2 * ((kLocalRows + 4) * kLocalWaves + 64) : 1];  // (kFuse) heads / tied elements of the 64 places, as lane masks
     const int tid = threadIdx.x;
     const int w = tid >> 6;
     const int lane = tid & 63;
     uint32_t *wcount = s_whist + w * kBins;  // this wave's counters: zeroed by the wave itself after every use
-    reinterpret_cast<uint4 *>(wcount)[lane] = make_uint4(0, 0, 0, 0);
+    local_zero4(reinterpret_cast<uint4 *>(wcount) + lane);
     static_assert(kBins == 256, "four counters per lane");
 
     uint32_t sub = blockIdx.x, first, count, cur_sub;
@@ -1638,6 +1652,8 @@ __global__ __launch_bounds__(kLocalThreads) void local_sort_kernel(
     uint32_t key[kLocalRows];
     local_load(keys_in, first, count, (int)((count + kLocalThreads - 1) / kLocalThreads), key, tid);
     bool order_ok = true;
+    bool preset_failure = false;  // (test hook NOLZSS_TEST_LOCAL_LOOKBACK_FAILS: the flag is up before the kernel starts)
+    if constexpr (kFuse) preset_failure = __hip_atomic_load(F.d_total + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
     while (count) {  // (uniform)
         // this sub-bucket's values (wanted when its keys have been ranked once) and the NEXT one's keys are asked for
         // before anything else (the values of the next one, too, took the registers over the edge: a prefetched value
@@ -1712,7 +1728,7 @@ __global__ __launch_bounds__(kLocalThreads) void local_sort_kernel(
 #pragma unroll
             for (int r = 0; r < kLocalRows; ++r)
                 if (r < rows) lrank[r] += wcount[digit_of(key[r], shift)];
-            reinterpret_cast<uint4 *>(wcount)[lane] = make_uint4(0, 0, 0, 0);  // (after the wave's own reads, before its next atomics)
+            local_zero4(reinterpret_cast<uint4 *>(wcount) + lane);  // (after the wave's own reads, before its next atomics)
             if constexpr (kFuse) {
                 if (pass + 1 == NPASS) {
                     // The last digit with the regroup of round 0 on the way.  The VALUES go first: their stores are
@@ -1816,17 +1832,22 @@ __global__ __launch_bounds__(kLocalThreads) void local_sort_kernel(
                         }
                         const uint32_t q = F.dense[cur_sub];
                         if (lane == 0) desc_store(F.lastkey + q, (1ull << 32) | (uint64_t)s_edge[1]);
-                        const uint32_t xs = lookback_exclusive_add_wide<4>(F.desc, q, total, F.d_total + 1);
+                        bool failed = preset_failure;
+                        const uint32_t xs = lookback_exclusive_add_wide<4>(F.desc, q, total, F.d_total + 1, kLocalSpinLimit, &failed);
                         if (lane == 0) {
                             s_edge[2] = xs;
+                            // (the look-back gave up: this workgroup stops behind this turn; the others give up on their own
+                            // next walk.  Looking at the flag in memory every turn cost 0.5 ms here, 13 ms at the top of the turn.)
+                            s_giveup = failed ? 1u : 0u;
                             if (q + 1u == F.nq) F.d_total[0] = xs + total;
                             uint32_t l0 = 0;  // (the very first suffix of the order)
                             if (q > 0u) {
                                 uint64_t d;
                                 uint32_t spins = 0;
                                 while (((d = desc_load(F.lastkey + (q - 1u))) >> 32) == 0) {
-                                    if (++spins > kSpinLimit) {  // (never hang the GPU)
+                                    if (++spins > kLocalSpinLimit) {  // (never hang the GPU)
                                         atomicExch(F.d_total + 1, 1u);
+                                        s_giveup = 1u;
                                         break;
                                     }
                                     __builtin_amdgcn_s_sleep(1);
@@ -1846,6 +1867,7 @@ __global__ __launch_bounds__(kLocalThreads) void local_sort_kernel(
                     LOCAL_CK(24)  // ... everybody
                     // Loop 2: the tied elements -- slot and slot of the group's head, in slot order
                     const uint32_t xsum = s_edge[2];
+                    const bool giveup = s_giveup != 0u;  // (uniform)
                     for (uint32_t p0 = 0, e = (uint32_t)w; p0 < count; p0 += kLocalThreads, e += kLocalWaves) {
                         const uint64_t hmask = s_mask[2 * e], kmask = s_mask[2 * e + 1];  // (wave-uniform)
                         if ((kmask >> lane) & 1ull) {
@@ -1860,6 +1882,7 @@ __global__ __launch_bounds__(kLocalThreads) void local_sort_kernel(
                     LOCAL_CK(25)  // loop 2 (wave 0)
                     lds_barrier();  // (the staging buffer is free again)
                     LOCAL_CK(26)  // ... everybody
+                    if (giveup) ncount = 0;  // (the loop over the sub-buckets ends)
                     continue;
                 }
             }
@@ -2021,6 +2044,8 @@ void local_sort_sub_buckets(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys
             uint64_t *dd = arena.alloc<uint64_t>(2 * (size_t)F.nq);
             HIP_CHECK(hipMemsetAsync(dd, 0, 2 * (size_t)F.nq * sizeof(uint64_t), stream));
             HIP_CHECK(hipMemsetAsync(rg->d_total, 0, 2 * sizeof(uint32_t), stream));
+            static const bool fail_lookback = getenv("NOLZSS_TEST_LOCAL_LOOKBACK_FAILS") != nullptr;  // (test hook: the way back)
+            if (fail_lookback) HIP_CHECK(hipMemsetAsync(rg->d_total + 1, 1, 1, stream));  // (the flag a look-back sets when it gives up)
             F.desc = dd; F.lastkey = dd + F.nq; F.dense = dense; F.prev_sub = prev_sub;
             {
                 ProfScope ps(prof, "rs_local_sort", stream, 16.0 * (double)n);  // (pairs in; suffixes and LCP out; the tied elements come on top)
@@ -2040,7 +2065,7 @@ void local_sort_sub_buckets(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys
                 rg->done = true;
                 return;
             }
-            if (h_t[1]) fprintf(stderr, "[nolzss] local_sort_kernel: look-back timed out; sorted again without the regroup on the way\n");
+            if (h_t[1] && !fail_lookback) fprintf(stderr, "[nolzss] local_sort_kernel: look-back timed out; sorted again without the regroup on the way\n");
             HIP_CHECK(hipMemsetAsync(ctl, 0, 4 * sizeof(uint32_t), stream));  // (a failed lane-order check shows again below)
         }
     }

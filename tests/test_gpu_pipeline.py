@@ -147,8 +147,10 @@ def test_sizes_around_tile_boundaries(native, n):
 
 
 @pytest.mark.parametrize("extra_env", [{}, {"NOLZSS_LOCAL_SORT_MIN": "1"},
-                                       {"NOLZSS_LOCAL_SORT_MIN": "1", "NOLZSS_TEST_LOCAL_ORDER_FAILS": "1"}],
-                         ids=["segmented-passes", "sub-buckets-in-lds", "sub-buckets-redone"])
+                                       {"NOLZSS_LOCAL_SORT_MIN": "1", "NOLZSS_TEST_LOCAL_ORDER_FAILS": "1"},
+                                       {"NOLZSS_LOCAL_SORT_MIN": "1", "NOLZSS_TEST_LOCAL_LOOKBACK_FAILS": "1"},
+                                       {"NOLZSS_LOCAL_SORT_MIN": "1", "NOLZSS_NO_LOCAL_REGROUP": "1"}],
+                         ids=["segmented-passes", "sub-buckets-in-lds", "sub-buckets-redone", "regroup-falls-back", "regroup-kernel"])
 def test_bucketed_key_sort_on_small_texts(extra_env):
     """The bucketed (most-significant-digit first) key sort normally starts at 2^20 bases; one child
     process with NOLZSS_DNA_FAST_MIN=1 runs it on small DNA cases: empty buckets, buckets smaller
@@ -156,7 +158,11 @@ def test_bucketed_key_sort_on_small_texts(extra_env):
     the form for 2^28 bases and more -- two most-significant-digit passes, the 65 536 sub-buckets sorted
     in LDS (local_sort_kernel) --, with sub-buckets beyond a workgroup's capacity (a run of 30 000 A's, a
     period-4 text) on the list for the segmented passes; NOLZSS_TEST_LOCAL_ORDER_FAILS pretends the
-    kernel's lane-order check failed, so every sub-bucket is redone by those passes."""
+    kernel's lane-order check failed, so every sub-bucket is redone by those passes.  Where no sub-bucket
+    overflows, that kernel also does the regroup of round 0 (heads, LCP from the keys, tied elements with a
+    look-back across the sub-buckets): NOLZSS_TEST_LOCAL_LOOKBACK_FAILS raises the flag a look-back sets
+    when it gives up (the text is sorted again by the plain kernel), NOLZSS_NO_LOCAL_REGROUP takes the
+    plain kernel and the regroup kernel from the start."""
     import os
     import subprocess
     import sys
