@@ -2028,7 +2028,11 @@ void local_sort_sub_buckets(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys
 #endif
     static const bool fail_order = getenv("NOLZSS_TEST_LOCAL_ORDER_FAILS") != nullptr;  // (test hook: the redo path)
     static const bool no_fuse = getenv("NOLZSS_NO_LOCAL_REGROUP") != nullptr;            // (A/B switch)
-    if (rg && !no_fuse && !fail_order && npass == 2 && num_sub % 1024u == 0) {
+    // (it pays where the regroup kernel is expensive -- many tied elements -- and the turns are long: 2^30 bases of the
+    // benchmark text 21.7 -> 20.0 ms for sort + regroup, but random DNA of 2^29 bases 10.7 -> 11.2 and of 2^28 bases 6.3 -> 7.5:
+    // the look-back and the two loops are a fixed cost per sub-bucket.  NOLZSS_LOCAL_REGROUP_MIN = smallest text that takes it.)
+    static const size_t fuse_min = getenv("NOLZSS_LOCAL_REGROUP_MIN") ? (size_t)atoll(getenv("NOLZSS_LOCAL_REGROUP_MIN")) : (size_t(3) << 28);
+    if (rg && !no_fuse && !fail_order && npass == 2 && num_sub % 1024u == 0 && n >= fuse_min) {
         // the regroup of round 0 on the way -- if no sub-bucket overflows a workgroup (the segmented passes that finish
         // those come after the kernel) and the kernel's checks hold; otherwise the plain form below runs from the same input
         uint32_t *dense = arena.alloc<uint32_t>(num_sub), *prev_sub = arena.alloc<uint32_t>(num_sub), *info = arena.alloc<uint32_t>(2);

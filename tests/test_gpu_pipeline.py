@@ -202,7 +202,8 @@ print("ok", len(cases))
 '''
     # (NOLZSS_TEST_INJECT_PENDING: one LCP entry per text is left "pending" on purpose, so the safety
     # net that compares those suffixes in the packed text runs as well)
-    env = dict(os.environ, NOLZSS_DNA_FAST_MIN="1", NOLZSS_TEST_INJECT_PENDING="1", **extra_env)
+    # (NOLZSS_LOCAL_REGROUP_MIN=1: the regroup on the way normally starts at 3 * 2^28 bases)
+    env = dict(os.environ, NOLZSS_DNA_FAST_MIN="1", NOLZSS_TEST_INJECT_PENDING="1", NOLZSS_LOCAL_REGROUP_MIN="1", **extra_env)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
