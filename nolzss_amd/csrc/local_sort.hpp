@@ -263,14 +263,13 @@ __global__ __launch_bounds__(kLocalThreads) void local_sort_kernel(
         // before anything else (the values of the next one, too, took the registers over the edge: a prefetched value
         // that is spilled is a value waited for)
         const int rows = (int)((count + kLocalThreads - 1) / kLocalThreads);
-        uint32_t val[kLocalRows];
-        local_load(vals_in, first, count, rows, val, tid);
-        uint32_t nfirst, ncount, next_sub;
-        local_next(sub_start, num_sub, sub, nfirst, ncount, ctl, large_list, tid, next_sub);
-        uint32_t nkey[kLocalRows];
-        LOCAL_CK(0)  // values asked for, the next sub-bucket found
-        local_load(keys_in, nfirst, ncount, (int)((ncount + kLocalThreads - 1) / kLocalThreads), nkey, tid);  // (ncount = 0: the first key of the array, 25 times)
-        LOCAL_CK(1)  // its keys asked for
+        uint32_t val[kLocalRows], nkey[kLocalRows];
+        uint32_t nfirst = 0, ncount = 0, next_sub = 0;
+        if constexpr (kFuse) {  // (the form with the regroup on the way has no register to spare for the later place below)
+            local_load(vals_in, first, count, rows, val, tid);
+            local_next(sub_start, num_sub, sub, nfirst, ncount, ctl, large_list, tid, next_sub);
+            local_load(keys_in, nfirst, ncount, (int)((ncount + kLocalThreads - 1) / kLocalThreads), nkey, tid);
+        }
 
         const uint32_t wbase = (uint32_t)w * (uint32_t)(rows * 64) + (uint32_t)lane;
         // the sorted pairs lie in the staging buffer from element `skew` = first & 3 on: a 16-byte quad of the buffer is a
@@ -292,6 +291,16 @@ __global__ __launch_bounds__(kLocalThreads) void local_sort_kernel(
 #pragma unroll
             for (int r = 0; r < kLocalRows; ++r)
                 if (r < rows) lrank[r] = atomicAdd(&wcount[digit_of(key[r], shift)], 1u);
+            if (pass == 0 && !kFuse) {
+                // This sub-bucket's values and the next one's keys are asked for HERE, behind the first ranking's atomics:
+                // finding the next sub-bucket (two scalar loads) and issuing 48 loads took 8 k cycles at the start of
+                // every turn with nothing else in flight.
+                local_load(vals_in, first, count, rows, val, tid);
+                local_next(sub_start, num_sub, sub, nfirst, ncount, ctl, large_list, tid, next_sub);
+                LOCAL_CK(0)  // values asked for, the next sub-bucket found
+                local_load(keys_in, nfirst, ncount, (int)((ncount + kLocalThreads - 1) / kLocalThreads), nkey, tid);  // (ncount = 0: the first key of the array, 24 times)
+                LOCAL_CK(1)  // its keys asked for
+            }
             {  // the lane-order check on row 0 (its counters started at zero)
                 const uint32_t d = digit_of(key[0], shift);
                 uint32_t diff_lo = 0, diff_hi = 0;
