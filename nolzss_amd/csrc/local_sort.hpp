@@ -386,19 +386,19 @@ __global__ __launch_bounds__(kLocalThreads) void local_sort_kernel(
                             const uint32_t pk = (uint32_t)__builtin_amdgcn_update_dpp((int)edge[u], (int)k[u], 0x138, 0xf, 0xf, false);  // wave_shr:1
                             const uint32_t nk = (uint32_t)__builtin_amdgcn_update_dpp((int)edge[u], (int)k[u], 0x130, 0xf, 0xf, false);  // wave_shl:1
                             // (a suffix that ends inside the key window -- tag < 16 -- ties with nobody: a head, and so is
-                            // whoever follows it; the first place of a sub-bucket is a head, and so is the one behind its last)
-                            const bool head = valid && (pl == 0u || k[u] != pk || (k[u] & 0xffu) < (uint32_t)kP16Syms);
-                            const bool nhead = pl + 1u >= count || nk != k[u] || (nk & 0xffu) < (uint32_t)kP16Syms;
-                            const bool keep = valid && !(head && nhead);
-                            if (valid && pl > 0u) {  // (place 0: below, with the last key of the sub-bucket in front)
-                                uint32_t l = kLcpPendingCode;
-                                if (head) {
-                                    const uint32_t y = (k[u] ^ pk) >> kP16TagBits, ta = k[u] & 0xffu, tb = pk & 0xffu;
-                                    uint32_t ls = y ? (uint32_t)__builtin_clz(y) >> 1 : 0xffffffffu;
-                                    ls = ls < ta ? ls : ta;
-                                    l = ls < tb ? ls : tb;
-                                }
-                                F.lcp[first + pl] = l;
+                            // whoever follows it; the first place of a sub-bucket is a head, and so is the one behind its last.
+                            // Bitwise & and | on purpose: with && and || every condition became a branch on the lane mask,
+                            // a hundred instructions per row of places.)
+                            const bool head = valid & ((pl == 0u) | (k[u] != pk) | ((k[u] & 0xffu) < (uint32_t)kP16Syms));
+                            const bool nhead = (pl + 1u >= count) | (nk != k[u]) | ((nk & 0xffu) < (uint32_t)kP16Syms);
+                            const bool keep = valid & !(head & nhead);
+                            {  // (place 0: below, with the last key of the sub-bucket in front)
+                                const uint32_t y = (k[u] ^ pk) >> kP16TagBits, ta = k[u] & 0xffu, tb = pk & 0xffu;
+                                uint32_t ls = (uint32_t)__clz((int)y) >> 1;  // (y = 0: 16, and no tag is larger)
+                                ls = ls < ta ? ls : ta;
+                                ls = ls < tb ? ls : tb;
+                                const uint32_t l = head ? ls : kLcpPendingCode;
+                                if (valid & (pl > 0u)) F.lcp[first + pl] = l;
                             }
                             const uint64_t hmask = __ballot(head), kmask = __ballot(keep);
                             if (lane == 0) {
