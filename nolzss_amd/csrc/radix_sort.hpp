@@ -97,6 +97,9 @@ void radix_sort_dna_keys(const PackedText &text, uint32_t *keys32[2], uint32_t *
 // Plain one-segment 2-bit DNA, 16-base key (text.hpp, kP16Syms): the most-significant-digit pass from the text
 // and THREE segmented passes over the 24 key bits above the tag byte of the stored word [24 key bits][8-bit tag].
 // The sorted words end in keys32[0], the suffixes in vals[0].  8 + 3 * 16 bytes of scatter traffic per suffix.
+// Texts of 2^28 .. 1.13 * 10^9 suffixes: ONE segmented pass, then the 65 536 sub-buckets sorted in LDS (local_sort.hpp:
+// local_sort_kernel) -- 8 + 16 + 16 bytes per suffix; from 3 * 2^28 suffixes up that kernel can do the regroup of round 0
+// on the way (Round0Regroup below: the keys are then not written at all).
 // (also segmented texts with a terminator table of at most kTermFew entries and segments of at least 16 symbols -- a
 // prepared reverse-complement string --: key16_applicable says whether a text takes this sort)
 bool key16_applicable(const PackedText &text);
